@@ -1,0 +1,97 @@
+"""ctypes binding of libcppf_hip.so (C ABI in include/cppf_hip.h).
+
+There is no CPU fallback: if the library is missing the import of any op fails loudly with
+instructions to build it.  The library is kept in-tree (cppf2_amd/libcppf_hip.so).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
+
+ABI_VERSION = 1
+
+
+class CppfError(RuntimeError):
+    pass
+
+
+class SceneGrid(C.Structure):
+    _fields_ = [("c0", C.c_float * 3), ("g", C.c_int32 * 3), ("ncell", C.c_int32), ("flags", C.c_int32)]
+
+
+class SceneResult(C.Structure):
+    _fields_ = [("argmax", C.c_int64), ("t", C.c_double * 3), ("R", C.c_double * 9), ("scale", C.c_float * 3),
+                ("peak", C.c_uint32), ("up_idx", C.c_int32), ("right_idx", C.c_int32), ("kept", C.c_int32),
+                ("up_count", C.c_float), ("right_count", C.c_float), ("flags", C.c_int32), ("ncell", C.c_int32), ("pad_", C.c_int32 * 3)]
+
+
+assert C.sizeof(SceneGrid) == 32
+assert C.sizeof(SceneResult) == 160
+
+_p = C.c_void_p
+_i = C.c_int
+_i32 = C.c_int32
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_f = C.c_float
+_d = C.c_double
+
+# name -> (restype, argtypes); must list every symbol include/cppf_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "cppf_version": (_i, []),
+    "cppf_last_error_string": (C.c_char_p, []),
+    "cppf_sample_tuples": (_i, [_i, _p, _p, _i, _i, _u64, _i32, _i32, _p, _p]),
+    "cppf_philox_uniform": (_i, [_i, _p, _i, _i, _u64, _i32, _i32, _i32, _p, _p]),
+    "cppf_shot352_workspace_bytes": (_i64, [_i64]),
+    "cppf_shot352": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i64, _p]),
+    "cppf_estimate_normals": (_i, [_i, _p, _p, _i64, _f, _p, _p]),
+    "cppf_encode_tuples_shot": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
+    "cppf_encode_tuples_coord": (_i, [_i, _p, _p, _i, _p, _p, _i64, _p, _i, _p]),
+    "cppf_decode_bins": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "cppf_generate_target_pairs": (_i, [_i, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    "cppf_scene_bounds": (_i, [_i, _p, _p, _f, _p, _p]),
+    "cppf_vote_center_workspace_bytes": (_i64, [_i, _i64]),
+    "cppf_vote_center": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _d, _i, _p, _p, _p, _p, _p, _i64, _i, _p, _i64,
+                              _p, _p, _p, _p]),
+    "cppf_backvote_workspace_bytes": (_i64, [_i64, _i]),
+    "cppf_backvote_filter": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _p, _p,
+                                  _p, _i64, _p]),
+    "cppf_rot_bins_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "cppf_rot_bins": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _i,
+                           _p, _p, _p, _p, _i64, _p]),
+    "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),
+    "cppf_assemble_pose": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once; raises CppfError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CppfError(
+            "libcppf_hip.so not found at %s -- build it with `python -m cppf2_amd.build` "
+            "(hipcc --offload-arch=gfx950).  cppf2_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.cppf_version()
+    if v != ABI_VERSION:
+        raise CppfError("libcppf_hip.so ABI version %d != expected %d; rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().cppf_last_error_string()
+        raise CppfError("%s failed with status %d: %s" % (what, status, (msg or b"").decode("utf-8", "replace")))

@@ -1,0 +1,51 @@
+"""Builds libcppf_hip.so (hipcc, gfx950) in-tree.  Used by __graft_entry__.build() and `python -m cppf2_amd.build`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libcppf_hip.so")
+SOURCES = ["cppf_core.hip", "cppf_vote.hip", "cppf_shot.hip"]
+# -ffp-contract=off: every float op rounds where it is written (bit-exact vote grid); fused ops are explicit fmaf().
+# -munsafe-fp-atomics: native ds/global float64 atomic add for the rotation-bin partial sums.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+         "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    inc = os.path.join(ROOT, "include")
+    hdrs = [os.path.join(inc, "cppf_hip.h"), os.path.join(CSRC, "cppf_common.h")]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-I", inc, "-I", CSRC, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,149 @@
+// Shared device helpers for libcppf_hip.so (gfx950 only; compiled with -ffp-contract=off so that
+// every float op below rounds exactly where it is written; fused operations are explicit fmaf()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cppf_hip.h"
+
+#define CPPF_WAVE 64
+
+extern thread_local char g_cppf_err[256];
+
+#define CPPF_CHECK_ARG(cond)                                                                  \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: invalid argument: %s", __func__, #cond);   \
+      return CPPF_EINVAL;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define CPPF_HIP(call)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: %s failed: %s", __func__, #call,           \
+               hipGetErrorString(e_));                                                        \
+      return CPPF_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+#define CPPF_LAUNCH_CHECK()                                                                   \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess) {                                                                   \
+      snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: kernel launch failed: %s", __func__,       \
+               hipGetErrorString(e_));                                                        \
+      return CPPF_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+struct Axes9 {
+  double a[9];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Stream layout shared with oracle/cppf_oracle.py and
+// cppf2_amd/synth.py: counter = (row, word-block, scene id, stream id), key = (seed lo, seed hi).
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Geometry shared by vote_center / vote_rotation (train_dino.py:176-192, 219-232).
+// The torch-CPU reference fuses exactly three things (probed; see oracle/cppf_oracle.py):
+//   torch.norm over 3 -> sqrt(fma(z,z, fma(y,y, x*x)));  torch.cross -> fma(a,b, -(c*d));
+//   mm with K=3 -> fma(a2,b2, fma(a1,b1, a0*b0)).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float norm3_fused(float x, float y, float z) {
+  return __fsqrt_rn(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+__device__ __forceinline__ float cross_term(float a, float b, float c, float d) {
+  return fmaf(a, b, -(c * d));
+}
+
+struct PairFrame {
+  float ux, uy, uz;   // unit pair direction (a-b)/max(|a-b|,1e-7)
+  float ax, ay, az;   // first point of the pair
+  float cox, coy, coz;  // perpendicular seed (un-normalised)
+  float nrm;          // |a-b|
+  float nco;          // |co|
+};
+
+__device__ __forceinline__ PairFrame pair_frame(const float* __restrict__ p, int i0, int i1) {
+  PairFrame f;
+  f.ax = p[3 * i0 + 0]; f.ay = p[3 * i0 + 1]; f.az = p[3 * i0 + 2];
+  const float bx = p[3 * i1 + 0], by = p[3 * i1 + 1], bz = p[3 * i1 + 2];
+  const float dx = f.ax - bx, dy = f.ay - by, dz = f.az - bz;
+  f.nrm = norm3_fused(dx, dy, dz);
+  const float den = fmaxf(f.nrm, 1e-7f);
+  f.ux = dx / den; f.uy = dy / den; f.uz = dz / den;
+  // co = (0, -u_z, u_y); if |co| < 1e-7 use (-u_y, u_x, 0)   (train_dino.py:187-189)
+  f.cox = 0.0f; f.coy = -f.uz; f.coz = f.uy;
+  f.nco = norm3_fused(f.cox, f.coy, f.coz);
+  if (f.nco < 1e-7f) {
+    f.cox = -f.uy; f.coy = f.ux; f.coz = 0.0f;
+    f.nco = norm3_fused(f.cox, f.coy, f.coz);
+  }
+  return f;
+}
+
+// dataset.py:118-135 on one pair (a, b) and a centre, with axes a1..a3; all in the reference's dtypes.
+__device__ __forceinline__ void target_pair(float ax, float ay, float az, float bx, float by, float bz,
+                                            double cx, double cy, double cz, const double* __restrict__ axes,
+                                            float* tr2, float* rot3) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  const float n = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);      // np.linalg.norm: un-fused
+  const float den = n + 1e-7f;
+  const double ux = (double)(dx / den), uy = (double)(dy / den), uz = (double)(dz / den);
+  const double acx = (double)ax - cx, acy = (double)ay - cy, acz = (double)az - cz;
+  const double proj = (acx * ux + acy * uy) + acz * uz;
+  const double ox = acx - proj * ux, oy = acy - proj * uy, oz = acz - proj * uz;
+  const double dist = sqrt((ox * ox + oy * oy) + oz * oz);
+  if (tr2) { tr2[0] = (float)proj; tr2[1] = (float)dist; }
+  if (rot3) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double d = (ux * axes[3 * a + 0] + uy * axes[3 * a + 1]) + uz * axes[3 * a + 2];
+      rot3[a] = (float)acos(d);
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_lane() { return threadIdx.x & (CPPF_WAVE - 1); }
+
+// first-maximum reduction on (value, index) pairs: larger value wins, ties -> smaller index.
+__device__ __forceinline__ void argmax_combine(uint32_t& v, int64_t& i, uint32_t ov, int64_t oi) {
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__device__ __forceinline__ void wave_argmax(uint32_t& v, int64_t& i) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t ov = __shfl_xor(v, off);
+    const int64_t oi = __shfl_xor(i, off);
+    argmax_combine(v, i, ov, oi);
+  }
+}

@@ -1,0 +1,419 @@
+// cppf_core.hip -- sampler, scene bounds, tuple encode, bin decode, vote-parameter decode.
+// gfx950 only.  See include/cppf_hip.h for the contract of each entry point.
+#include "cppf_common.h"
+
+thread_local char g_cppf_err[256] = "";
+
+extern "C" int cppf_version(void) { return CPPF_ABI_VERSION; }
+extern "C" const char* cppf_last_error_string(void) { return g_cppf_err; }
+
+// scene lookup for flattened rows: largest b with off[b] <= row (B is small: linear/binary search in L1)
+__device__ __forceinline__ int find_scene(const int32_t* __restrict__ off, int B, int64_t row) {
+  int lo = 0, hi = B;   // invariant: off[lo] <= row < off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)off[mid] <= row) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1. tuple sampler
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_tuples_kernel(int B, const int32_t* __restrict__ pt_off,
+                                                            const int32_t* __restrict__ tup_off, int k,
+                                                            uint32_t key0, uint32_t key1, int32_t sid_base,
+                                                            int32_t sid_stride, int32_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const uint32_t n = (uint32_t)(pt_off[b + 1] - pt_off[b]);
+  const uint32_t sid = (uint32_t)(sid_base + b * sid_stride);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+    int32_t* row = out + (int64_t)(t0 + t) * k;
+    for (int blk = 0; blk * 4 < k; ++blk) {
+      const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, 0u, key0, key1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (blk * 4 + j < k) row[blk * 4 + j] = (int32_t)(((uint64_t)w.v[j] * n) >> 32);
+    }
+  }
+}
+
+extern "C" int cppf_sample_tuples(int B, const int32_t* pt_off, const int32_t* tup_off, int max_t, int k,
+                                  uint64_t seed, int32_t scene_id_base, int32_t scene_id_stride,
+                                  int32_t* out_idx, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pt_off && tup_off && out_idx);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  if (max_t <= 0) return CPPF_OK;
+  dim3 grid((max_t + 255) / 256, B);
+  hipLaunchKernelGGL(sample_tuples_kernel, grid, dim3(256), 0, (hipStream_t)stream, B, pt_off, tup_off, k,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), scene_id_base, scene_id_stride, out_idx);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+__global__ __launch_bounds__(256) void philox_uniform_kernel(int B, const int32_t* __restrict__ tup_off, int m,
+                                                             uint32_t key0, uint32_t key1, int32_t sid_base,
+                                                             int32_t sid_stride, uint32_t stream_id,
+                                                             float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const uint32_t sid = (uint32_t)(sid_base + b * sid_stride);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+    float* row = out + (int64_t)(t0 + t) * m;
+    for (int blk = 0; blk * 4 < m; ++blk) {
+      const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, stream_id, key0, key1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (blk * 4 + j < m) row[blk * 4 + j] = (float)(w.v[j] >> 8) * 5.9604644775390625e-8f;  // 2^-24
+    }
+  }
+}
+
+extern "C" int cppf_philox_uniform(int B, const int32_t* tup_off, int max_t, int m, uint64_t seed,
+                                   int32_t scene_id_base, int32_t scene_id_stride, int32_t stream_id,
+                                   float* out, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && tup_off && out);
+  CPPF_CHECK_ARG(m >= 1 && m <= 8);
+  if (max_t <= 0) return CPPF_OK;
+  dim3 grid((max_t + 255) / 256, B);
+  hipLaunchKernelGGL(philox_uniform_kernel, grid, dim3(256), 0, (hipStream_t)stream, B, tup_off, m,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), scene_id_base, scene_id_stride,
+                     (uint32_t)stream_id, out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scene bounds (train_dino.py:172-173): one workgroup per scene, min/max over the cloud.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scene_bounds_kernel(const float* __restrict__ pts,
+                                                           const int32_t* __restrict__ pt_off, float res,
+                                                           CppfSceneGrid* __restrict__ out) {
+  const int b = blockIdx.x;
+  const int p0 = pt_off[b], n = pt_off[b + 1] - p0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = pts[3 * (int64_t)(p0 + i) + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+  }
+  __shared__ float s_mn[4][3], s_mx[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
+    }
+  }
+  const int w = threadIdx.x >> 6;
+  if (wave_lane() == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_mn[w][c] = mn[c]; s_mx[w][c] = mx[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    CppfSceneGrid g;
+    int64_t cells = 1;
+    g.flags = (n <= 0) ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float lo = fminf(fminf(s_mn[0][c], s_mn[1][c]), fminf(s_mn[2][c], s_mn[3][c]));
+      const float hi = fmaxf(fmaxf(s_mx[0][c], s_mx[1][c]), fmaxf(s_mx[2][c], s_mx[3][c]));
+      g.c0[c] = lo;
+      const float q = (hi - lo) / res;                 // float32 division, then .long() truncation
+      int gi = (n > 0 && q < 2.0e9f) ? (int)q + 1 : 0;
+      g.g[c] = gi;
+      cells *= (int64_t)gi;
+    }
+    if (cells > 0x7fffffffLL) { g.flags |= 2; cells = 0; }
+    if (n <= 0) cells = 0;
+    g.ncell = (int32_t)cells;
+    out[b] = g;
+  }
+}
+
+extern "C" int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off, float res, CppfSceneGrid* out,
+                                 void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && out);
+  CPPF_CHECK_ARG(res > 0.0f);
+  hipLaunchKernelGGL(scene_bounds_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pts, pt_off, res, out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3. tuple encode.  One thread per float4 of an output row: rows are 16-byte aligned whenever
+// row_len % 4 == 0 (360 for the SHOT model), so every store is a coalesced dwordx4; the feature
+// table [n, feat_dim] is small (1 MB/scene) and served by L2.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+struct Combos {
+  static constexpr int NP = K * (K - 1) / 2;
+};
+
+__device__ __forceinline__ void combo_of(int q, int k, int& i, int& j) {
+  // q-th pair of itertools.combinations(range(k), 2)
+  i = 0;
+  int rem = q;
+  while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+  j = i + 1 + rem;
+}
+
+__device__ __forceinline__ float encode_scalar(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                               const int32_t* __restrict__ row_idx, int p0, int k, int np, int f) {
+  if (f < 3 * np) {
+    int i, j;
+    combo_of(f / 3, k, i, j);
+    const int c = f % 3;
+    return pts[3 * (int64_t)(p0 + row_idx[i]) + c] - pts[3 * (int64_t)(p0 + row_idx[j]) + c];
+  }
+  int i, j;
+  combo_of(f - 3 * np, k, i, j);
+  const float* ni = nrm + 3 * (int64_t)(p0 + row_idx[i]);
+  const float* nj = nrm + 3 * (int64_t)(p0 + row_idx[j]);
+  const float s = (ni[0] * nj[0] + ni[1] * nj[1]) + ni[2] * nj[2];
+  // max(sum(n_i*n_j), sum(-n_i*n_j)): the second sum is exactly -s (negation commutes with rounding)
+  return fmaxf(s, -s);
+}
+
+__global__ __launch_bounds__(256) void encode_shot_kernel(int B, const float* __restrict__ pts,
+                                                          const float* __restrict__ nrm,
+                                                          const float* __restrict__ feat, int feat_dim,
+                                                          const int32_t* __restrict__ idx, int k,
+                                                          const int32_t* __restrict__ pt_off,
+                                                          const int32_t* __restrict__ tup_off, int64_t total,
+                                                          float* __restrict__ out) {
+  const int np = k * (k - 1) / 2;
+  const int head = 4 * np;                       // coord (3np) + normal (np) scalars
+  const int row_len = head + k * feat_dim;
+  const int vec_per_row = row_len >> 2;          // row_len % 4 == 0 checked by the host
+  const int64_t nvec = total * vec_per_row;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / vec_per_row;
+    const int c = (int)(v - t * vec_per_row);
+    const int b = find_scene(tup_off, B, t);
+    const int p0 = pt_off[b];
+    const int32_t* row_idx = idx + t * k;
+    float4 o;
+    const int f0 = c * 4;
+    if (f0 >= head) {
+      const int ff = f0 - head;
+      const int kk = ff / feat_dim;
+      const int col = ff - kk * feat_dim;
+      o = *reinterpret_cast<const float4*>(feat + (int64_t)(p0 + row_idx[kk]) * feat_dim + col);
+    } else {
+      o.x = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 0);
+      o.y = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 1);
+      o.z = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 2);
+      o.w = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 3);
+    }
+    *reinterpret_cast<float4*>(out + t * row_len + f0) = o;
+  }
+}
+
+extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* normals, const float* feat,
+                                       int feat_dim, const int32_t* idx, int k, const int32_t* pt_off,
+                                       const int32_t* tup_off, int64_t total_tuples, float* out, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && normals && feat && idx && pt_off && tup_off && out);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  CPPF_CHECK_ARG(feat_dim > 0 && feat_dim % 4 == 0);
+  const int np = k * (k - 1) / 2;
+  if (total_tuples <= 0) return CPPF_OK;
+  const int64_t nvec = total_tuples * ((4 * np + k * feat_dim) / 4);
+  const int64_t blocks = (nvec + 255) / 256;
+  const int grid = (int)(blocks < 256 * 64 ? blocks : 256 * 64);
+  hipLaunchKernelGGL(encode_shot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, pts, normals, feat,
+                     feat_dim, idx, k, pt_off, tup_off, total_tuples, out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+__global__ __launch_bounds__(256) void encode_coord_kernel(int B, const float* __restrict__ pts,
+                                                           const int32_t* __restrict__ idx, int k,
+                                                           const int32_t* __restrict__ pt_off,
+                                                           const int32_t* __restrict__ tup_off, int64_t total,
+                                                           float* __restrict__ out, int out_stride) {
+  const int np = k * (k - 1) / 2;
+  const int per_row = 3 * np;
+  const int64_t n = total * per_row;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / per_row;
+    const int f = (int)(v - t * per_row);
+    const int b = find_scene(tup_off, B, t);
+    const int p0 = pt_off[b];
+    const int32_t* row_idx = idx + t * k;
+    int i, j;
+    combo_of(f / 3, k, i, j);
+    const int c = f % 3;
+    out[t * out_stride + f] = pts[3 * (int64_t)(p0 + row_idx[i]) + c] - pts[3 * (int64_t)(p0 + row_idx[j]) + c];
+  }
+}
+
+extern "C" int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
+                                        const int32_t* tup_off, int64_t total_tuples, float* out, int out_stride,
+                                        void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && idx && pt_off && tup_off && out);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  CPPF_CHECK_ARG(out_stride >= 3 * (k * (k - 1) / 2));
+  if (total_tuples <= 0) return CPPF_OK;
+  const int64_t n = total_tuples * 3 * (k * (k - 1) / 2);
+  const int64_t blocks = (n + 255) / 256;
+  const int grid = (int)(blocks < 256 * 64 ? blocks : 256 * 64);
+  hipLaunchKernelGGL(encode_coord_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, pts, idx, k, pt_off,
+                     tup_off, total_tuples, out, out_stride);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4 + a5. bin decode fused with generate_target_pairs.
+// Workgroup = 192 threads = 32 tuples x 6 coordinates: phase 1, one thread per (tuple, coord) reads its
+// 32 logits (one 128-byte line), softmax-weights them and draws a bin by inverse CDF; phase 2, one thread
+// per tuple assembles the pair, the metric scale and the float64 vote parameters.
+// ---------------------------------------------------------------------------------------------
+#define DEC_TUPLES 32
+#define DEC_MAX_NB 4096
+
+// NB > 0: bin count known at compile time, the CDF lives in registers.  NB == 0: generic bin count,
+// three passes over the (L1-resident) logit line instead of a runtime-indexed array (which would spill).
+template <int NB>
+__global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
+    int B, const float* __restrict__ logits, int nb_rt, const float* __restrict__ uniforms,
+    const float* __restrict__ pts, const int32_t* __restrict__ idx, int k, const int32_t* __restrict__ pt_off,
+    const int32_t* __restrict__ tup_off, int64_t total, Axes9 axes, int32_t* __restrict__ bins,
+    float* __restrict__ scaled, float* __restrict__ scale_out, float* __restrict__ tr, float* __restrict__ rot) {
+  __shared__ int s_bin[DEC_TUPLES * 6];
+  const int nb = NB > 0 ? NB : nb_rt;
+  const int64_t tbase = (int64_t)blockIdx.x * DEC_TUPLES;
+  {
+    const int lt = threadIdx.x / 6, c = threadIdx.x - lt * 6;
+    const int64_t t = tbase + lt;
+    int bin = 0;
+    if (t < total) {
+      const float* lg = logits + (t * 6 + c) * nb;
+      int cnt = 0;
+      if constexpr (NB > 0) {
+        float e[NB];
+        const float4* lg4 = reinterpret_cast<const float4*>(lg);
+#pragma unroll
+        for (int j = 0; j < NB / 4; ++j) {
+          const float4 v = lg4[j];
+          e[4 * j + 0] = v.x; e[4 * j + 1] = v.y; e[4 * j + 2] = v.z; e[4 * j + 3] = v.w;
+        }
+        float m = e[0];
+#pragma unroll
+        for (int j = 1; j < NB; ++j) m = fmaxf(m, e[j]);
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { acc += expf(e[j] - m); e[j] = acc; }   // running f32 CDF
+        const float target = uniforms[t * 6 + c] * acc;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cnt += (e[j] <= target) ? 1 : 0;        // first j with cdf[j] > target
+      } else {
+        float m = lg[0];
+        for (int j = 1; j < nb; ++j) m = fmaxf(m, lg[j]);
+        float acc = 0.0f;
+        for (int j = 0; j < nb; ++j) acc += expf(lg[j] - m);
+        const float target = uniforms[t * 6 + c] * acc;
+        float run = 0.0f;
+        for (int j = 0; j < nb; ++j) { run += expf(lg[j] - m); cnt += (run <= target) ? 1 : 0; }
+      }
+      bin = cnt < nb - 1 ? cnt : nb - 1;
+      if (bins) bins[t * 6 + c] = bin;
+    }
+    s_bin[threadIdx.x] = bin;
+  }
+  __syncthreads();
+  if (threadIdx.x < DEC_TUPLES) {
+    const int64_t t = tbase + threadIdx.x;
+    if (t >= total) return;
+    const int b = find_scene(tup_off, B, t);
+    const int p0 = pt_off[b];
+    const int i0 = idx[t * k + 0], i1 = idx[t * k + 1];
+    float pr[6];
+    const float den = (float)(nb - 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pr[c] = (float)s_bin[threadIdx.x * 6 + c] / den - 0.5f;   // eval.py:230
+    // real pair length: np.linalg.norm(input_pairs[:,1]-input_pairs[:,0]) (un-fused f32), eval.py:233
+    const float* pa = pts + 3 * (int64_t)(p0 + i0);
+    const float* pb = pts + 3 * (int64_t)(p0 + i1);
+    const float rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
+    const float real_len = __fsqrt_rn((rx * rx + ry * ry) + rz * rz);
+    // predicted pair length: torch.norm (fused), clamp_min 1e-7, eval.py:234
+    const float pred_len = norm3_fused(pr[3] - pr[0], pr[4] - pr[1], pr[5] - pr[2]);
+    const float sc = real_len / fmaxf(pred_len, 1e-7f);
+    float ps[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ps[c] = pr[c] * sc;                                        // eval.py:235
+    if (scale_out) scale_out[t] = sc;
+    if (scaled) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) scaled[t * 6 + c] = ps[c];
+    }
+    float tr2[2], rot3[3];
+    target_pair(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], 0.0, 0.0, 0.0, axes.a, tr2, rot3);
+    if (tr) { tr[t * 2 + 0] = tr2[0]; tr[t * 2 + 1] = tr2[1]; }
+    if (rot) { rot[t * 3 + 0] = rot3[0]; rot[t * 3 + 1] = rot3[1]; rot[t * 3 + 2] = rot3[2]; }
+  }
+}
+
+extern "C" int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
+                                const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                                int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,
+                                float* scale, float* tr, float* rot, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && logits && uniforms && pts && idx && pt_off && tup_off && h_axes);
+  CPPF_CHECK_ARG(nb >= 2 && nb <= DEC_MAX_NB);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  if (total_tuples <= 0) return CPPF_OK;
+  Axes9 ax;
+  for (int i = 0; i < 9; ++i) ax.a[i] = h_axes[i];
+  const int64_t blocks = (total_tuples + DEC_TUPLES - 1) / DEC_TUPLES;
+  if (nb == 32)
+    hipLaunchKernelGGL(decode_bins_kernel<32>, dim3((unsigned)blocks), dim3(DEC_TUPLES * 6), 0, (hipStream_t)stream,
+                       B, logits, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
+                       tr, rot);
+  else
+    hipLaunchKernelGGL(decode_bins_kernel<0>, dim3((unsigned)blocks), dim3(DEC_TUPLES * 6), 0, (hipStream_t)stream,
+                       B, logits, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
+                       tr, rot);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+__global__ __launch_bounds__(256) void target_pairs_kernel(int B, const float* __restrict__ pairs,
+                                                           const int32_t* __restrict__ tup_off, int64_t total,
+                                                           Axes9 axes, const double* __restrict__ centers,
+                                                           float* __restrict__ tr, float* __restrict__ rot) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    if (centers) {
+      const int b = find_scene(tup_off, B, t);
+      cx = centers[3 * b + 0]; cy = centers[3 * b + 1]; cz = centers[3 * b + 2];
+    }
+    const float* p = pairs + t * 6;
+    float tr2[2], rot3[3];
+    target_pair(p[0], p[1], p[2], p[3], p[4], p[5], cx, cy, cz, axes.a, tr2, rot3);
+    if (tr) { tr[t * 2 + 0] = tr2[0]; tr[t * 2 + 1] = tr2[1]; }
+    if (rot) { rot[t * 3 + 0] = rot3[0]; rot[t * 3 + 1] = rot3[1]; rot[t * 3 + 2] = rot3[2]; }
+  }
+}
+
+extern "C" int cppf_generate_target_pairs(int B, const float* pairs, const int32_t* tup_off, int64_t total_tuples,
+                                          const double* h_axes, const double* centers, float* tr, float* rot,
+                                          void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pairs && tup_off && h_axes);
+  if (total_tuples <= 0) return CPPF_OK;
+  Axes9 ax;
+  for (int i = 0; i < 9; ++i) ax.a[i] = h_axes[i];
+  const int64_t blocks = (total_tuples + 255) / 256;
+  const int grid = (int)(blocks < 65535 ? blocks : 65535);
+  hipLaunchKernelGGL(target_pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, pairs, tup_off,
+                     total_tuples, ax, centers, tr, rot);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

@@ -1,0 +1,988 @@
+// cppf_vote.hip -- centre Hough vote + first-max, back-vote filter, rotation vote + sphere bins,
+// pose assembly.  gfx950 only.  See include/cppf_hip.h for the contract of each entry point.
+#include "cppf_common.h"
+
+// =============================================================================================
+// a6. vote_center (train_dino.py:171-215)
+//
+// MI355X design: the vote grid of a scene (1.6e5 .. 1e6 uint32 cells) is cut into slabs of
+// VC_SLAB_CELLS consecutive flat cells that fit the 160 KiB LDS of one CU.  Workgroup (scene, slab)
+// regenerates the scene's votes in registers (lane = pair, loop over the wave-uniform rotation
+// table) and counts the ones that land in its slab with LDS atomics; the slab is then streamed out
+// with plain coalesced stores (or not at all when the caller only wants the peak) and its first
+// maximum is reduced in place.  HBM sees the tuple/vote-parameter reads and, optionally, one write of
+// the grid -- no global atomics, no memset.  Vote generation is ~80 VALU ops and is repeated once
+// per slab; that is cheaper than 3.6 M L2 atomics per scene as long as a scene has < ~30 slabs.
+// For small batches the pair list of a slab is additionally split over P workgroups that merge
+// their slabs into the (pre-zeroed) global grid with one atomic per non-zero cell.
+// Mode 2 (global atomics, one thread per pair) is kept for huge grids and as an A/B reference.
+// =============================================================================================
+#define VC_THREADS 1024
+#define VC_SLAB_CELLS 36864            // 144 KiB of uint32 counters
+#define VC_ARG_BLOCKS 32
+
+struct SlabBest {
+  int64_t idx;
+  uint32_t val;
+  uint32_t pad;
+};
+
+// one vote: returns flat cell index or -1 (train_dino.py:195-203)
+__device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                         float yy, float yz, float cs, float sn, float c0x, float c0y, float c0z,
+                                         float res, int gx, int gy, int gz) {
+  const float ox = cs * xx + sn * yx;
+  const float oy = cs * xy + sn * yy;
+  const float oz = cs * xz + sn * yz;
+  const float fx = ((cx + ox) - c0x) / res + 0.5f;
+  const float fy = ((cy + oy) - c0y) / res + 0.5f;
+  const float fz = ((cz + oz) - c0z) / res + 0.5f;
+  // (f).long() > 0  <=>  f >= 1 ; (f).long() < g  <=>  f < g   (NaN/inf fail both, like the int64 cast)
+  const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
+  if (!ok) return -1;
+  return ((int)fx * gy + (int)fy) * gz + (int)fz;
+}
+
+struct VoteSetup {
+  float cx, cy, cz, xx, xy, xz, yx, yy, yz;
+  bool ok;
+};
+
+__device__ __forceinline__ VoteSetup vote_setup(const float* __restrict__ p, int i0, int i1, float proj, float od,
+                                                float res) {
+  VoteSetup s;
+  const PairFrame f = pair_frame(p, i0, i1);
+  s.ok = (f.nrm > 1e-7f) & (od > res);                                  // train_dino.py:182
+  s.cx = f.ax - f.ux * proj; s.cy = f.ay - f.uy * proj; s.cz = f.az - f.uz * proj;   // :186
+  s.xx = f.cox / f.nco * od; s.xy = f.coy / f.nco * od; s.xz = f.coz / f.nco * od;   // :191
+  s.yx = cross_term(s.xy, f.uz, s.xz, f.uy);                            // :192 torch.cross(x, ab)
+  s.yy = cross_term(s.xz, f.ux, s.xx, f.uz);
+  s.yz = cross_term(s.xx, f.uy, s.xy, f.ux);
+  return s;
+}
+
+__global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, float res, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
+    uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
+    SlabBest* __restrict__ slab_best, int s_max, int P) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
+  const int b = blockIdx.z, s = blockIdx.y, pc = blockIdx.x;
+  const CppfSceneGrid g = grids[b];
+  const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
+  const int lo = s * VC_SLAB_CELLS;
+  if (lo >= G) return;
+  const int n = min(VC_SLAB_CELLS, G - lo);
+  for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
+  __syncthreads();
+
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const int per = (nt + P - 1) / P;
+  const int ts = pc * per, te = min(nt, ts + per);
+  const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+  const float c0x = g.c0[0], c0y = g.c0[1], c0z = g.c0[2];
+  for (int t = ts + threadIdx.x; t < te; t += VC_THREADS) {
+    const int64_t row = (int64_t)(t0 + t);
+    const VoteSetup v = vote_setup(p, idx[row * k], idx[row * k + 1], tr[row * 2], tr[row * 2 + 1], res);
+    if (!v.ok) continue;
+    for (int r = 0; r < num_rots; ++r) {
+      const float cs = cos_tab[r], sn = sin_tab[r];
+      const int lin = vote_cell(v.cx, v.cy, v.cz, v.xx, v.xy, v.xz, v.yx, v.yy, v.yz, cs, sn, c0x, c0y, c0z, res,
+                                gx, gy, gz);
+      const unsigned rel = (unsigned)(lin - lo);
+      if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+    }
+  }
+  __syncthreads();
+
+  const int64_t goff = grid ? (grid_off ? grid_off[b] : (int64_t)b * cells_cap) : 0;
+  if (P == 1) {
+    uint32_t bv = 0;
+    int64_t bi = INT64_MAX;
+    for (int i = threadIdx.x; i < n; i += VC_THREADS) {
+      const uint32_t c = slab[i];
+      if (grid) grid[goff + lo + i] = c;
+      argmax_combine(bv, bi, c, (int64_t)(lo + i));
+    }
+    wave_argmax(bv, bi);
+    __shared__ uint32_t s_v[VC_THREADS / 64];
+    __shared__ int64_t s_i[VC_THREADS / 64];
+    if (wave_lane() == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < VC_THREADS / 64; ++w) argmax_combine(bv, bi, s_v[w], s_i[w]);
+      SlabBest o; o.idx = bi; o.val = bv; o.pad = 0;
+      slab_best[(int64_t)b * s_max + s] = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += VC_THREADS) {
+      const uint32_t c = slab[i];
+      if (c) atomicAdd(&grid[goff + lo + i], c);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vote_center_global_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, float res, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
+    uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap) {
+  const int b = blockIdx.y;
+  const CppfSceneGrid g = grids[b];
+  if ((int64_t)g.ncell > cells_cap || g.ncell <= 0) return;
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  uint32_t* gb = grid + (grid_off ? grid_off[b] : (int64_t)b * cells_cap);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+    const int64_t row = (int64_t)(t0 + t);
+    const VoteSetup v = vote_setup(p, idx[row * k], idx[row * k + 1], tr[row * 2], tr[row * 2 + 1], res);
+    if (!v.ok) continue;
+    for (int r = 0; r < num_rots; ++r) {
+      const int lin = vote_cell(v.cx, v.cy, v.cz, v.xx, v.xy, v.xz, v.yx, v.yy, v.yz, cos_tab[r], sin_tab[r],
+                                g.c0[0], g.c0[1], g.c0[2], res, g.g[0], g.g[1], g.g[2]);
+      if (lin >= 0) atomicAdd(&gb[lin], 1u);
+    }
+  }
+}
+
+// first maximum of a uint32 grid, stage 1: VC_ARG_BLOCKS partials per scene
+__global__ __launch_bounds__(256) void grid_argmax_partial_kernel(const uint32_t* __restrict__ grid,
+                                                                  const int64_t* __restrict__ grid_off,
+                                                                  int64_t cells_cap,
+                                                                  const CppfSceneGrid* __restrict__ grids,
+                                                                  SlabBest* __restrict__ partial, int s_max) {
+  const int b = blockIdx.y;
+  const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
+  const uint32_t* gb = grid + (grid_off ? grid_off[b] : (int64_t)b * cells_cap);
+  const int per = (G + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(G, lo + per);
+  uint32_t bv = 0;
+  int64_t bi = INT64_MAX;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) argmax_combine(bv, bi, gb[i], (int64_t)i);
+  wave_argmax(bv, bi);
+  __shared__ uint32_t s_v[4];
+  __shared__ int64_t s_i[4];
+  if (wave_lane() == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) argmax_combine(bv, bi, s_v[w], s_i[w]);
+    SlabBest o; o.idx = bi; o.val = bv; o.pad = 0;
+    partial[(int64_t)b * s_max + blockIdx.x] = o;
+  }
+}
+
+// stage 2: combine partials, unravel, world coordinates (train_dino.py:212-213)
+__global__ __launch_bounds__(64) void grid_argmax_final_kernel(const SlabBest* __restrict__ partial, int s_max,
+                                                               int fixed_parts,
+                                                               const CppfSceneGrid* __restrict__ grids,
+                                                               int64_t cells_cap, double res,
+                                                               int64_t* __restrict__ out_argmax,
+                                                               uint32_t* __restrict__ out_peak,
+                                                               double* __restrict__ out_world) {
+  const int b = blockIdx.x;
+  const CppfSceneGrid g = grids[b];
+  const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
+  const int parts = fixed_parts > 0 ? fixed_parts : (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+  uint32_t bv = 0;
+  int64_t bi = INT64_MAX;
+  for (int i = threadIdx.x; i < parts; i += 64) {
+    const SlabBest sb = partial[(int64_t)b * s_max + i];
+    argmax_combine(bv, bi, sb.val, sb.idx);
+  }
+  wave_argmax(bv, bi);
+  if (threadIdx.x == 0) {
+    if (bi == INT64_MAX) bi = 0;
+    out_argmax[b] = bi;
+    if (out_peak) out_peak[b] = bv;
+    if (out_world) {
+      const int64_t gyz = (int64_t)g.g[1] * g.g[2];
+      const int64_t ix = gyz > 0 ? bi / gyz : 0;
+      const int64_t rem = gyz > 0 ? bi - ix * gyz : 0;
+      const int64_t iy = g.g[2] > 0 ? rem / g.g[2] : 0;
+      const int64_t iz = g.g[2] > 0 ? rem - iy * g.g[2] : 0;
+      out_world[3 * b + 0] = (double)g.c0[0] + (double)ix * res;
+      out_world[3 * b + 1] = (double)g.c0[1] + (double)iy * res;
+      out_world[3 * b + 2] = (double)g.c0[2] + (double)iz * res;
+    }
+  }
+}
+
+// zero the caller's grid ranges (offsets live on the device)
+__global__ __launch_bounds__(256) void grid_zero_kernel(uint32_t* __restrict__ grid,
+                                                        const int64_t* __restrict__ grid_off, int64_t cells_cap,
+                                                        const CppfSceneGrid* __restrict__ grids) {
+  const int b = blockIdx.y;
+  const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
+  uint32_t* gb = grid + (grid_off ? grid_off[b] : (int64_t)b * cells_cap);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) gb[i] = 0u;
+}
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static inline int vc_parts(int64_t cells_cap) {
+  int64_t s_max = (cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+  if (s_max < VC_ARG_BLOCKS) s_max = VC_ARG_BLOCKS;
+  return (int)s_max;
+}
+
+extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap) {
+  if (B <= 0 || cells_cap <= 0) return 0;
+  return align_up((int64_t)B * vc_parts(cells_cap) * (int64_t)sizeof(SlabBest), 256) +
+         align_up((int64_t)B * cells_cap * 4, 256);
+}
+
+extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                                const int32_t* tup_off, int max_t, const float* tr, double res, int num_rots,
+                                const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
+                                uint32_t* grid, const int64_t* grid_off, int64_t cells_cap, int mode,
+                                void* workspace, int64_t workspace_bytes, int64_t* out_argmax, uint32_t* out_peak,
+                                double* out_world, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && tr && cos_tab && sin_tab && grids && out_argmax);
+  CPPF_CHECK_ARG(k >= 2 && num_rots > 0 && res > 0.0 && cells_cap > 0 && cells_cap <= 0x7fffffffLL);
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_vote_center_workspace_bytes(B, cells_cap));
+  CPPF_CHECK_ARG(grid == nullptr || grid_off != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  const int s_max_parts = vc_parts(cells_cap);
+  SlabBest* best = (SlabBest*)workspace;
+  uint32_t* ws_grid = (uint32_t*)((char*)workspace + align_up((int64_t)B * s_max_parts * sizeof(SlabBest), 256));
+  const int s_max = (int)((cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
+  if (mode == 0) mode = (s_max <= 64) ? 1 : 2;
+  const float res32 = (float)res;
+  if (max_t <= 0) mode = 2;
+
+  if (mode == 1) {
+    // enough (scene, slab) workgroups to fill 256 CUs?  otherwise split each slab's pair list P ways
+    int P = 1;
+    const int64_t wgs = (int64_t)B * s_max;
+    if (wgs < 256) {
+      P = (int)((256 + wgs - 1) / wgs);
+      const int pmax = (max_t + VC_THREADS - 1) / VC_THREADS;
+      if (P > pmax) P = pmax;
+      if (P < 1) P = 1;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   VC_SLAB_CELLS * 4));
+      attr_set = true;
+    }
+    uint32_t* g_use = grid;
+    const int64_t* goff_use = grid_off;
+    if (P > 1) {
+      if (!g_use) { g_use = ws_grid; goff_use = nullptr; }
+      // slabs are merged with atomics -> the target must start from zero
+      hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
+      CPPF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(vote_center_slab_kernel, dim3(P, s_max, B), dim3(VC_THREADS), VC_SLAB_CELLS * 4, st, pts,
+                       pt_off, idx, k, tup_off, tr, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use,
+                       cells_cap, best, s_max_parts, P);
+    CPPF_LAUNCH_CHECK();
+    if (P == 1) {
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap,
+                         res, out_argmax, out_peak, out_world);
+    } else {
+      hipLaunchKernelGGL(grid_argmax_partial_kernel, dim3(VC_ARG_BLOCKS, B), dim3(256), 0, st, g_use, goff_use,
+                         cells_cap, grids, best, s_max_parts);
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, grids,
+                         cells_cap, res, out_argmax, out_peak, out_world);
+    }
+    CPPF_LAUNCH_CHECK();
+    return CPPF_OK;
+  }
+  if (mode == 2) {
+    uint32_t* g_use = grid ? grid : ws_grid;
+    const int64_t* goff_use = grid ? grid_off : nullptr;
+    hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
+    CPPF_LAUNCH_CHECK();
+    if (max_t > 0) {
+      hipLaunchKernelGGL(vote_center_global_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx,
+                         k, tup_off, tr, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap);
+      CPPF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(grid_argmax_partial_kernel, dim3(VC_ARG_BLOCKS, B), dim3(256), 0, st, g_use, goff_use,
+                       cells_cap, grids, best, s_max_parts);
+    hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, grids,
+                       cells_cap, res, out_argmax, out_peak, out_world);
+    CPPF_LAUNCH_CHECK();
+    return CPPF_OK;
+  }
+  snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_vote_center: unknown mode %d", mode);
+  return CPPF_EINVAL;
+}
+
+// =============================================================================================
+// a7. back-vote filter + importance weights (eval.py:251-275).  One workgroup per scene.
+// =============================================================================================
+#define BV_THREADS 1024
+
+// block-wide exclusive scan of one flag per thread; returns this thread's offset, *total = block sum
+__device__ __forceinline__ int block_scan_flag(bool flag, int* s_wave, int* total) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = wave_lane(), w = threadIdx.x >> 6;
+  const int within = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[w] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < BV_THREADS / 64; ++i) {
+    const int c = s_wave[i];
+    if (i < w) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + within;
+}
+
+// k-th smallest (0-based) of n non-negative floats by 3-pass radix select on the bit pattern.
+// Returns the bit pattern; *n_le = number of elements <= that value.
+__device__ uint32_t radix_select(const float* __restrict__ v, int n, int kth, uint32_t* s_hist, int* s_misc,
+                                 int* n_le) {
+  uint32_t prefix = 0;      // bits fixed so far
+  int remaining = kth;      // rank inside the current candidate set
+  int below = 0;            // elements strictly below the candidate set
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  uint32_t mask_fixed = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = shifts[pass], nbins = 1 << widths[pass];
+    for (int i = threadIdx.x; i < nbins; i += BV_THREADS) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BV_THREADS) {
+      const uint32_t bits = __float_as_uint(v[i]);
+      if ((bits & mask_fixed) == prefix) atomicAdd(&s_hist[(bits >> sh) & (nbins - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      // 64 lanes x (nbins/64) consecutive bins
+      const int per = nbins / 64;
+      uint32_t sum = 0;
+      for (int j = 0; j < per; ++j) sum += s_hist[threadIdx.x * per + j];
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if ((int)threadIdx.x >= off) incl += o;
+      }
+      const uint32_t excl = incl - sum;
+      if ((uint32_t)remaining >= excl && (uint32_t)remaining < incl) {
+        uint32_t run = excl;
+        for (int j = 0; j < per; ++j) {
+          const uint32_t c = s_hist[threadIdx.x * per + j];
+          if ((uint32_t)remaining < run + c) {
+            s_misc[0] = threadIdx.x * per + j;   // chosen bin
+            s_misc[1] = (int)run;                // elements of the candidate set below the chosen bin
+            s_misc[2] = (int)c;                  // elements in the chosen bin
+            break;
+          }
+          run += c;
+        }
+      }
+    }
+    __syncthreads();
+    const int bin = s_misc[0];
+    below += s_misc[1];
+    remaining -= s_misc[1];
+    prefix |= ((uint32_t)bin) << sh;
+    mask_fixed |= ((uint32_t)(nbins - 1)) << sh;
+    if (pass == 2) *n_le = below + s_misc[2];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(BV_THREADS) void backvote_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, const double* __restrict__ centers,
+    Axes9 axes, const int32_t* __restrict__ kidx, const float* __restrict__ gammas, double margin, int num_rots,
+    uint8_t* __restrict__ mask, int32_t* __restrict__ kept_tuple, int32_t* __restrict__ kept_count,
+    double* __restrict__ kept_wt, int32_t* __restrict__ kept_row0, float* __restrict__ errs,
+    float* __restrict__ thr_out, int32_t* __restrict__ hits) {
+  __shared__ uint32_t s_hist[2048];
+  __shared__ int s_misc[4];
+  __shared__ int s_wave[BV_THREADS / 64];
+  __shared__ float s_f[BV_THREADS / 64];
+  const int b = blockIdx.x;
+  const int p0 = pt_off[b];
+  const float* p = pts + 3 * (int64_t)p0;
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  float* e = errs + t0;
+  if (nt <= 0) {
+    if (threadIdx.x == 0) { kept_count[b] = 0; if (thr_out) thr_out[b] = NAN; }
+    return;
+  }
+  const double cx = centers[3 * b], cy = centers[3 * b + 1], cz = centers[3 * b + 2];
+  // 1. back-projected vote parameters of the real pairs w.r.t. the voted centre (eval.py:252-257)
+  for (int t = threadIdx.x; t < nt; t += BV_THREADS) {
+    const int64_t row = (int64_t)(t0 + t);
+    const float* a = p + 3 * (int64_t)idx[row * k];
+    const float* bb = p + 3 * (int64_t)idx[row * k + 1];
+    float tb[2];
+    target_pair(a[0], a[1], a[2], bb[0], bb[1], bb[2], cx, cy, cz, axes.a, tb, nullptr);
+    const float d0 = tr[row * 2] - tb[0], d1 = tr[row * 2 + 1] - tb[1];
+    e[t] = __fsqrt_rn(d0 * d0 + d1 * d1);
+  }
+  __syncthreads();
+  // 2. np.percentile(back_errs, ratio*100), method 'linear' (eval.py:258): order statistics kq and kq+1
+  int kq = kidx[b];
+  if (kq > nt - 1) kq = nt - 1;
+  const float gamma = gammas[b];
+  int n_le = 0;
+  const uint32_t bits_lo = radix_select(e, nt, kq, s_hist, s_misc, &n_le);
+  const float v_lo = __uint_as_float(bits_lo);
+  float v_hi = v_lo;
+  if (kq + 1 <= nt - 1 && kq + 1 >= n_le) {
+    // next order statistic = smallest element strictly above v_lo (bit order == value order for x >= 0, NaN last)
+    uint32_t mn = 0xffffffffu;
+    for (int i = threadIdx.x; i < nt; i += BV_THREADS) {
+      const uint32_t bits = __float_as_uint(e[i]);
+      if (bits > bits_lo && bits < mn) mn = bits;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    if (wave_lane() == 0) s_hist[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < BV_THREADS / 64; ++w) mn = min(mn, s_hist[w]);
+      s_hist[64] = mn;
+    }
+    __syncthreads();
+    v_hi = __uint_as_float(s_hist[64]);
+    __syncthreads();
+  }
+  // numpy _lerp in float32: a + (b-a)*t, replaced by b - (b-a)*(1-t) where t >= 0.5
+  const float diff = v_hi - v_lo;
+  float thr = v_lo + diff * gamma;
+  if (gamma >= 0.5f) thr = v_hi - diff * (1.0f - gamma);
+  if (threadIdx.x == 0 && thr_out) thr_out[b] = thr;
+  // 3. mask + ordered compaction (eval.py:258-268)
+  int kept = 0;
+  for (int base = 0; base < nt; base += BV_THREADS) {
+    const int t = base + threadIdx.x;
+    const bool keep = (t < nt) && (e[t] < thr);
+    if (t < nt) mask[t0 + t] = keep ? 1 : 0;
+    int tot;
+    const int pos = block_scan_flag(keep, s_wave, &tot);
+    if (keep) kept_tuple[t0 + kept + pos] = t;
+    kept += tot;
+  }
+  if (threadIdx.x == 0) kept_count[b] = kept;
+  __syncthreads();
+  // 4. per-point hit histogram (eval.py:264-265), hits[] was zeroed by the host wrapper
+  int32_t* h = hits + p0;
+  for (int j = threadIdx.x; j < kept; j += BV_THREADS) {
+    const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+    atomicAdd(&h[idx[row * k]], 1);
+    atomicAdd(&h[idx[row * k + 1]], 1);
+  }
+  __threadfence();
+  __syncthreads();
+  int hmax = 0;
+  for (int j = threadIdx.x; j < kept; j += BV_THREADS) {
+    const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+    hmax = max(hmax, __hip_atomic_load(&h[idx[row * k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    hmax = max(hmax, __hip_atomic_load(&h[idx[row * k + 1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) hmax = max(hmax, __shfl_xor(hmax, off));
+  if (wave_lane() == 0) s_wave[threadIdx.x >> 6] = hmax;
+  __syncthreads();
+  hmax = 0;
+  for (int w = 0; w < BV_THREADS / 64; ++w) hmax = max(hmax, s_wave[w]);
+  __syncthreads();
+  const double dmax = (double)hmax;
+  // 5. pair weights (eval.py:274-275) + row of each pair in vote_rotation's compacted candidate list
+  int rank = 0;
+  for (int base = 0; base < kept; base += BV_THREADS) {
+    const int j = base + threadIdx.x;
+    bool valid = false;
+    if (j < kept) {
+      const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+      const int i0 = idx[row * k], i1 = idx[row * k + 1];
+      const double w0 = (double)__hip_atomic_load(&h[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / dmax;
+      const double w1 = (double)__hip_atomic_load(&h[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / dmax;
+      kept_wt[t0 + j] = (w0 + w1) + margin;
+      const float dx = p[3 * i0] - p[3 * i1], dy = p[3 * i0 + 1] - p[3 * i1 + 1], dz = p[3 * i0 + 2] - p[3 * i1 + 2];
+      valid = norm3_fused(dx, dy, dz) > 1e-7f;                        // train_dino.py:223
+    }
+    int tot;
+    const int pos = block_scan_flag(valid, s_wave, &tot);
+    if (j < kept) kept_row0[t0 + j] = valid ? (rank + pos) * num_rots : -1;
+    rank += tot;
+  }
+  (void)s_f;
+}
+
+extern "C" int64_t cppf_backvote_workspace_bytes(int64_t total_points, int B) {
+  (void)B;
+  return align_up(total_points * 4, 256);
+}
+
+extern "C" int cppf_backvote_filter(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                                    const int32_t* tup_off, const float* tr, const double* centers,
+                                    const double* h_axes, const int32_t* kidx, const float* gammas,
+                                    double imp_wt_margin, int num_rots, uint8_t* mask, int32_t* kept_tuple,
+                                    int32_t* kept_count, double* kept_wt, int32_t* kept_row0, float* back_errs,
+                                    float* thr, void* workspace, int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && tr && centers && h_axes && kidx && gammas);
+  CPPF_CHECK_ARG(mask && kept_tuple && kept_count && kept_wt && kept_row0 && back_errs);
+  CPPF_CHECK_ARG(workspace && workspace_bytes > 0);
+  Axes9 ax;
+  for (int i = 0; i < 9; ++i) ax.a[i] = h_axes[i];
+  CPPF_HIP(hipMemsetAsync(workspace, 0, (size_t)workspace_bytes, (hipStream_t)stream));
+  hipLaunchKernelGGL(backvote_kernel, dim3(B), dim3(BV_THREADS), 0, (hipStream_t)stream, pts, pt_off, idx, k, tup_off,
+                     tr, centers, ax, kidx, gammas, imp_wt_margin, num_rots, mask, kept_tuple, kept_count, kept_wt,
+                     kept_row0, back_errs, thr, (int32_t*)workspace);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// =============================================================================================
+// a8 + a9. vote_rotation (train_dino.py:218-239) fused with get_topk_dir (eval.py:37-51).
+//
+// Dense kernel: a workgroup takes RB_PAIRS kept pairs of one (scene, axis), generates their
+// RB_PAIRS*num_rots candidate axes once into LDS (one thread per candidate), then every thread owns one
+// sphere bin per 64-bin group and walks the candidate list (LDS broadcast reads), accumulating
+// 1/weight in float64 for candidates inside the cone.  Per-chunk (bmm_size rows) float64 sums are merged
+// with float64 atomics and folded into float32 counts chunk by chunk, exactly like the reference's
+// `counts += torch.sum(... / wt, 0)`.
+// =============================================================================================
+#define RB_THREADS 256
+#define RB_MAX_CAND 1024
+
+struct RotCand {
+  float x, y, z;
+  int slot;      // chunk id of the row this candidate occupies (absolute); -1 = skip
+  double inv_wt;
+};
+
+// one candidate axis (train_dino.py:233-237)
+__device__ __forceinline__ void rot_candidate(const PairFrame& f, float tn, float cs, float sn, float& ox, float& oy,
+                                              float& oz) {
+  // x = co / clamp_min(|co|, 1e-7); y = cross(x, u)
+  const float den = fmaxf(f.nco, 1e-7f);
+  const float xx = f.cox / den, xy = f.coy / den, xz = f.coz / den;
+  const float yx = cross_term(xy, f.uz, xz, f.uy);
+  const float yy = cross_term(xz, f.ux, xx, f.uz);
+  const float yz = cross_term(xx, f.uy, xy, f.ux);
+  const float offx = cs * xx + sn * yx, offy = cs * xy + sn * yy, offz = cs * xz + sn * yz;
+  const float sg = (tn > 0.0f) ? 1.0f : -1.0f;
+  const float ux = tn * offx + sg * f.ux, uy = tn * offy + sg * f.uy, uz = tn * offz + sg * f.uz;
+  const float n = fmaxf(norm3_fused(ux, uy, uz), 1e-7f);
+  ox = ux / n; oy = uy / n; oz = uz / n;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void rot_bins_dense_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ rot, int rot_col,
+    const int32_t* __restrict__ kept_tuple, const int32_t* __restrict__ kept_count,
+    const double* __restrict__ kept_wt, const int32_t* __restrict__ kept_row0, int pairs_per_block, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const float* __restrict__ sphere, int S,
+    float cos_thr, int bmm_size, int max_chunks, double* __restrict__ sums /* [B][max_chunks][S] */) {
+  __shared__ RotCand s_c[RB_MAX_CAND];
+  __shared__ int s_cb;
+  const int b = blockIdx.y;
+  const int kept = kept_count[b];
+  const int j0 = blockIdx.x * pairs_per_block;
+  if (j0 >= kept) return;
+  const int npairs = min(pairs_per_block, kept - j0);
+  const int ncand = npairs * num_rots;
+  const int t0 = tup_off[b];
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  if (threadIdx.x == 0) s_cb = 0x7fffffff;
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncand; c += RB_THREADS) {
+    const int pj = c / num_rots, r = c - pj * num_rots;
+    const int j = j0 + pj;
+    const int row0 = kept_row0[t0 + j];
+    RotCand rc;
+    rc.slot = -1; rc.x = rc.y = rc.z = 0.0f; rc.inv_wt = 0.0;
+    if (row0 >= 0) {
+      const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+      const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
+      const float tn = tanf(rot[row * 3 + rot_col]);
+      rot_candidate(f, tn, cos_tab[r], sin_tab[r], rc.x, rc.y, rc.z);
+      rc.slot = (row0 + r) / bmm_size;
+      rc.inv_wt = 1.0 / kept_wt[t0 + j];
+      atomicMin(&s_cb, rc.slot);
+    }
+    s_c[c] = rc;
+  }
+  __syncthreads();
+  const int cb = s_cb;
+  if (cb == 0x7fffffff) return;
+  double* out = sums + ((int64_t)b * max_chunks) * S;
+  for (int s = threadIdx.x; s < S; s += RB_THREADS) {
+    const float bx = sphere[3 * s], by = sphere[3 * s + 1], bz = sphere[3 * s + 2];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int c = 0; c < ncand; ++c) {
+      const RotCand rc = s_c[c];
+      if (rc.slot < 0) continue;
+      const float d = fmaf(rc.z, bz, fmaf(rc.y, by, rc.x * bx));     // mm, K = 3: fused like sgemm
+      const double w = (d > cos_thr) ? rc.inv_wt : 0.0;
+      if (rc.slot == cb) acc0 += w; else acc1 += w;
+    }
+    if (acc0 != 0.0) atomicAdd(&out[(int64_t)cb * S + s], acc0);
+    if (acc1 != 0.0) atomicAdd(&out[(int64_t)(cb + 1) * S + s], acc1);
+  }
+}
+
+// Windowed kernel for fibonacci_sphere bins (utils/util.py:191-207): bin i sits at y_i = 1 - 2 i/(S-1), so a
+// candidate with |angle| <= cone to bin i satisfies |y - y_i| <= 2 sin(cone/2) <= cone; only the bins whose
+// index is within `win` of (1-y)(S-1)/2 can pass the cosine test.  One thread per candidate, hits (about
+// 0.2 per candidate) go to LDS float64 accumulators.
+#define RW_THREADS 256
+__global__ __launch_bounds__(RW_THREADS) void rot_bins_window_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ rot, int rot_col,
+    const int32_t* __restrict__ kept_tuple, const int32_t* __restrict__ kept_count,
+    const double* __restrict__ kept_wt, const int32_t* __restrict__ kept_row0, int pairs_per_block, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const float* __restrict__ sphere, int S,
+    float cos_thr, int win, int bmm_size, int max_chunks, double* __restrict__ sums) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_sph = (float*)smem;                       // [S][3]
+  double* s_acc = (double*)(smem + ((size_t)S * 12 + 15) / 16 * 16);   // [2][S]
+  __shared__ int s_cb;
+  const int b = blockIdx.y;
+  const int kept = kept_count[b];
+  const int j0 = blockIdx.x * pairs_per_block;
+  if (j0 >= kept) return;
+  const int npairs = min(pairs_per_block, kept - j0);
+  const int ncand = npairs * num_rots;
+  const int t0 = tup_off[b];
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  for (int i = threadIdx.x; i < 3 * S; i += RW_THREADS) s_sph[i] = sphere[i];
+  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) s_acc[i] = 0.0;
+  if (threadIdx.x == 0) {
+    // chunk of the first valid pair of the block (rows increase with j)
+    int cb = 0x7fffffff;
+    for (int pj = 0; pj < npairs; ++pj) {
+      const int row0 = kept_row0[t0 + j0 + pj];
+      if (row0 >= 0) { cb = row0 / bmm_size; break; }
+    }
+    s_cb = cb;
+  }
+  __syncthreads();
+  const int cb = s_cb;
+  if (cb == 0x7fffffff) return;
+  const float half = 0.5f * (float)(S - 1);
+  for (int c = threadIdx.x; c < ncand; c += RW_THREADS) {
+    const int pj = c / num_rots, r = c - pj * num_rots;
+    const int j = j0 + pj;
+    const int row0 = kept_row0[t0 + j];
+    if (row0 < 0) continue;
+    const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+    const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
+    const float tn = tanf(rot[row * 3 + rot_col]);
+    float x, y, z;
+    rot_candidate(f, tn, cos_tab[r], sin_tab[r], x, y, z);
+    if (!(y == y)) continue;                                           // NaN candidate never passes the test
+    const int slot = (row0 + r) / bmm_size - cb;
+    const double inv_wt = 1.0 / kept_wt[t0 + j];
+    const int ic = (int)((1.0f - y) * half + 0.5f);
+    const int lo = max(0, ic - win), hi = min(S - 1, ic + win);
+    for (int s = lo; s <= hi; ++s) {
+      const float d = fmaf(z, s_sph[3 * s + 2], fmaf(y, s_sph[3 * s + 1], x * s_sph[3 * s]));
+      if (d > cos_thr) atomicAdd(&s_acc[slot * S + s], inv_wt);
+    }
+  }
+  __syncthreads();
+  double* out = sums + ((int64_t)b * max_chunks) * S;
+  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) {
+    const double v = s_acc[i];
+    if (v != 0.0) {
+      const int slot = i / S, s = i - slot * S;
+      atomicAdd(&out[(int64_t)(cb + slot) * S + s], v);
+    }
+  }
+}
+
+// counts (float32) = fold of the per-chunk float64 sums, then first maximum
+__global__ __launch_bounds__(256) void rot_bins_final_kernel(const double* __restrict__ sums, int S, int max_chunks,
+                                                             float* __restrict__ counts, int32_t* __restrict__ top_idx,
+                                                             float* __restrict__ top_count) {
+  const int b = blockIdx.x;
+  const double* in = sums + ((int64_t)b * max_chunks) * S;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    float c = 0.0f;
+    for (int ch = 0; ch < max_chunks; ++ch) c = (float)((double)c + in[(int64_t)ch * S + s]);
+    counts[(int64_t)b * S + s] = c;
+    if (c > best || (c == best && s < besti)) { best = c; besti = s; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(besti, off);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  __shared__ float s_b[4];
+  __shared__ int s_i[4];
+  if (wave_lane() == 0) { s_b[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_b[w] > best || (s_b[w] == best && s_i[w] < besti)) { best = s_b[w]; besti = s_i[w]; }
+    if (besti == 0x7fffffff) besti = 0;
+    if (top_idx) top_idx[b] = besti;
+    if (top_count) top_count[b] = best;
+  }
+}
+
+static inline int rb_max_chunks(int max_kept, int num_rots, int bmm_size) {
+  const int64_t rows = (int64_t)max_kept * num_rots;
+  return (int)((rows + bmm_size - 1) / bmm_size) + 1;
+}
+
+extern "C" int64_t cppf_rot_bins_workspace_bytes(int B, int S, int max_kept, int num_rots, int bmm_size) {
+  if (B <= 0 || S <= 0 || max_kept < 0 || num_rots <= 0 || bmm_size <= 0) return 0;
+  return align_up((int64_t)B * rb_max_chunks(max_kept, num_rots, bmm_size) * S * 8, 256);
+}
+
+extern "C" int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                             const int32_t* tup_off, const float* rot, int rot_col, const int32_t* kept_tuple,
+                             const int32_t* kept_count, const double* kept_wt, const int32_t* kept_row0, int max_kept,
+                             int num_rots, const float* cos_tab, const float* sin_tab, const float* sphere, int S,
+                             float cos_thr, int bmm_size, int fibonacci, float* counts, int32_t* top_idx,
+                             float* top_count, void* workspace, int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && rot && kept_tuple && kept_count && kept_wt && kept_row0);
+  CPPF_CHECK_ARG(cos_tab && sin_tab && sphere && counts);
+  CPPF_CHECK_ARG(rot_col >= 0 && rot_col < 3 && S > 0 && num_rots > 0 && num_rots <= RB_MAX_CAND && bmm_size > 0);
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size));
+  hipStream_t st = (hipStream_t)stream;
+  const int max_chunks = rb_max_chunks(max_kept, num_rots, bmm_size);
+  double* sums = (double*)workspace;
+  CPPF_HIP(hipMemsetAsync(sums, 0, (size_t)B * max_chunks * S * 8, st));
+  if (max_kept > 0) {
+    int ppb = RB_MAX_CAND / num_rots;
+    if (ppb > 4) ppb = 4;
+    if (ppb < 1) ppb = 1;
+    // a block's rows must not straddle more than two chunks
+    if ((int64_t)ppb * num_rots > bmm_size) {
+      ppb = bmm_size / num_rots;
+      if (ppb < 1) {
+        snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_rot_bins: bmm_size %d < num_rots %d unsupported", bmm_size,
+                 num_rots);
+        return CPPF_EUNSUPPORTED;
+      }
+    }
+    const int blocks = (max_kept + ppb - 1) / ppb;
+    const size_t win_lds = ((size_t)S * 12 + 15) / 16 * 16 + (size_t)2 * S * 8;
+    if (fibonacci && cos_thr > 0.5f && S >= 16 && win_lds <= 60000) {
+      // |dy| <= cone angle (+1e-4 rad slack for f32 rounding of dot/normalisation), in index units, +1
+      const double cone = acos((double)cos_thr) + 1e-4;
+      const int win = (int)ceil(cone * 0.5 * (double)(S - 1)) + 1;
+      hipLaunchKernelGGL(rot_bins_window_kernel, dim3(blocks, B), dim3(RW_THREADS), win_lds, st, pts, pt_off, idx, k,
+                         tup_off, rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab,
+                         sin_tab, sphere, S, cos_thr, win, bmm_size, max_chunks, sums);
+    } else {
+      hipLaunchKernelGGL(rot_bins_dense_kernel, dim3(blocks, B), dim3(RB_THREADS), 0, st, pts, pt_off, idx, k, tup_off,
+                         rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab, sin_tab,
+                         sphere, S, cos_thr, bmm_size, max_chunks, sums);
+    }
+    CPPF_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rot_bins_final_kernel, dim3(B), dim3(256), 0, st, sums, S, max_chunks, counts, top_idx,
+                     top_count);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone halves with the reference's signatures
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void vr_scan_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
+                                                       int k, int T, uint8_t* __restrict__ valid,
+                                                       int32_t* __restrict__ rank, int32_t* __restrict__ n_valid) {
+  __shared__ int s_wave[BV_THREADS / 64];
+  int base_rank = 0;
+  for (int base = 0; base < T; base += BV_THREADS) {
+    const int t = base + threadIdx.x;
+    bool v = false;
+    if (t < T) {
+      const int i0 = idx[(int64_t)t * k], i1 = idx[(int64_t)t * k + 1];
+      v = norm3_fused(pts[3 * i0] - pts[3 * i1], pts[3 * i0 + 1] - pts[3 * i1 + 1],
+                      pts[3 * i0 + 2] - pts[3 * i1 + 2]) > 1e-7f;
+      valid[t] = v ? 1 : 0;
+    }
+    int tot;
+    const int pos = block_scan_flag(v, s_wave, &tot);
+    if (t < T) rank[t] = v ? base_rank + pos : -1;
+    base_rank += tot;
+  }
+  if (threadIdx.x == 0) *n_valid = base_rank;
+}
+
+__global__ __launch_bounds__(256) void vr_emit_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx,
+                                                      int k, int T, const float* __restrict__ angle, int num_rots,
+                                                      const float* __restrict__ cos_tab,
+                                                      const float* __restrict__ sin_tab,
+                                                      const int32_t* __restrict__ rank, float* __restrict__ up) {
+  const int64_t total = (int64_t)T * num_rots;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(c / num_rots), r = (int)(c - (int64_t)t * num_rots);
+    const int rk = rank[t];
+    if (rk < 0) continue;
+    const PairFrame f = pair_frame(pts, idx[(int64_t)t * k], idx[(int64_t)t * k + 1]);
+    float x, y, z;
+    rot_candidate(f, tanf(angle[t]), cos_tab[r], sin_tab[r], x, y, z);
+    float* o = up + ((int64_t)rk * num_rots + r) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+  }
+}
+
+extern "C" int cppf_vote_rotation(const float* pts, int n_points, const int32_t* idx, int k, int T,
+                                  const float* rot_angle, int num_rots, const float* cos_tab, const float* sin_tab,
+                                  float* up, uint8_t* valid, int32_t* n_valid, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(pts && idx && rot_angle && cos_tab && sin_tab && up && valid && n_valid && workspace);
+  CPPF_CHECK_ARG(n_points > 0 && k >= 2 && T >= 0 && num_rots > 0 && workspace_bytes >= (int64_t)T * 4);
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* rank = (int32_t*)workspace;
+  hipLaunchKernelGGL(vr_scan_kernel, dim3(1), dim3(BV_THREADS), 0, st, pts, idx, k, T, valid, rank, n_valid);
+  CPPF_LAUNCH_CHECK();
+  if (T > 0) {
+    const int64_t blocks = ((int64_t)T * num_rots + 255) / 256;
+    hipLaunchKernelGGL(vr_emit_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, pts, idx, k,
+                       T, rot_angle, num_rots, cos_tab, sin_tab, rank, up);
+    CPPF_LAUNCH_CHECK();
+  }
+  return CPPF_OK;
+}
+
+// get_topk_dir on explicit candidates: thread = sphere bin, rows of a chunk split over SC_SPLIT workgroups
+#define SC_ROWS 512
+__global__ __launch_bounds__(256) void sphere_counts_kernel(const float* __restrict__ cand, int64_t M,
+                                                            const double* __restrict__ wt,
+                                                            const float* __restrict__ sphere, int S, float cos_thr,
+                                                            int bmm_size, int blocks_per_chunk,
+                                                            double* __restrict__ sums) {
+  __shared__ float s_x[SC_ROWS], s_y[SC_ROWS], s_z[SC_ROWS];
+  __shared__ double s_w[SC_ROWS];
+  const int chunk = blockIdx.x / blocks_per_chunk, sub = blockIdx.x - chunk * blocks_per_chunk;
+  const int64_t c_lo = (int64_t)chunk * bmm_size;
+  const int64_t c_hi = (c_lo + bmm_size < M) ? c_lo + bmm_size : M;
+  const int64_t lo = c_lo + (int64_t)sub * SC_ROWS;
+  if (lo >= c_hi) return;
+  const int n = (int)((c_hi - lo < SC_ROWS) ? c_hi - lo : SC_ROWS);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    s_x[i] = cand[(lo + i) * 3]; s_y[i] = cand[(lo + i) * 3 + 1]; s_z[i] = cand[(lo + i) * 3 + 2];
+    s_w[i] = wt ? 1.0 / wt[lo + i] : 1.0;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const float bx = sphere[3 * s], by = sphere[3 * s + 1], bz = sphere[3 * s + 2];
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const float d = fmaf(s_z[i], bz, fmaf(s_y[i], by, s_x[i] * bx));
+      acc += (d > cos_thr) ? s_w[i] : 0.0;
+    }
+    if (acc != 0.0) atomicAdd(&sums[(int64_t)chunk * S + s], acc);
+  }
+}
+
+extern "C" int cppf_sphere_counts(const float* cand, int64_t M, const double* wt, const float* sphere, int S,
+                                  float cos_thr, int bmm_size, float* counts, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  CPPF_CHECK_ARG(cand && sphere && counts && workspace && S > 0 && bmm_size > 0 && M >= 0);
+  const int nchunks = (int)((M + bmm_size - 1) / bmm_size);
+  const int mc = nchunks > 0 ? nchunks : 1;
+  CPPF_CHECK_ARG(workspace_bytes >= (int64_t)mc * S * 8);
+  hipStream_t st = (hipStream_t)stream;
+  double* sums = (double*)workspace;
+  CPPF_HIP(hipMemsetAsync(sums, 0, (size_t)mc * S * 8, st));
+  if (M > 0) {
+    const int bpc = (bmm_size + SC_ROWS - 1) / SC_ROWS;
+    hipLaunchKernelGGL(sphere_counts_kernel, dim3(nchunks * bpc), dim3(256), 0, st, cand, M, wt, sphere, S, cos_thr,
+                       bmm_size, bpc, sums);
+    CPPF_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rot_bins_final_kernel, dim3(1), dim3(256), 0, st, sums, S, mc, counts, (int32_t*)nullptr,
+                     (float*)nullptr);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// =============================================================================================
+// a11. pose assembly (eval.py:295-313) + lower median of the scale head over kept pairs (eval.py:309)
+// =============================================================================================
+__global__ __launch_bounds__(256) void assemble_pose_kernel(
+    const float* __restrict__ sphere, const int32_t* __restrict__ up_idx, const float* __restrict__ up_count,
+    const int32_t* __restrict__ right_idx, const float* __restrict__ right_count, int up_axis, int right_axis,
+    const int64_t* __restrict__ argmax, const uint32_t* __restrict__ peak, const double* __restrict__ world,
+    const CppfSceneGrid* __restrict__ grids, const float* __restrict__ pred_scales,
+    const int32_t* __restrict__ tup_off, const int32_t* __restrict__ kept_tuple,
+    const int32_t* __restrict__ kept_count, CppfSceneResult* __restrict__ out) {
+  const int b = blockIdx.x;
+  __shared__ float s_med[3];
+  const int kept = kept_count ? kept_count[b] : 0;
+  if (threadIdx.x < 3) s_med[threadIdx.x] = NAN;
+  __syncthreads();
+  if (pred_scales && kept > 0) {
+    // lower median = element of rank (kept-1)/2 under (value, position) order; rank by counting
+    const int t0 = tup_off[b];
+    const int target = (kept - 1) / 2;
+    for (int col = 0; col < 3; ++col) {
+      for (int i = threadIdx.x; i < kept; i += blockDim.x) {
+        const float vi = pred_scales[(int64_t)(t0 + kept_tuple[t0 + i]) * 3 + col];
+        int rank = 0;
+        for (int j = 0; j < kept; ++j) {
+          const float vj = pred_scales[(int64_t)(t0 + kept_tuple[t0 + j]) * 3 + col];
+          rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0;
+        }
+        if (rank == target) s_med[col] = vi;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  CppfSceneResult r;
+  r.argmax = argmax[b];
+  r.peak = peak ? peak[b] : 0u;
+  r.t[0] = world[3 * b]; r.t[1] = world[3 * b + 1]; r.t[2] = world[3 * b + 2];
+  r.up_idx = up_idx[b]; r.right_idx = right_idx[b];
+  r.up_count = up_count ? up_count[b] : 0.0f;
+  r.right_count = right_count ? right_count[b] : 0.0f;
+  r.kept = kept;
+  r.flags = grids ? grids[b].flags : 0;
+  r.ncell = grids ? grids[b].ncell : 0;
+  r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+  r.scale[0] = s_med[0]; r.scale[1] = s_med[1]; r.scale[2] = s_med[2];
+  // eval.py:295-296: float32 Gram-Schmidt of the right vote against the up vote
+  const float ux = sphere[3 * r.up_idx], uy = sphere[3 * r.up_idx + 1], uz = sphere[3 * r.up_idx + 2];
+  float rx = sphere[3 * r.right_idx], ry = sphere[3 * r.right_idx + 1], rz = sphere[3 * r.right_idx + 2];
+  const float d = (ux * rx + uy * ry) + uz * rz;
+  rx = rx - d * ux; ry = ry - d * uy; rz = rz - d * uz;
+  const float n = __fsqrt_rn((rx * rx + ry * ry) + rz * rz) + 1e-9f;
+  rx = rx / n; ry = ry / n; rz = rz / n;
+  double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  R[0][up_axis] = ux; R[1][up_axis] = uy; R[2][up_axis] = uz;
+  R[0][right_axis] = rx; R[1][right_axis] = ry; R[2][right_axis] = rz;
+  const int o = 3 - up_axis - right_axis;
+  const int c1 = (o + 1) % 3, c2 = (o + 2) % 3;
+  R[0][o] = R[1][c1] * R[2][c2] - R[2][c1] * R[1][c2];
+  R[1][o] = R[2][c1] * R[0][c2] - R[0][c1] * R[2][c2];
+  R[2][o] = R[0][c1] * R[1][c2] - R[1][c1] * R[0][c2];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.R[3 * i + j] = R[i][j];
+  out[b] = r;
+}
+
+extern "C" int cppf_assemble_pose(int B, const float* sphere, const int32_t* up_idx, const float* up_count,
+                                  const int32_t* right_idx, const float* right_count, int up_axis, int right_axis,
+                                  const int64_t* argmax, const uint32_t* peak, const double* world,
+                                  const CppfSceneGrid* grids, const float* pred_scales, const int32_t* tup_off,
+                                  const int32_t* kept_tuple, const int32_t* kept_count, CppfSceneResult* out,
+                                  void* stream) {
+  CPPF_CHECK_ARG(B > 0 && sphere && up_idx && right_idx && argmax && world && out);
+  CPPF_CHECK_ARG(up_axis >= 0 && up_axis < 3 && right_axis >= 0 && right_axis < 3 && up_axis != right_axis);
+  CPPF_CHECK_ARG(pred_scales == nullptr || (tup_off && kept_tuple && kept_count));
+  hipLaunchKernelGGL(assemble_pose_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sphere, up_idx, up_count,
+                     right_idx, right_count, up_axis, right_axis, argmax, peak, world, grids, pred_scales, tup_off,
+                     kept_tuple, kept_count, out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

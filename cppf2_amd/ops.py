@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's operator interface for the voting hot path.
+
+Same names, argument meaning and return types as the reference's Python callables
+(train_dino.py:171-239 vote_center / vote_rotation, eval.py:37-51 get_topk_dir,
+dataset.py:118-135 generate_target_pairs, utils/util.py:191-207 fibonacci_sphere), on
+top of the C ABI in include/cppf_hip.h.  Every function here runs on the GPU through
+libcppf_hip.so; there is no CPU path (import fails loudly without the library, calls
+fail loudly without a GPU).
+
+PyTorch is plumbing only: device memory, the current HIP stream, dtype conversion.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CppfError, SceneGrid, SceneResult
+
+_L = _lib.load()
+
+BMM_SIZE = 100000          # eval.py:81
+
+
+# ----------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------
+def _dev():
+    if not torch.cuda.is_available():
+        raise CppfError("cppf2_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def _t(x, dtype, device=None):
+    """torch tensor on the device with the given dtype, contiguous (accepts numpy / torch / lists)."""
+    device = device or _dev()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), device="cpu").to(device=device, dtype=dtype).contiguous()
+
+
+def _axes9(a1, a2, a3):
+    arr = (C.c_double * 9)(*[float(v) for ax in (a1, a2, a3) for v in np.asarray(ax).reshape(3)])
+    return arr
+
+
+def fibonacci_sphere(samples):
+    """utils/util.py:191-207 (host, float64 Python math; cast to float32 by the caller, eval.py:80)."""
+    ga = math.pi * (3.0 - math.sqrt(5.0))
+    out = []
+    for i in range(samples):
+        y = 1 - (i / float(samples - 1)) * 2
+        rad = math.sqrt(1 - y * y)
+        out.append((math.cos(ga * i) * rad, y, math.sin(ga * i) * rad))
+    return out
+
+
+_SPHERE_CACHE = {}
+
+
+def sphere_bins(angle_tol=1.0):
+    """eval.py:79-80: float32 [int(4*pi/(angle_tol/180*pi)), 3]."""
+    n = int(4 * np.pi / (angle_tol / 180 * np.pi))
+    if n not in _SPHERE_CACHE:
+        _SPHERE_CACHE[n] = np.array(fibonacci_sphere(n), dtype=np.float32)
+    return _SPHERE_CACHE[n]
+
+
+def is_fibonacci(sphere_pts):
+    s = np.asarray(sphere_pts)
+    if s.ndim != 2 or s.shape[1] != 3 or s.shape[0] < 16:
+        return False
+    return bool(np.array_equal(s.astype(np.float32), np.array(fibonacci_sphere(s.shape[0]), dtype=np.float32)))
+
+
+_TRIG_CACHE = {}
+
+
+def rotation_table(num_rots, device=None):
+    """train_dino.py:194-195 built with torch on the HOST (so the table is the one the CPU reference uses),
+    uploaded once per (num_rots, device).  Returns (cos, sin) device float32 tensors."""
+    device = device or _dev()
+    key = (int(num_rots), str(device))
+    if key not in _TRIG_CACHE:
+        angles = torch.arange(num_rots).float() / num_rots * 2 * np.pi
+        _TRIG_CACHE[key] = (torch.cos(angles).to(device), torch.sin(angles).to(device))
+    return _TRIG_CACHE[key]
+
+
+def _trig(num_rots, trig, device):
+    if trig is None:
+        return rotation_table(num_rots, device)
+    return _t(trig[0], torch.float32, device), _t(trig[1], torch.float32, device)
+
+
+def cone_threshold(angle_tol):
+    """eval.py:45 compares an f32 tensor with np.cos(2*angle_tol/180*pi): the comparison happens in f32."""
+    return float(np.float32(np.cos(2 * angle_tol / 180 * np.pi)))
+
+
+def percentile_params(n, ratio):
+    """(index k, weight gamma) np.percentile(x_f32[n], ratio*100) interpolates with -- NumPy 2.x arithmetic:
+    q = f32(q)/f32(100); virtual = (n-1)*q in f32; gamma = f32(f64(virtual) - floor)."""
+    q = np.true_divide(ratio * 100, np.float32(100))
+    q = np.asanyarray(q)
+    virt = np.asanyarray((n - 1) * q)
+    prev = np.floor(virt)
+    k = int(prev)
+    gamma = np.asanyarray(virt - prev.astype(np.intp), dtype=virt.dtype)
+    if k >= n - 1:
+        return max(n - 1, 0), 0.0
+    return k, float(gamma)
+
+
+def _offsets(counts, device):
+    off = np.zeros(len(counts) + 1, dtype=np.int32)
+    np.cumsum(np.asarray(counts, dtype=np.int64), out=off[1:])
+    return torch.from_numpy(off).to(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1. sampler
+# ----------------------------------------------------------------------------------------------
+def sample_tuples(num_points, num_tuples, k, seed, scene_ids=(0,), device=None):
+    """Replaces np.random.randint(0, N, (T, k)) (eval.py:207).  Returns int32 [B*T, k] for the scenes in
+    scene_ids (an arithmetic progression: base + b*stride)."""
+    device = device or _dev()
+    B = len(scene_ids)
+    stride = (scene_ids[1] - scene_ids[0]) if B > 1 else 1
+    assert all(scene_ids[b] == scene_ids[0] + b * stride for b in range(B)), "scene_ids must be arithmetic"
+    pt_off = _offsets([num_points] * B, device)
+    tup_off = _offsets([num_tuples] * B, device)
+    out = torch.empty((B * num_tuples, k), dtype=torch.int32, device=device)
+    _lib.check(_L.cppf_sample_tuples(B, _p(pt_off), _p(tup_off), num_tuples, k, C.c_uint64(seed),
+                                     int(scene_ids[0]), int(stride), _p(out), _stream()), "cppf_sample_tuples")
+    return out
+
+
+def philox_uniform(num_rows, m, seed, stream_id, scene_ids=(0,), device=None):
+    device = device or _dev()
+    B = len(scene_ids)
+    stride = (scene_ids[1] - scene_ids[0]) if B > 1 else 1
+    tup_off = _offsets([num_rows] * B, device)
+    out = torch.empty((B * num_rows, m), dtype=torch.float32, device=device)
+    _lib.check(_L.cppf_philox_uniform(B, _p(tup_off), num_rows, m, C.c_uint64(seed), int(scene_ids[0]), int(stride),
+                                      int(stream_id), _p(out), _stream()), "cppf_philox_uniform")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a3. encode
+# ----------------------------------------------------------------------------------------------
+def encode_tuples_shot(points, point_idxs_all, shot_feat, normal, pt_off=None, tup_off=None):
+    """BeyondCPPF.prepare_tuple_inputs of the SHOT model (train_shot.py:75-83): [T, C(k,2)*4 + k*F]."""
+    dev = _dev()
+    pts = _t(points, torch.float32, dev)
+    idx = _t(point_idxs_all, torch.int32, dev)
+    feat = _t(shot_feat, torch.float32, dev)
+    nrm = _t(normal, torch.float32, dev)
+    T, k = idx.shape
+    F = feat.shape[1]
+    B = 1 if pt_off is None else pt_off.numel() - 1
+    if pt_off is None:
+        pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    out = torch.empty((T, k * (k - 1) // 2 * 4 + k * F), dtype=torch.float32, device=dev)
+    _lib.check(_L.cppf_encode_tuples_shot(B, _p(pts), _p(nrm), _p(feat), F, _p(idx), k, _p(pt_off), _p(tup_off), T,
+                                          _p(out), _stream()), "cppf_encode_tuples_shot")
+    return out
+
+
+def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=None):
+    """Coordinate part of the DINO model's prepare_tuple_inputs (train_dino.py:92): [T, C(k,2)*3]
+    (written into the leading columns of `out` if given)."""
+    dev = _dev()
+    pts = _t(points, torch.float32, dev)
+    idx = _t(point_idxs_all, torch.int32, dev)
+    T, k = idx.shape
+    B = 1 if pt_off is None else pt_off.numel() - 1
+    if pt_off is None:
+        pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    ncol = k * (k - 1) // 2 * 3
+    if out is None:
+        out = torch.empty((T, ncol), dtype=torch.float32, device=dev)
+    assert out.is_contiguous() and out.shape[0] == T and out.shape[1] >= ncol and out.dtype == torch.float32
+    _lib.check(_L.cppf_encode_tuples_coord(B, _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T, _p(out),
+                                           out.shape[1], _stream()), "cppf_encode_tuples_coord")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a4 + a5. decode
+# ----------------------------------------------------------------------------------------------
+def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt_off=None, tup_off=None):
+    """eval.py:225-240.  pred_cls [T,6,nb] logits, uniforms [T,6] in [0,1).  (up, right, front) are the three
+    axis vectors in the positional order of generate_target_pairs' signature (the reference call site passes
+    cfg.up, cfg.front, cfg.right).  Returns dict(bins, pred_pairs_scaled [T,2,3], scale, targets_tr, targets_rot)."""
+    dev = _dev()
+    lg = _t(pred_cls, torch.float32, dev)
+    T, six, nb = lg.shape
+    assert six == 6
+    un = _t(uniforms, torch.float32, dev).reshape(T, 6)
+    pts = _t(points, torch.float32, dev)
+    idx = _t(point_idxs_all, torch.int32, dev)
+    k = idx.shape[1]
+    B = 1 if pt_off is None else pt_off.numel() - 1
+    if pt_off is None:
+        pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    bins = torch.empty((T, 6), dtype=torch.int32, device=dev)
+    scaled = torch.empty((T, 2, 3), dtype=torch.float32, device=dev)
+    scale = torch.empty((T,), dtype=torch.float32, device=dev)
+    tr = torch.empty((T, 2), dtype=torch.float32, device=dev)
+    rot = torch.empty((T, 3), dtype=torch.float32, device=dev)
+    _lib.check(_L.cppf_decode_bins(B, _p(lg), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
+                                   _axes9(up, right, front), _p(bins), _p(scaled), _p(scale), _p(tr), _p(rot),
+                                   _stream()), "cppf_decode_bins")
+    return dict(bins=bins, pred_pairs_scaled=scaled, scale=scale, targets_tr=tr, targets_rot=rot)
+
+
+def generate_target_pairs(point_pairs, up, right, front, center=np.zeros((3,))):
+    """dataset.py:118-135: NumPy in, NumPy out (float32 [T,2], float32 [T,3]), computed on the GPU."""
+    dev = _dev()
+    pp = _t(point_pairs, torch.float32, dev).reshape(-1, 6)
+    T = pp.shape[0]
+    tup_off = _offsets([T], dev)
+    ctr = _t(np.asarray(center, dtype=np.float64).reshape(1, 3), torch.float64, dev)
+    tr = torch.empty((T, 2), dtype=torch.float32, device=dev)
+    rot = torch.empty((T, 3), dtype=torch.float32, device=dev)
+    _lib.check(_L.cppf_generate_target_pairs(1, _p(pp), _p(tup_off), T, _axes9(up, right, front), _p(ctr), _p(tr),
+                                             _p(rot), _stream()), "cppf_generate_target_pairs")
+    return tr.cpu().numpy(), rot.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# a6. vote_center
+# ----------------------------------------------------------------------------------------------
+def scene_bounds(pts, pt_off, res):
+    B = pt_off.numel() - 1
+    grids = torch.empty((B, 32), dtype=torch.uint8, device=pts.device)
+    _lib.check(_L.cppf_scene_bounds(B, _p(pts), _p(pt_off), C.c_float(res), _p(grids), _stream()), "cppf_scene_bounds")
+    return grids
+
+
+def grids_to_host(grids):
+    raw = grids.cpu().numpy().tobytes()
+    n = len(raw) // 32
+    return (SceneGrid * n).from_buffer_copy(raw)
+
+
+def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, vis=None, trig=None, mode=0, return_device=False):
+    """train_dino.py:171-215.  Returns (grid_obj int64 ndarray [gx,gy,gz], cand_world float64 ndarray [3])."""
+    dev = _dev()
+    pts = _t(pc, torch.float32, dev)
+    tr = _t(preds_tr, torch.float32, dev)
+    idx = _t(point_idxs, torch.int32, dev)
+    T, k = idx.shape
+    cs, sn = _trig(num_rots, trig, dev)
+    pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    grids = scene_bounds(pts, pt_off, res)
+    g = grids_to_host(grids)[0]                       # the reference syncs here as well (.cpu() at :206)
+    if g.flags & 2 or g.ncell <= 0:
+        raise CppfError("vote_center: grid of %s cells is not representable" % (list(g.g),))
+    G = int(g.ncell)
+    grid = torch.empty((G,), dtype=torch.int32, device=dev)
+    grid_off = torch.tensor([0, G], dtype=torch.int64, device=dev)
+    ws_bytes = _L.cppf_vote_center_workspace_bytes(1, G)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    argmax = torch.empty((1,), dtype=torch.int64, device=dev)
+    peak = torch.empty((1,), dtype=torch.int32, device=dev)
+    world = torch.empty((1, 3), dtype=torch.float64, device=dev)
+    _lib.check(_L.cppf_vote_center(1, _p(pts), _p(pt_off), _p(idx), k, _p(tup_off), T, _p(tr), C.c_double(res),
+                                   num_rots, _p(cs), _p(sn), _p(grids), _p(grid), _p(grid_off), G, mode, _p(ws),
+                                   ws_bytes, _p(argmax), _p(peak), _p(world), _stream()), "cppf_vote_center")
+    shape = (int(g.g[0]), int(g.g[1]), int(g.g[2]))
+    if return_device:
+        return grid.view(shape), world[0], argmax, peak
+    grid_obj = grid.to(torch.int64).cpu().numpy().reshape(shape)
+    return grid_obj, world[0].cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# a8 / a9 with the reference's signatures
+# ----------------------------------------------------------------------------------------------
+def vote_rotation(pc, preds_rot, point_idxs, num_rots=36, trig=None):
+    """train_dino.py:218-239.  Returns (up float32 tensor [n, num_rots, 3], mask bool tensor [T])."""
+    dev = _dev()
+    pts = _t(pc, torch.float32, dev)
+    ang = _t(preds_rot, torch.float32, dev)
+    idx = _t(point_idxs, torch.int32, dev)
+    T, k = idx.shape
+    cs, sn = _trig(num_rots, trig, dev)
+    up = torch.empty((max(T, 1), num_rots, 3), dtype=torch.float32, device=dev)
+    valid = torch.empty((max(T, 1),), dtype=torch.uint8, device=dev)
+    nvalid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((max(T, 1) * 4,), dtype=torch.uint8, device=dev)
+    _lib.check(_L.cppf_vote_rotation(_p(pts), pts.shape[0], _p(idx), k, T, _p(ang), num_rots, _p(cs), _p(sn), _p(up),
+                                     _p(valid), _p(nvalid), _p(ws), ws.numel(), _stream()), "cppf_vote_rotation")
+    n = int(nvalid.item())
+    return up[:n], valid[:T].bool()
+
+
+def sphere_counts(pred, sphere_pts, bmm_size, angle_tol, wt=None):
+    """The accumulation half of get_topk_dir (eval.py:41-45): float32 counts [S] on the device."""
+    dev = _dev()
+    cand = _t(pred, torch.float32, dev).reshape(-1, 3)
+    sph = _t(sphere_pts, torch.float32, dev)
+    M, S = cand.shape[0], sph.shape[0]
+    w = None if wt is None else _t(wt, torch.float64, dev).reshape(-1)
+    if w is not None:
+        assert w.numel() == M
+    nch = max((M + bmm_size - 1) // bmm_size, 1)
+    ws = torch.empty((nch * S * 8,), dtype=torch.uint8, device=dev)
+    counts = torch.empty((S,), dtype=torch.float32, device=dev)
+    _lib.check(_L.cppf_sphere_counts(_p(cand), M, _p(w), _p(sph), S, C.c_float(cone_threshold(angle_tol)),
+                                     int(bmm_size), _p(counts), _p(ws), ws.numel(), _stream()), "cppf_sphere_counts")
+    return counts
+
+
+def get_topk_dir(pred, sphere_pts, bmm_size, angle_tol, wt=None, topk=1):
+    """eval.py:37-51.  Returns (dirs float32 ndarray [topk,3], counts float32 ndarray [topk])."""
+    counts = sphere_counts(pred, sphere_pts, bmm_size, angle_tol, wt)
+    topk_idx = torch.topk(counts, topk)[1].cpu().numpy()
+    sphere_np = np.asarray(sphere_pts)
+    return np.array(sphere_np[topk_idx]), counts.cpu().numpy()[topk_idx]

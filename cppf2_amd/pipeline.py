@@ -1,0 +1,151 @@
+"""Batched voting pipeline: eval.py:207-313 for B scenes at once, one launch per stage.
+
+The reference processes one object instance at a time with >= 6 host syncs per instance
+(SURVEY.md section 3.1).  Here every stage takes B scenes (ragged through offset arrays), all
+buffers are allocated once, nothing is copied to the host until the final per-scene record
+(CppfSceneResult, 160 bytes) is read, and no stage depends on a host-side value computed from
+device data (grid sizes are bounded by `cells_cap`, kept-pair counts by the percentile index).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import SceneResult
+
+_L = _lib.load()
+
+RESULT_DTYPE = np.dtype([("argmax", "<i8"), ("t", "<f8", (3,)), ("R", "<f8", (3, 3)), ("scale", "<f4", (3,)),
+                         ("peak", "<u4"), ("up_idx", "<i4"), ("right_idx", "<i4"), ("kept", "<i4"),
+                         ("up_count", "<f4"), ("right_count", "<f4"), ("flags", "<i4"), ("ncell", "<i4"), ("pad_", "<i4", (3,))])
+assert RESULT_DTYPE.itemsize == C.sizeof(SceneResult) == 160
+
+
+class VotingPipeline:
+    """Decode -> centre vote -> back-vote filter -> rotation votes -> pose, for a fixed batch geometry.
+
+    cfg_up / cfg_right / cfg_front are the YAML axis vectors (config/config.yaml:12-14).  The reference hands
+    (up, front, right) to generate_target_pairs(point_pairs, up, right, front) (eval.py:237-240), so column 2
+    of targets_rot is the angle to cfg_right; that quirk is reproduced here.
+    """
+
+    def __init__(self, counts_points, counts_tuples, k=5, res=2e-3, num_rots=180, angle_tol=1.0,
+                 backproj_ratio=0.1, imp_wt_margin=0.01, bmm_size=ops.BMM_SIZE, cfg_up=(0, 1, 0), cfg_right=(1, 0, 0),
+                 cfg_front=(0, 0, 1), cells_cap=1 << 21, vote_mode=0, sphere_pts=None, device=None, trig=None):
+        self.dev = device or ops._dev()
+        self.B = len(counts_points)
+        assert len(counts_tuples) == self.B
+        self.np_, self.nt_ = list(map(int, counts_points)), list(map(int, counts_tuples))
+        self.pt_off = ops._offsets(self.np_, self.dev)
+        self.tup_off = ops._offsets(self.nt_, self.dev)
+        self.Ntot, self.Ttot = int(sum(self.np_)), int(sum(self.nt_))
+        self.max_n, self.max_t = max(self.np_), max(self.nt_)
+        self.k, self.res, self.R = int(k), float(res), int(num_rots)
+        self.angle_tol, self.ratio, self.margin, self.bmm = float(angle_tol), float(backproj_ratio), float(imp_wt_margin), int(bmm_size)
+        self.cfg_up, self.cfg_right, self.cfg_front = np.array(cfg_up), np.array(cfg_right), np.array(cfg_front)
+        # positional (up, right, front) of generate_target_pairs <- (cfg.up, cfg.front, cfg.right), eval.py:237-240
+        self.axes = ops._axes9(self.cfg_up, self.cfg_front, self.cfg_right)
+        self.up_axis = int(np.nonzero(self.cfg_up)[0][0])
+        self.right_axis = int(np.nonzero(self.cfg_right)[0][0])
+        self.cells_cap = int(cells_cap)
+        self.vote_mode = int(vote_mode)
+        sph = ops.sphere_bins(angle_tol) if sphere_pts is None else np.asarray(sphere_pts, dtype=np.float32)
+        self.sphere_np = sph
+        self.S = sph.shape[0]
+        self.fib = 1 if ops.is_fibonacci(sph) else 0
+        self.sphere = torch.from_numpy(sph).to(self.dev)
+        self.cos_thr = ops.cone_threshold(angle_tol)
+        self.cs, self.sn = ops._trig(self.R, trig, self.dev)
+        kg = [ops.percentile_params(n, self.ratio) for n in self.nt_]
+        self.kidx = torch.tensor([a for a, _ in kg], dtype=torch.int32, device=self.dev)
+        self.gamma = torch.tensor([b for _, b in kg], dtype=torch.float32, device=self.dev)
+        self.max_kept = max(a for a, _ in kg) + 1
+        d, B, T = self.dev, self.B, self.Ttot
+        e = torch.empty
+        self.grids = e((B, 32), dtype=torch.uint8, device=d)
+        self.bins = e((T, 6), dtype=torch.int32, device=d)
+        self.scaled = e((T, 2, 3), dtype=torch.float32, device=d)
+        self.scale = e((T,), dtype=torch.float32, device=d)
+        self.tr = e((T, 2), dtype=torch.float32, device=d)
+        self.rot = e((T, 3), dtype=torch.float32, device=d)
+        self.argmax = e((B,), dtype=torch.int64, device=d)
+        self.peak = e((B,), dtype=torch.int32, device=d)
+        self.world = e((B, 3), dtype=torch.float64, device=d)
+        self.mask = e((T,), dtype=torch.uint8, device=d)
+        self.kept_tuple = e((T,), dtype=torch.int32, device=d)
+        self.kept_count = e((B,), dtype=torch.int32, device=d)
+        self.kept_wt = e((T,), dtype=torch.float64, device=d)
+        self.kept_row0 = e((T,), dtype=torch.int32, device=d)
+        self.errs = e((T,), dtype=torch.float32, device=d)
+        self.thr = e((B,), dtype=torch.float32, device=d)
+        self.counts = e((2, B, self.S), dtype=torch.float32, device=d)
+        self.top_idx = e((2, B), dtype=torch.int32, device=d)
+        self.top_cnt = e((2, B), dtype=torch.float32, device=d)
+        self.results = e((B, 160), dtype=torch.uint8, device=d)
+        self.ws_vote_bytes = _L.cppf_vote_center_workspace_bytes(B, self.cells_cap)
+        self.ws_bv_bytes = _L.cppf_backvote_workspace_bytes(self.Ntot, B)
+        self.ws_rot_bytes = _L.cppf_rot_bins_workspace_bytes(B, self.S, self.max_kept, self.R, self.bmm)
+        self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
+
+    # -- stages ---------------------------------------------------------------------------------
+    def decode(self, pts, idx, logits, uniforms):
+        _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), logits.shape[-1], ops._p(uniforms), ops._p(pts),
+                                       ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
+                                       self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
+                                       ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")
+
+    def vote_center(self, pts, idx, grid=None, grid_off=None):
+        st = ops._stream()
+        _lib.check(_L.cppf_scene_bounds(self.B, ops._p(pts), ops._p(self.pt_off), C.c_float(self.res),
+                                        ops._p(self.grids), st), "cppf_scene_bounds")
+        _lib.check(_L.cppf_vote_center(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                       ops._p(self.tup_off), self.max_t, ops._p(self.tr), C.c_double(self.res),
+                                       self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.grids), ops._p(grid),
+                                       ops._p(grid_off), self.cells_cap, self.vote_mode, ops._p(self.ws),
+                                       self.ws_vote_bytes, ops._p(self.argmax), ops._p(self.peak), ops._p(self.world),
+                                       st), "cppf_vote_center")
+
+    def backvote(self, pts, idx):
+        _lib.check(_L.cppf_backvote_filter(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                           ops._p(self.tup_off), ops._p(self.tr), ops._p(self.world), self.axes,
+                                           ops._p(self.kidx), ops._p(self.gamma), C.c_double(self.margin), self.R,
+                                           ops._p(self.mask), ops._p(self.kept_tuple), ops._p(self.kept_count),
+                                           ops._p(self.kept_wt), ops._p(self.kept_row0), ops._p(self.errs),
+                                           ops._p(self.thr), ops._p(self.ws), self.ws_bv_bytes, ops._stream()),
+                   "cppf_backvote_filter")
+
+    def rot_bins(self, pts, idx, fibonacci=None):
+        fib = self.fib if fibonacci is None else int(fibonacci)
+        for a, col in ((0, 0), (1, 2)):            # up <- targets_rot[:,0], "right" <- targets_rot[:,2] (eval.py:278,287)
+            _lib.check(_L.cppf_rot_bins(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                        ops._p(self.tup_off), ops._p(self.rot), col, ops._p(self.kept_tuple),
+                                        ops._p(self.kept_count), ops._p(self.kept_wt), ops._p(self.kept_row0),
+                                        self.max_kept, self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.sphere),
+                                        self.S, C.c_float(self.cos_thr), self.bmm, fib, ops._p(self.counts[a]),
+                                        ops._p(self.top_idx[a]), ops._p(self.top_cnt[a]), ops._p(self.ws),
+                                        self.ws_rot_bytes, ops._stream()), "cppf_rot_bins")
+
+    def assemble(self, pred_scales=None):
+        _lib.check(_L.cppf_assemble_pose(self.B, ops._p(self.sphere), ops._p(self.top_idx[0]), ops._p(self.top_cnt[0]),
+                                         ops._p(self.top_idx[1]), ops._p(self.top_cnt[1]), self.up_axis,
+                                         self.right_axis, ops._p(self.argmax), ops._p(self.peak), ops._p(self.world),
+                                         ops._p(self.grids), ops._p(pred_scales), ops._p(self.tup_off),
+                                         ops._p(self.kept_tuple), ops._p(self.kept_count), ops._p(self.results),
+                                         ops._stream()), "cppf_assemble_pose")
+
+    def vote(self, pts, idx, logits, uniforms, pred_scales=None, grid=None, grid_off=None):
+        """Everything after the MLP: eval.py:225-313.  All arguments are device tensors in the batch layout.
+        Returns the device tensor of B result records (uint8 [B,160]); use results_to_numpy() to read them."""
+        self.decode(pts, idx, logits, uniforms)
+        self.vote_center(pts, idx, grid, grid_off)
+        self.backvote(pts, idx)
+        self.rot_bins(pts, idx)
+        self.assemble(pred_scales)
+        return self.results
+
+    def results_to_numpy(self, results=None):
+        r = self.results if results is None else results
+        return np.frombuffer(r.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).copy()

@@ -1,0 +1,57 @@
+"""Drop-in for the reference's native module `src_shot.build.shot` (src_shot/shot.cpp:164-168).
+
+    from cppf2_amd import shot
+    shot_feat, normal = shot.compute(pc, normal_r, shot_r)     # eval.py:210
+
+Same call signature and return convention as the pybind11 module: NumPy float arrays in (float64 is
+silently converted like pybind11's forcecast, shot.cpp:45), a list of two 1-D float32 arrays out that
+the caller reshapes to [N,352] / [N,3] (eval.py:211,214); rows PCL leaves undefined are NaN.
+The computation runs on the GPU (cppf_shot352 in libcppf_hip.so); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+_L = _lib.load()
+
+
+def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
+    """Batched device API: pts float32 [Ntot,3] (device), pt_off int32 [B+1] (device).
+    Returns (shot [Ntot,352], normal [Ntot,3][, rf [Ntot,9]]) device tensors."""
+    dev = pts.device
+    n = pts.shape[0]
+    B = pt_off.numel() - 1
+    out_shot = torch.empty((n, 352), dtype=torch.float32, device=dev)
+    out_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_rf = torch.empty((n, 9), dtype=torch.float32, device=dev) if want_rf else None
+    _lib.check(_L.cppf_shot352(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
+                               ops._p(out_shot), ops._p(out_normal), ops._p(out_rf), None, 0, ops._stream()),
+               "cppf_shot352")
+    if want_rf:
+        return out_shot, out_normal, out_rf
+    return out_shot, out_normal
+
+
+def compute(pc, normal_r=0.1, shot_r=0.17):
+    """shot.compute (src_shot/shot.cpp:45-100): returns [float32[N*352], float32[N*3]]."""
+    dev = ops._dev()
+    pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
+    pt_off = ops._offsets([pts.shape[0]], dev)
+    s, n = compute_device(pts, pt_off, float(normal_r), float(shot_r))
+    return [s.reshape(-1).cpu().numpy(), n.reshape(-1).cpu().numpy()]
+
+
+def estimate_normal(pc, normal_r):
+    """shot.estimate_normal (src_shot/shot.cpp:12-42): returns float32[N*3]."""
+    dev = ops._dev()
+    pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
+    pt_off = ops._offsets([pts.shape[0]], dev)
+    out = torch.empty((pts.shape[0], 3), dtype=torch.float32, device=dev)
+    _lib.check(_L.cppf_estimate_normals(1, ops._p(pts), ops._p(pt_off), pts.shape[0], C.c_float(normal_r), ops._p(out),
+                                        ops._stream()), "cppf_estimate_normals")
+    return out.reshape(-1).cpu().numpy()

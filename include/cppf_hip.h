@@ -1,0 +1,204 @@
+/*
+ * cppf_hip.h -- C ABI of libcppf_hip.so, the MI355X (gfx950) implementation of the
+ * CPPF++ (qq456cvb/CPPF2) point-pair-feature voting hot path.
+ *
+ * The reference has no FFI of its own for this path except one pybind11 module
+ * (src_shot/shot.cpp:164-168); everything else is Python glue over torch ops.  Each entry
+ * point below names the reference code it replaces (file:line under the reference root).
+ * The Python binding (ctypes) lives in cppf2_amd/_lib.py; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative CPPF_E* code; no C++ exception
+ *    crosses the boundary; cppf_last_error_string() describes the last failure of the
+ *    calling thread.
+ *  - all pointers are DEVICE pointers unless the name starts with h_ (host).  The caller
+ *    owns every buffer (inputs, outputs, workspace); the library allocates nothing.
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); functions
+ *    are re-entrant; there is no global mutable state.
+ *  - batch-first: B independent scenes per call.  Ragged scenes are described by device
+ *    offset arrays pt_off[B+1] (points) and tup_off[B+1] (tuples), int32, plus host-side
+ *    maxima used only to size launches.
+ *  - point indices are int32; tuples are rows of `k` indices (k = 2 + num_more, <= 8).
+ */
+#ifndef CPPF_HIP_H_
+#define CPPF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPPF_OK            0
+#define CPPF_EINVAL       -1   /* bad argument (null pointer, size out of range) */
+#define CPPF_EUNSUPPORTED -2   /* valid request this build does not implement */
+#define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
+#define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
+
+#define CPPF_ABI_VERSION 1
+
+/* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
+typedef struct CppfSceneGrid {
+  float   c0[3];    /* pc.min(0) */
+  int32_t g[3];     /* ((max-min)/res).long() + 1 */
+  int32_t ncell;    /* g[0]*g[1]*g[2], 0 if empty / overflow */
+  int32_t flags;    /* bit0: empty scene; bit1: cell count overflows int32 */
+} CppfSceneGrid;
+
+/* Per-scene result record gathered across ranks (one RCCL all_gather). 160 bytes. */
+typedef struct CppfSceneResult {
+  int64_t  argmax;       /* flat index of the first maximum of the centre grid (C order) */
+  double   t[3];         /* cand_world = c0 + cell*res, float64 like train_dino.py:213 */
+  double   R[9];         /* row-major R_est, eval.py:298-313 */
+  float    scale[3];     /* lower median of pred_scales over kept pairs, eval.py:309 */
+  uint32_t peak;         /* vote count at argmax */
+  int32_t  up_idx;       /* top-1 sphere bin of the "up" vote, eval.py:284 */
+  int32_t  right_idx;    /* top-1 sphere bin of the "right" vote, eval.py:292 */
+  int32_t  kept;         /* pairs surviving the back-vote filter, eval.py:258 */
+  float    up_count;     /* counts[up_idx] */
+  float    right_count;  /* counts[right_idx] */
+  int32_t  flags;        /* CppfSceneGrid.flags | (bit2: grid larger than cells_cap) */
+  int32_t  ncell;        /* cells of the scene's vote grid */
+  int32_t  pad_[3];
+} CppfSceneResult;
+
+int         cppf_version(void);
+const char* cppf_last_error_string(void);
+
+/* ---- a1. tuple sampler: replaces np.random.randint(0, N, (T, k)) at eval.py:207,
+ * train_shot.py:88, train_dino.py:103.  Philox4x32-10, counter (tuple, word-block, scene id, 0),
+ * key = seed; scene id of scene b = scene_id_base + b*scene_id_stride, so the table does not
+ * depend on how scenes are sharded over ranks.  out_idx: int32[tup_off[B], k]. */
+int cppf_sample_tuples(int B, const int32_t* pt_off, const int32_t* tup_off, int max_t, int k,
+                       uint64_t seed, int32_t scene_id_base, int32_t scene_id_stride,
+                       int32_t* out_idx, void* stream);
+
+/* Uniforms in [0,1) (24-bit) from the same generator, counter (row, word-block, scene id, stream_id):
+ * stands in for the unseeded torch.multinomial draw of eval.py:229.  out: float32[tup_off[B], m], m <= 8. */
+int cppf_philox_uniform(int B, const int32_t* tup_off, int max_t, int m, uint64_t seed,
+                        int32_t scene_id_base, int32_t scene_id_stride, int32_t stream_id,
+                        float* out, void* stream);
+
+/* ---- a2. SHOT352 + normals: replaces shot.compute(pc, normal_r, shot_r) (src_shot/shot.cpp:45-100,
+ * PCL 1.9.1 NormalEstimation + SHOTEstimation).  out_shot: float32[n,352], out_normal: float32[n,3];
+ * rows PCL would leave NaN are written as NaN (callers zero them, eval.py:215-216).
+ * workspace: cppf_shot352_workspace_bytes(total_points) bytes. */
+int64_t cppf_shot352_workspace_bytes(int64_t total_points);
+int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r, float shot_r,
+                 float* out_shot, float* out_normal, float* out_rf /* optional float32[n,9] local frames */,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+/* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42). */
+int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
+                          float* out_normal, void* stream);
+
+/* ---- a3. tuple encode: replaces BeyondCPPF.prepare_tuple_inputs.
+ * SHOT model (train_shot.py:75-83): row = [p_i-p_j for i<j (C(k,2)*3) | max(n_i.n_j, -n_i.n_j) (C(k,2)) |
+ *   feat[idx_0..k-1] (k*feat_dim)]; feat is the per-point output of shot_encoder, float32[n,feat_dim],
+ *   feat_dim % 4 == 0.  out: float32[tup_off[B], C(k,2)*4 + k*feat_dim].
+ * DINO model (train_dino.py:92): only the coordinate part, written at the start of rows of
+ *   `out_stride` floats (the descriptor part is an nn.Linear, left to PyTorch). */
+int cppf_encode_tuples_shot(int B, const float* pts, const float* normals, const float* feat, int feat_dim,
+                            const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                            int64_t total_tuples, float* out, void* stream);
+int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
+                             const int32_t* tup_off, int64_t total_tuples, float* out, int out_stride,
+                             void* stream);
+
+/* ---- a4+a5. bin decode + vote parameters: replaces eval.py:225-240 (softmax, one multinomial draw per
+ * (tuple, coord) by inverse CDF from `uniforms`, bin/(nb-1)-0.5, per-pair metric scale) fused with
+ * generate_target_pairs(pred_pairs_scaled, a1, a2, a3) (dataset.py:118-135, centre 0).
+ * logits: float32[T,6,nb] (nb <= 64); uniforms: float32[T,6]; h_axes: 9 doubles = the three axis vectors
+ * in the positional order handed to generate_target_pairs (eval.py passes up, front, right).
+ * Outputs (any may be NULL): bins int32[T,6], scaled float32[T,6] (pred_pairs_scaled), scale float32[T],
+ * tr float32[T,2] (proj_len, dist2o), rot float32[T,3]. */
+int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
+                     const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                     int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled, float* scale,
+                     float* tr, float* rot, void* stream);
+
+/* generate_target_pairs(point_pairs, a1, a2, a3, center) (dataset.py:118-135) for explicit pairs
+ * float32[T,2,3]; centers: float64[B,3] per scene (NULL = zeros). */
+int cppf_generate_target_pairs(int B, const float* pairs, const int32_t* tup_off, int64_t total_tuples,
+                               const double* h_axes, const double* centers, float* tr, float* rot, void* stream);
+
+/* ---- a6. centre Hough vote + argmax: replaces vote_center (train_dino.py:171-215).
+ * cppf_scene_bounds fills CppfSceneGrid[B] (train_dino.py:172-173).
+ * cppf_vote_center accumulates the votes and extracts the first maximum.
+ *   tr: float32[T,2]; cos_tab/sin_tab: device float32[num_rots] (train_dino.py:194-195 table, built by the caller
+ *     so that table values are an input, not a libm detail);
+ *   grid / grid_off: optional uint32 output grid (all scenes concatenated, scene b at grid_off[b],
+ *     int64 device offsets); pass NULL to keep the accumulator on-chip only.
+ *   cells_cap: upper bound on ncell of any scene in the batch (sizes the launch; scenes above it get
+ *     flags bit2 and no votes).  mode: 0 = auto, 1 = LDS-slab accumulation, 2 = global atomics.
+ *   workspace: cppf_vote_center_workspace_bytes(B, cells_cap) bytes.
+ *   out_argmax int64[B], out_peak uint32[B], out_world float64[B,3]. */
+int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off, float res, CppfSceneGrid* out, void* stream);
+int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap);
+int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                     const int32_t* tup_off, int max_t, const float* tr, double res, int num_rots,
+                     const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
+                     uint32_t* grid, const int64_t* grid_off, int64_t cells_cap, int mode,
+                     void* workspace, int64_t workspace_bytes,
+                     int64_t* out_argmax, uint32_t* out_peak, double* out_world, void* stream);
+
+/* ---- a7. back-vote ("noisy pair") filter + importance weights: replaces eval.py:251-275.
+ *   centers: float64[B,3] voted centres (T_est); kidx/gamma: per scene, the order-statistic index and
+ *   interpolation weight np.percentile(back_errs, ratio*100) uses (device arrays int32[B], float32[B];
+ *   cppf2_amd.ops.percentile_params computes them exactly as NumPy does).
+ *   Outputs: mask uint8[T]; kept_tuple int32 (scene b's kept tuples, in order, at tup_off[b]..),
+ *   kept_count int32[B]; kept_wt float64 (imp_pair_wt, same layout as kept_tuple);
+ *   kept_row0 int32 (first row of the pair in the flattened candidate list of vote_rotation, -1 if
+ *   |ab| <= 1e-7, train_dino.py:223); back_errs float32[T] and thr float32[B] optional.
+ *   workspace: cppf_backvote_workspace_bytes(total_points) bytes. */
+int64_t cppf_backvote_workspace_bytes(int64_t total_points, int B);
+int cppf_backvote_filter(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                         const int32_t* tup_off, const float* tr, const double* centers, const double* h_axes,
+                         const int32_t* kidx, const float* gamma, double imp_wt_margin, int num_rots,
+                         uint8_t* mask, int32_t* kept_tuple, int32_t* kept_count, double* kept_wt,
+                         int32_t* kept_row0, float* back_errs, float* thr,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- a8+a9. rotation vote: replaces vote_rotation (train_dino.py:218-239) fused with get_topk_dir
+ * (eval.py:37-51): candidates are generated in registers and tested against the `S` sphere bins.
+ *   rot: float32[T,3] (targets_rot); rot_col: which column holds the angle (0 = up, 2 = "right", eval.py:278,287);
+ *   the kept_* arrays come from cppf_backvote_filter; max_kept >= max_b kept_count[b];
+ *   sphere: float32[S,3]; cos_thr = float32(cos(2*angle_tol deg)); bmm_size: rows per float32
+ *   accumulation chunk (eval.py:81, 100000).  fibonacci != 0 promises sphere is fibonacci_sphere(S)
+ *   (utils/util.py:191-207) and enables the windowed search.
+ *   Outputs: counts float32[B,S], top_idx int32[B], top_count float32[B].
+ *   workspace: cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size). */
+int64_t cppf_rot_bins_workspace_bytes(int B, int S, int max_kept, int num_rots, int bmm_size);
+int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                  const int32_t* tup_off, const float* rot, int rot_col,
+                  const int32_t* kept_tuple, const int32_t* kept_count, const double* kept_wt,
+                  const int32_t* kept_row0, int max_kept, int num_rots, const float* cos_tab, const float* sin_tab,
+                  const float* sphere, int S, float cos_thr, int bmm_size, int fibonacci,
+                  float* counts, int32_t* top_idx, float* top_count,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Stand-alone halves with the reference's own signatures (used by the drop-in wrappers):
+ * vote_rotation -> up float32[n_valid, num_rots, 3] (valid pairs compacted in order), valid uint8[T];
+ * get_topk_dir on explicit candidates float32[M,3] with weights float64[M] (NULL = ones). */
+int cppf_vote_rotation(const float* pts, int n_points, const int32_t* idx, int k, int T, const float* rot_angle,
+                       int num_rots, const float* cos_tab, const float* sin_tab,
+                       float* up, uint8_t* valid, int32_t* n_valid, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+int cppf_sphere_counts(const float* cand, int64_t M, const double* wt, const float* sphere, int S,
+                       float cos_thr, int bmm_size, float* counts, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+
+/* ---- a11. pose assembly: replaces eval.py:295-313 (Gram-Schmidt, cross product, median scale).
+ *   h_up_axis / h_right_axis: column of R the up / right vote fills (np.where(cfg.up)[0][0]).
+ *   pred_scales float32[T,3] (MLP scale head) may be NULL. */
+int cppf_assemble_pose(int B, const float* sphere, const int32_t* up_idx, const float* up_count,
+                       const int32_t* right_idx, const float* right_count, int up_axis, int right_axis,
+                       const int64_t* argmax, const uint32_t* peak, const double* world,
+                       const CppfSceneGrid* grids, const float* pred_scales, const int32_t* tup_off,
+                       const int32_t* kept_tuple, const int32_t* kept_count,
+                       CppfSceneResult* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPPF_HIP_H_ */

@@ -1,0 +1,307 @@
+/*
+ * shot_oracle.c -- CPU oracle for shot.compute / estimate_normal.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * PARITY UNPINNED.  The reference's src_shot/shot.cpp:12-100 is a thin pybind11 wrapper over
+ * PCL 1.9.1 (environment.yml:39: pcl=1.9.1, flann=1.9.1): pcl::NormalEstimation<PointXYZ,Normal>,
+ * pcl::SHOTEstimation<PointXYZ,Normal,SHOT352> (+ SHOTLocalReferenceFrameEstimation) over a
+ * pcl::search::KdTree (FLANN).  PCL is a third-party dependency that is NOT under /root/reference
+ * and is not installed in this image; the reference has no tests or golden vectors for it.  This file
+ * therefore restates PCL 1.9.1's published algorithm (features/impl/normal_3d.hpp, shot_lrf.hpp,
+ * shot.hpp) from its documentation and is validated by invariants and hand-built known-answer
+ * clouds (tests/test_shot.py), not by PCL outputs.
+ *
+ * Stated deviations from PCL 1.9.1 (all below PCL's own float rounding noise):
+ *  - neighbour order is ascending point index (PCL: FLANN distance order).  Only float summation
+ *    order depends on it, except the 5-point median rule of the LRF sign tie-break, which is
+ *    evaluated here on the (distance, index)-sorted list like PCL does.
+ *  - normal covariance is accumulated in double about the query point (PCL 1.9.1: single-pass float
+ *    on raw coordinates, whose cancellation error at z ~ 0.8 m is ~1e-3 relative).
+ *  - 3x3 symmetric eigenproblems use cyclic Jacobi in double (PCL: closed-form float eigen33 for
+ *    normals, Eigen::SelfAdjointEigenSolver<Matrix3d> for the LRF).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SHOT_LEN 352
+#define NR_BINS 10          /* nr_shape_bins_ */
+#define MAX_SECTORS 32
+
+/* Cyclic Jacobi for a symmetric 3x3 matrix; eigenvalues ascending in w, eigenvectors in columns of v. */
+static void jacobi3(const double a_in[6] /* xx xy xz yy yz zz */, double w[3], double v[3][3]) {
+  double a[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int p = 0; p < 2; ++p) {
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = a[p][q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0);
+        const double s = t * c;
+        a[p][p] = a[p][p] - t * apq;
+        a[q][q] = a[q][q] + t * apq;
+        a[p][q] = 0.0;
+        a[q][p] = 0.0;
+        const int r = 3 - p - q;
+        const double arp = a[r][p], arq = a[r][q];
+        a[r][p] = c * arp - s * arq;
+        a[p][r] = a[r][p];
+        a[r][q] = s * arp + c * arq;
+        a[q][r] = a[r][q];
+        for (int i = 0; i < 3; ++i) {
+          const double vip = v[i][p], viq = v[i][q];
+          v[i][p] = c * vip - s * viq;
+          v[i][q] = s * vip + c * viq;
+        }
+      }
+    }
+  }
+  int order[3] = {0, 1, 2};
+  double d[3] = {a[0][0], a[1][1], a[2][2]};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2 - i; ++j)
+      if (d[order[j]] > d[order[j + 1]]) { int tmp = order[j]; order[j] = order[j + 1]; order[j + 1] = tmp; }
+  double vv[3][3];
+  memcpy(vv, v, sizeof(vv));
+  for (int k = 0; k < 3; ++k) {
+    w[k] = d[order[k]];
+    for (int i = 0; i < 3; ++i) v[i][k] = vv[i][order[k]];
+  }
+}
+
+static float sqdist(const float* a, const float* b) {
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* pcl::NormalEstimation with radius search + flipNormalTowardsViewpoint(vp = origin). */
+void shot_oracle_normals(const float* pts, int n, float radius, float* normals) {
+  const float r2 = radius * radius;
+  for (int i = 0; i < n; ++i) {
+    const float* p = pts + 3 * i;
+    double s[9] = {0};
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) {
+      const float* q = pts + 3 * j;
+      if (!(sqdist(p, q) < r2)) continue;
+      const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+      s[0] += x * x; s[1] += x * y; s[2] += x * z; s[3] += y * y; s[4] += y * z; s[5] += z * z;
+      s[6] += x; s[7] += y; s[8] += z;
+      ++cnt;
+    }
+    float* o = normals + 3 * i;
+    if (cnt < 3) { o[0] = o[1] = o[2] = NAN; continue; }
+    const double inv = 1.0 / (double)cnt;
+    const double mx = s[6] * inv, my = s[7] * inv, mz = s[8] * inv;
+    const double cov[6] = {s[0] * inv - mx * mx, s[1] * inv - mx * my, s[2] * inv - mx * mz,
+                           s[3] * inv - my * my, s[4] * inv - my * mz, s[5] * inv - mz * mz};
+    double w[3], v[3][3];
+    jacobi3(cov, w, v);
+    double nx = v[0][0], ny = v[1][0], nz = v[2][0];
+    /* flip towards the viewpoint (0,0,0): (vp - p) . n < 0  -> negate */
+    const double ct = (0.0 - (double)p[0]) * nx + (0.0 - (double)p[1]) * ny + (0.0 - (double)p[2]) * nz;
+    if (ct < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+    o[0] = (float)nx; o[1] = (float)ny; o[2] = (float)nz;
+  }
+}
+
+typedef struct { float d2; int idx; } Nb;
+static int nb_cmp(const void* a, const void* b) {
+  const Nb* x = (const Nb*)a; const Nb* y = (const Nb*)b;
+  if (x->d2 < y->d2) return -1;
+  if (x->d2 > y->d2) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+/* SHOTLocalReferenceFrameEstimation::getLocalRF.  rf = rows x, y, z (float); returns 0 if NaN. */
+static int shot_lrf(const float* pts, int n, int i, float radius, float rf[9]) {
+  const float* p = pts + 3 * i;
+  const float r2 = radius * radius;
+  double cov[6] = {0}, sum = 0.0;
+  int valid = 0;
+  for (int j = 0; j < n; ++j) {
+    const float* q = pts + 3 * j;
+    const float d2 = sqdist(p, q);
+    if (!(d2 < r2)) continue;
+    if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) continue;
+    const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+    const double w = (double)radius - (double)sqrtf(d2);
+    cov[0] += w * (x * x); cov[1] += w * (x * y); cov[2] += w * (x * z);
+    cov[3] += w * (y * y); cov[4] += w * (y * z); cov[5] += w * (z * z);
+    sum += w;
+    ++valid;
+  }
+  if (valid < 5) { for (int c = 0; c < 9; ++c) rf[c] = NAN; return 0; }
+  for (int c = 0; c < 6; ++c) cov[c] /= sum;
+  double w[3], v[3][3];
+  jacobi3(cov, w, v);
+  if (!isfinite(w[0]) || !isfinite(w[1]) || !isfinite(w[2])) { for (int c = 0; c < 9; ++c) rf[c] = NAN; return 0; }
+  double v1[3] = {v[0][2], v[1][2], v[2][2]};   /* largest eigenvalue  -> x */
+  double v3[3] = {v[0][0], v[1][0], v[2][0]};   /* smallest eigenvalue -> z */
+  int plus1 = 0, plus3 = 0;
+  for (int j = 0; j < n; ++j) {
+    const float* q = pts + 3 * j;
+    const float d2 = sqdist(p, q);
+    if (!(d2 < r2)) continue;
+    if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) continue;
+    const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+    if ((x * v1[0] + y * v1[1]) + z * v1[2] >= 0.0) ++plus1;
+    if ((x * v3[0] + y * v3[1]) + z * v3[2] >= 0.0) ++plus3;
+  }
+  plus1 = 2 * plus1 - valid;
+  plus3 = 2 * plus3 - valid;
+  if (plus1 == 0 || plus3 == 0) {
+    /* tie: look at the 5 neighbours around the median of the distance-sorted valid list */
+    Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)valid);
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+      const float* q = pts + 3 * j;
+      const float d2 = sqdist(p, q);
+      if (!(d2 < r2)) continue;
+      if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) continue;
+      nb[m].d2 = d2; nb[m].idx = j; ++m;
+    }
+    qsort(nb, (size_t)m, sizeof(Nb), nb_cmp);
+    const int med = valid / 2;
+    int c1 = 0, c3 = 0;
+    for (int t = -2; t <= 2; ++t) {
+      const float* q = pts + 3 * nb[med - t].idx;
+      const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+      if ((x * v1[0] + y * v1[1]) + z * v1[2] > 0.0) ++c1;
+      if ((x * v3[0] + y * v3[1]) + z * v3[2] > 0.0) ++c3;
+    }
+    free(nb);
+    if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
+    if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
+  }
+  if (plus1 < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
+  if (plus3 < 0) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+  rf[0] = (float)v1[0]; rf[1] = (float)v1[1]; rf[2] = (float)v1[2];
+  rf[6] = (float)v3[0]; rf[7] = (float)v3[1]; rf[8] = (float)v3[2];
+  /* y = z x x (float) */
+  rf[3] = rf[7] * rf[2] - rf[8] * rf[1];
+  rf[4] = rf[8] * rf[0] - rf[6] * rf[2];
+  rf[5] = rf[6] * rf[1] - rf[7] * rf[0];
+  return 1;
+}
+
+#define RAD_45 0.78539816339744830961566084581988
+#define RAD_90 1.5707963267948966192313216916398
+#define RAD_135 2.3561944901923449288469825374596
+#define RAD_PI_7_8 2.7488935718910690836548129603691
+
+/* one neighbour's contribution (SHOTEstimation::interpolateSingleChannel body); returns nothing, adds into shot[] */
+static void shot_accumulate(const float* p, const float* q, float d2, const float* nq, const float rf[9], double radius,
+                            float* shot) {
+  /* createBinDistanceShape */
+  if (!isfinite(nq[0]) || !isfinite(nq[1]) || !isfinite(nq[2])) return;
+  double cosd = (double)((nq[0] * rf[6] + nq[1] * rf[7]) + nq[2] * rf[8]);
+  if (cosd > 1.0) cosd = 1.0;
+  if (cosd < -1.0) cosd = -1.0;
+  double bin_distance = ((1.0 + cosd) * NR_BINS) / 2;
+
+  const double distance = sqrt((double)d2);
+  if (fabs(distance) < 1e-15) return;
+  const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+  double xf = (double)((dx * rf[0] + dy * rf[1]) + dz * rf[2]);
+  double yf = (double)((dx * rf[3] + dy * rf[4]) + dz * rf[5]);
+  double zf = (double)((dx * rf[6] + dy * rf[7]) + dz * rf[8]);
+  if (fabs(yf) < 1e-30) yf = 0;
+  if (fabs(xf) < 1e-30) xf = 0;
+  if (fabs(zf) < 1e-30) zf = 0;
+  const double r12 = radius / 2.0, r14 = radius / 4.0, r34 = radius * 3.0 / 4.0;
+
+  const int bit4 = ((yf > 0) || ((yf == 0.0) && (xf < 0))) ? 1 : 0;
+  const int bit3 = ((xf > 0) || ((xf == 0.0) && (yf > 0))) ? !bit4 : bit4;
+  int desc_index = (bit4 << 3) + (bit3 << 2);
+  desc_index = desc_index << 1;
+  if ((xf * yf > 0) || (xf == 0.0))
+    desc_index += (fabs(xf) >= fabs(yf)) ? 0 : 4;
+  else
+    desc_index += (fabs(xf) > fabs(yf)) ? 4 : 0;
+  desc_index += zf > 0 ? 1 : 0;
+  desc_index += (distance > r12) ? 2 : 0;
+
+  const int step_index = (int)floor(bin_distance + 0.5);
+  const int volume_index = desc_index * (NR_BINS + 1);
+  bin_distance -= step_index;
+  double w = 1.0 - fabs(bin_distance);
+  if (bin_distance > 0)
+    shot[volume_index + ((step_index + 1) % NR_BINS)] += (float)bin_distance;
+  else
+    shot[volume_index + ((step_index - 1 + NR_BINS) % NR_BINS)] += -(float)bin_distance;
+
+  if (distance > r12) {
+    const double rd = (distance - r34) / r12;
+    if (distance > r34) w += 1 - rd;
+    else { w += 1 + rd; shot[(desc_index - 2) * (NR_BINS + 1) + step_index] -= (float)rd; }
+  } else {
+    const double rd = (distance - r14) / r12;
+    if (distance < r14) w += 1 + rd;
+    else { w += 1 - rd; shot[(desc_index + 2) * (NR_BINS + 1) + step_index] += (float)rd; }
+  }
+
+  double inc_cos = zf / distance;
+  if (inc_cos < -1.0) inc_cos = -1.0;
+  if (inc_cos > 1.0) inc_cos = 1.0;
+  const double inc = acos(inc_cos);
+  if (inc > RAD_90 || (fabs(inc - RAD_90) < 1e-30 && zf <= 0)) {
+    const double id = (inc - RAD_135) / RAD_90;
+    if (inc > RAD_135) w += 1 - id;
+    else { w += 1 + id; shot[(desc_index + 1) * (NR_BINS + 1) + step_index] -= (float)id; }
+  } else {
+    const double id = (inc - RAD_45) / RAD_90;
+    if (inc < RAD_45) w += 1 + id;
+    else { w += 1 - id; shot[(desc_index - 1) * (NR_BINS + 1) + step_index] += (float)id; }
+  }
+
+  if (yf != 0.0 || xf != 0.0) {
+    const double az = atan2(yf, xf);
+    const int sel = desc_index >> 2;
+    double ad = (az - (-RAD_PI_7_8 + RAD_45 * sel)) / RAD_45;
+    ad = fmax(-0.5, fmin(ad, 0.5));
+    if (ad > 0) {
+      w += 1 - ad;
+      shot[((desc_index + 4) % MAX_SECTORS) * (NR_BINS + 1) + step_index] += (float)ad;
+    } else {
+      w += 1 + ad;
+      shot[((desc_index - 4 + MAX_SECTORS) % MAX_SECTORS) * (NR_BINS + 1) + step_index] -= (float)ad;
+    }
+  }
+  shot[volume_index + step_index] += (float)w;
+}
+
+/* shot.compute(pc, normal_r, shot_r): out_shot [n,352], out_normal [n,3]; optional out_rf [n,9]. */
+void shot_oracle_compute(const float* pts, int n, float normal_r, float shot_r, float* out_shot, float* out_normal,
+                         float* out_rf) {
+  shot_oracle_normals(pts, n, normal_r, out_normal);
+  const float r2 = shot_r * shot_r;
+  for (int i = 0; i < n; ++i) {
+    const float* p = pts + 3 * i;
+    float* shot = out_shot + (size_t)SHOT_LEN * i;
+    float rf[9];
+    const int ok = shot_lrf(pts, n, i, shot_r, rf);
+    if (out_rf) memcpy(out_rf + 9 * i, rf, sizeof(rf));
+    int nn = 0;
+    for (int j = 0; j < n; ++j) nn += (sqdist(p, pts + 3 * j) < r2) ? 1 : 0;
+    if (!ok || nn < 5) { for (int c = 0; c < SHOT_LEN; ++c) shot[c] = NAN; continue; }
+    memset(shot, 0, sizeof(float) * SHOT_LEN);
+    for (int j = 0; j < n; ++j) {
+      const float* q = pts + 3 * j;
+      const float d2 = sqdist(p, q);
+      if (!(d2 < r2)) continue;
+      shot_accumulate(p, q, d2, out_normal + 3 * j, rf, (double)shot_r, shot);
+    }
+    double acc = 0.0;
+    for (int c = 0; c < SHOT_LEN; ++c) acc += (double)shot[c] * (double)shot[c];
+    acc = sqrt(acc);
+    for (int c = 0; c < SHOT_LEN; ++c) shot[c] /= (float)acc;
+  }
+}

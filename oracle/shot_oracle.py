@@ -1,0 +1,51 @@
+"""ctypes loader of oracle/libshot_oracle.so (C restatement of PCL 1.9.1 normals + SHOT352).
+TEST INFRASTRUCTURE, NOT PRODUCT.  PARITY UNPINNED (see shot_oracle.c header)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libshot_oracle.so")
+
+
+def build():
+    src = os.path.join(_HERE, "shot_oracle.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libshot_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.shot_oracle_compute.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.shot_oracle_compute.restype = None
+        _lib.shot_oracle_normals.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        _lib.shot_oracle_normals.restype = None
+    return _lib
+
+
+def compute(pc, normal_r, shot_r):
+    """Returns (shot f32[N,352], normal f32[N,3], rf f32[N,9])."""
+    pc = np.ascontiguousarray(pc, dtype=np.float32).reshape(-1, 3)
+    n = pc.shape[0]
+    shot = np.empty((n, 352), np.float32)
+    normal = np.empty((n, 3), np.float32)
+    rf = np.empty((n, 9), np.float32)
+    _load().shot_oracle_compute(pc.ctypes.data, n, C.c_float(normal_r), C.c_float(shot_r), shot.ctypes.data,
+                                normal.ctypes.data, rf.ctypes.data)
+    return shot, normal, rf
+
+
+def normals(pc, normal_r):
+    pc = np.ascontiguousarray(pc, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((pc.shape[0], 3), np.float32)
+    _load().shot_oracle_normals(pc.ctypes.data, pc.shape[0], C.c_float(normal_r), out.ctypes.data)
+    return out

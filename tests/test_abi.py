@@ -1,0 +1,84 @@
+"""CPU checks of the boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/cppf_hip.h declares; struct layouts match; argument validation fails loudly (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "cppf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cppf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cppf2_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "missing export " + s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signatures out of sync with the header"
+    assert lib.cppf_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts():
+    from cppf2_amd import _lib
+    from cppf2_amd.pipeline import RESULT_DTYPE
+    assert C.sizeof(_lib.SceneGrid) == 32 and C.sizeof(_lib.SceneResult) == 160
+    for name in RESULT_DTYPE.names:
+        if name == "R":
+            assert RESULT_DTYPE.fields[name][1] == _lib.SceneResult.R.offset
+        else:
+            assert RESULT_DTYPE.fields[name][1] == getattr(_lib.SceneResult, name).offset, name
+
+
+def test_argument_validation_is_loud():
+    from cppf2_amd import _lib
+    lib = _lib.load()
+    # null pointers / bad sizes are rejected before anything touches a device
+    st = lib.cppf_sample_tuples(0, None, None, 10, 5, 1, 0, 1, None, None)
+    assert st == -1
+    assert b"invalid argument" in lib.cppf_last_error_string()
+    with pytest.raises(_lib.CppfError):
+        _lib.check(st, "cppf_sample_tuples")
+    assert lib.cppf_vote_center_workspace_bytes(4, 1 << 20) > 4 * (1 << 20) * 4
+    assert lib.cppf_rot_bins_workspace_bytes(2, 720, 2000, 180, 100000) >= 2 * 5 * 720 * 8
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cppf2_amd import ops
+    with pytest.raises(ops.CppfError):
+        ops.sample_tuples(100, 10, 5, 0)
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from cppf2_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CppfError):
+        _lib.load()
+
+
+def test_percentile_params_match_numpy():
+    import numpy as np
+    from cppf2_amd.ops import percentile_params
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 7, 512, 1111, 20000, 65536):
+        for ratio in (0.1, 0.25, 0.5, 0.05):
+            x = np.sort(rng.rand(n).astype(np.float32))
+            k, g = percentile_params(n, ratio)
+            g = np.float32(g)
+            lo = x[k]
+            hi = x[min(k + 1, n - 1)]
+            d = hi - lo
+            want = np.percentile(x, ratio * 100)
+            got = lo + d * g if g < 0.5 else hi - d * (np.float32(1) - g)
+            assert np.float32(got) == np.float32(want), (n, ratio)

@@ -1,0 +1,112 @@
+"""SHOT352 / normals.  PARITY UNPINNED against PCL (absent from the image, no reference fixtures): the C
+oracle (oracle/shot_oracle.c) restates PCL 1.9.1's algorithm and is validated here by invariants and
+known-answer clouds on CPU; the HIP kernel is compared with the oracle on the GPU."""
+import numpy as np
+import pytest
+
+from oracle import shot_oracle as S
+from cppf2_amd import synth
+
+
+def _rot(seed):
+    rng = np.random.RandomState(seed)
+    q, _ = np.linalg.qr(rng.randn(3, 3))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def test_oracle_unit_norm_and_frames():
+    sc = synth.make_scene(0, 1, 1500)
+    shot, nrm, rf = S.compute(sc["pc"], 0.02, 0.02)
+    ok = ~np.isnan(shot).any(1)
+    assert ok.mean() > 0.99
+    assert np.allclose(np.linalg.norm(shot[ok], axis=1), 1.0, atol=1e-5)
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+    x, y, z = rf[ok, 0:3], rf[ok, 3:6], rf[ok, 6:9]
+    assert np.abs((x * z).sum(1)).max() < 1e-5 and np.abs((x * y).sum(1)).max() < 1e-5
+    assert np.allclose(np.cross(z, x), y, atol=1e-6)           # y = z x x, right-handed
+    # normals face the camera at the origin
+    assert np.all((nrm * (-sc["pc"])).sum(1) >= 0)
+
+
+def test_oracle_plane_known_answer():
+    # interior point of a flat patch: every neighbour normal is +-z of the LRF -> only cosine slots 0 / 10
+    g = np.arange(-15, 16) * 0.002
+    xx, yy = np.meshgrid(g, g)
+    pc = np.stack([xx.ravel(), yy.ravel(), np.full(xx.size, 0.8)], -1).astype(np.float32)
+    pc += (np.random.RandomState(0).rand(*pc.shape).astype(np.float32) - 0.5) * np.float32([2e-4, 2e-4, 0])
+    shot, nrm, rf = S.compute(pc, 0.01, 0.01)
+    centre = np.argmin(np.abs(pc[:, :2]).sum(1))
+    assert abs(abs(nrm[centre, 2]) - 1) < 1e-5 and nrm[centre, 2] < 0     # faces the origin
+    d = shot[centre].reshape(32, 11)
+    assert np.all(d[:, 1:10] == 0) and d.sum() > 0
+    assert abs(abs(rf[centre, 8]) - 1) < 1e-5
+
+
+def test_oracle_nan_policy():
+    pc = np.array([[0, 0, 1], [0.001, 0, 1], [0, 0.001, 1], [0.5, 0.5, 1.5]], np.float32)
+    shot, nrm, rf = S.compute(pc, 0.01, 0.01)
+    assert np.isnan(shot).all()                         # < 5 neighbours everywhere
+    assert np.isnan(nrm[3]).all() and not np.isnan(nrm[0]).any()   # isolated point: < 3 neighbours
+
+
+def test_oracle_rigid_motion_invariance():
+    # the descriptor depends on geometry relative to the viewpoint only through normal orientation:
+    # rotate the cloud about the camera (origin) -> same descriptors
+    sc = synth.make_scene(2, 0, 800)
+    R = _rot(4)
+    s1, n1, _ = S.compute(sc["pc"], 0.02, 0.02)
+    s2, n2, _ = S.compute((sc["pc"].astype(np.float64) @ R.T).astype(np.float32), 0.02, 0.02)
+    ok = ~(np.isnan(s1).any(1) | np.isnan(s2).any(1))
+    # float32 coordinates change under rotation: neighbour sets at the radius edge may differ, and where the
+    # two large LRF eigenvalues are (nearly) equal -- interior of the flat caps -- the x axis is ill-conditioned
+    # by construction of SHOT, so a minority of descriptors legitimately change
+    close = np.abs(s1[ok] - s2[ok]).max(1) < 5e-3
+    assert close.mean() > 0.9 and np.median(np.abs(s1[ok] - s2[ok]).max(1)) < 1e-4
+    assert np.abs(n1 @ R.T - n2).max(1).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_shot_vs_oracle():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from cppf2_amd import ops, shot
+    scs = [synth.make_scene(5, s, n) for s, n in enumerate((1200, 777))]
+    pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
+    pt_off = ops._offsets([1200, 777], pts.device)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True)
+    hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
+    o = 0
+    for sc in scs:
+        n = sc["pc"].shape[0]
+        os_, on, orf = S.compute(sc["pc"], 0.02, 0.02)
+        assert np.array_equal(np.isnan(os_), np.isnan(hs[o:o + n]))
+        # normals / frames: float64 Jacobi with +,-,*,/,sqrt only; partial sums are combined in a different
+        # order across lanes (1e-16 relative) -> equal to float32 rounding
+        assert np.allclose(hn[o:o + n], on, atol=2e-6, equal_nan=True)
+        assert np.allclose(hrf[o:o + n], orf, atol=2e-5, equal_nan=True)
+        # histogram: float32 accumulation in a different order + device acos/atan2 ulps
+        ok = ~np.isnan(os_).any(1)
+        assert np.abs(hs[o:o + n][ok] - os_[ok]).max() < 2e-5
+        o += n
+    # drop-in module call convention (src_shot/shot.cpp:45): list of two flat float32 arrays
+    r = shot.compute(scs[1]["pc"].astype(np.float64), 0.02, 0.02)
+    assert isinstance(r, list) and r[0].shape == (777 * 352,) and r[1].shape == (777 * 3,) and r[0].dtype == np.float32
+    assert np.allclose(r[0].reshape(-1, 352), hs[1200:], atol=1e-6, equal_nan=True)
+    nn = shot.estimate_normal(scs[1]["pc"], 0.02)
+    assert np.allclose(nn.reshape(-1, 3), hn[1200:], atol=1e-7, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_hip_shot_nan_policy_and_plane():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from cppf2_amd import shot
+    pc = np.array([[0, 0, 1], [0.001, 0, 1], [0, 0.001, 1], [0.5, 0.5, 1.5]], np.float32)
+    s, n = shot.compute(pc, 0.01, 0.01)
+    assert np.isnan(s).all()
+    n = n.reshape(-1, 3)
+    assert np.isnan(n[3]).all() and not np.isnan(n[0]).any()
