@@ -79,6 +79,9 @@ def load():
         raise CppfError(
             "libcppf_hip.so not found at %s -- build it with `python -m cppf2_amd.build` "
             "(hipcc --offload-arch=gfx950).  cppf2_amd has no CPU fallback." % LIB_PATH)
+    # torch ships its own libamdhip64.so.7; it must be the HIP runtime of the process (it owns the device
+    # context of every tensor we are handed), so make sure it is loaded before our NEEDED entry is resolved.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud by design

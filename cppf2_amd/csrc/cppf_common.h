@@ -77,7 +77,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 //   mm with K=3 -> fma(a2,b2, fma(a1,b1, a0*b0)).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float norm3_fused(float x, float y, float z) {
-  return __fsqrt_rn(fmaf(z, z, fmaf(y, y, x * x)));
+  return __builtin_sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
 }
 
 __device__ __forceinline__ float cross_term(float a, float b, float c, float d) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void target_pair(float ax, float ay, float az, float 
                                             double cx, double cy, double cz, const double* __restrict__ axes,
                                             float* tr2, float* rot3) {
   const float dx = ax - bx, dy = ay - by, dz = az - bz;
-  const float n = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);      // np.linalg.norm: un-fused
+  const float n = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);      // np.linalg.norm: un-fused
   const float den = n + 1e-7f;
   const double ux = (double)(dx / den), uy = (double)(dy / den), uz = (double)(dz / den);
   const double acx = (double)ax - cx, acy = (double)ay - cy, acz = (double)az - cz;

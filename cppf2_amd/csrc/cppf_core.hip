@@ -343,7 +343,7 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
     const float* pa = pts + 3 * (int64_t)(p0 + i0);
     const float* pb = pts + 3 * (int64_t)(p0 + i1);
     const float rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
-    const float real_len = __fsqrt_rn((rx * rx + ry * ry) + rz * rz);
+    const float real_len = __builtin_sqrtf((rx * rx + ry * ry) + rz * rz);
     // predicted pair length: torch.norm (fused), clamp_min 1e-7, eval.py:234
     const float pred_len = norm3_fused(pr[3] - pr[0], pr[4] - pr[1], pr[5] - pr[2]);
     const float sc = real_len / fmaxf(pred_len, 1e-7f);

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void shot_kernel(int B, const float* __restrict
       if (pos < SH_LCAP) s_list[pos] = j;
       if (!(qx == px && qy == py && qz == pz)) {
         const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-        const double w = (double)radius - (double)__fsqrt_rn(d2);
+        const double w = (double)radius - (double)__builtin_sqrtf(d2);
         cov[0] += w * (x * x); cov[1] += w * (x * y); cov[2] += w * (x * z);
         cov[3] += w * (y * y); cov[4] += w * (y * z); cov[5] += w * (z * z);
         sum += w;

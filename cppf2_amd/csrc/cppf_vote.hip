@@ -422,7 +422,7 @@ __global__ __launch_bounds__(BV_THREADS) void backvote_kernel(
     float tb[2];
     target_pair(a[0], a[1], a[2], bb[0], bb[1], bb[2], cx, cy, cz, axes.a, tb, nullptr);
     const float d0 = tr[row * 2] - tb[0], d1 = tr[row * 2 + 1] - tb[1];
-    e[t] = __fsqrt_rn(d0 * d0 + d1 * d1);
+    e[t] = __builtin_sqrtf(d0 * d0 + d1 * d1);
   }
   __syncthreads();
   // 2. np.percentile(back_errs, ratio*100), method 'linear' (eval.py:258): order statistics kq and kq+1
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void assemble_pose_kernel(
   float rx = sphere[3 * r.right_idx], ry = sphere[3 * r.right_idx + 1], rz = sphere[3 * r.right_idx + 2];
   const float d = (ux * rx + uy * ry) + uz * rz;
   rx = rx - d * ux; ry = ry - d * uy; rz = rz - d * uz;
-  const float n = __fsqrt_rn((rx * rx + ry * ry) + rz * rz) + 1e-9f;
+  const float n = __builtin_sqrtf((rx * rx + ry * ry) + rz * rz) + 1e-9f;
   rx = rx / n; ry = ry / n; rz = rz / n;
   double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   R[0][up_axis] = ux; R[1][up_axis] = uy; R[2][up_axis] = uz;
