@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the CPPF++ voting hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the whole path over a batch of synthetic scenes resident in HBM:
+  sampler (HIP) -> normals + SHOT352 (HIP) -> shot_encoder (torch fp32) -> tuple encode (HIP) -> tuple MLP
+  (torch fp32) -> bin decode + vote parameters (HIP) -> centre vote + argmax (HIP) -> back-vote filter (HIP)
+  -> rotation votes x2 (HIP) -> pose assembly (HIP) -> one RCCL all_gather of the 160-byte scene records (N > 1).
+Workload = BASELINE.json configs[1]: SHOT model, 4096 points x 20 000 tuples per scene, 180 rotations, 720 sphere
+bins, res 2 mm ('bottle' axes), scenes = seeded synthetic bottle-like clouds (cppf2_amd.synth); weights are
+random-init (no checkpoints ship with the reference) plus a fixed teacher logit prior so that votes cluster the
+way trained weights make them.  Scenes are sharded over ranks (weak scaling: --scenes-per-gpu each).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant HIP kernel, HIP-event
+timed inside the timed region) + `cpu_baseline` (the oracle timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class Cfg:
+    num_more = 3
+    res = 2e-3
+    up, right, front = [0, 1, 0], [1, 0, 0], [0, 0, 1]     # config/config.yaml:12-14
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scenes-per-gpu", type=int, default=64)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--tuples", type=int, default=20000)
+    ap.add_argument("--rots", type=int, default=180)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--vote-mode", type=int, default=0)
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
+    return ap.parse_args()
+
+
+class Step:
+    """Holds the resident inputs and runs one pass of the path."""
+
+    STAGES = ["sample_tuples", "normals", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
+              "decode_bins", "vote_center", "backvote_filter", "rot_bins", "assemble_pose", "gather"]
+
+    def __init__(self, args, rank, world, dev):
+        from cppf2_amd import ops, synth
+        from cppf2_amd.models import BeyondCPPFShot
+        from cppf2_amd.pipeline import VotingPipeline
+        self.ops, self.args, self.rank, self.world, self.dev = ops, args, rank, world, dev
+        B, N, T = args.scenes_per_gpu, args.points, args.tuples
+        self.B, self.N, self.T = B, N, T
+        self.scene0 = rank * B
+        scenes = [synth.make_scene(args.seed, self.scene0 + b, N) for b in range(B)]
+        self.scenes = scenes
+        self.pts = torch.from_numpy(np.concatenate([s["pc"] for s in scenes])).to(dev)
+        self.pipe = VotingPipeline([N] * B, [T] * B, k=5, res=Cfg.res, num_rots=args.rots, cfg_up=Cfg.up,
+                                   cfg_right=Cfg.right, cfg_front=Cfg.front, cells_cap=1 << 21,
+                                   vote_mode=args.vote_mode, device=dev)
+        torch.manual_seed(args.seed)
+        self.model = BeyondCPPFShot(Cfg()).to(dev).eval()
+        # teacher prior (untimed setup): peaked at the true canonical coordinates of each tuple's pair
+        idx = ops.sample_tuples(N, T, 5, args.seed, tuple(range(self.scene0, self.scene0 + B)), dev)
+        canon = torch.from_numpy(np.concatenate([s["pc_canon"] for s in scenes])).to(dev)
+        base = (torch.arange(B, device=dev, dtype=torch.int64) * N).repeat_interleave(T)
+        coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(B * T, 6)
+        pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
+        kbin = torch.arange(32, device=dev, dtype=torch.float32)
+        self.prior = (-0.5 * ((kbin[None, None, :] - pos[..., None]) / 0.6) ** 2).contiguous()
+        self.shot = torch.empty((B * N, 352), dtype=torch.float32, device=dev)
+        self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
+        self.gathered = [torch.empty((B, 160), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self.ev = None
+
+    def _mark(self, name):
+        if self.ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.ev.append((name, e))
+
+    @torch.no_grad()
+    def run(self, timed=False):
+        from cppf2_amd import shot as shotmod
+        ops, pipe, a = self.ops, self.pipe, self.args
+        B, N, T = self.B, self.N, self.T
+        self.ev = [] if timed else None
+        self._mark("start")
+        idx = ops.sample_tuples(N, T, 5, a.seed, tuple(range(self.scene0, self.scene0 + B)), self.dev)
+        self._mark("sample_tuples")
+        shotmod.normals_device(self.pts, pipe.pt_off, Cfg.res * 10, out=self.normal)       # eval.py:210
+        self._mark("normals")
+        shotmod.descriptors_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot)
+        self._mark("shot352")
+        shot = torch.nan_to_num_(self.shot, nan=0.0)                                       # eval.py:215-216
+        normal = torch.nan_to_num_(self.normal, nan=0.0)
+        feat = self.model.shot_encoder(shot)
+        self._mark("shot_encoder_torch")
+        x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
+        self._mark("encode_tuples")
+        logits, scales = self.model.heads(x)
+        logits = logits.add_(self.prior)
+        self._mark("tuple_mlp_torch")
+        u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
+        pipe.decode(self.pts, idx, logits, u)
+        self._mark("decode_bins")
+        pipe.vote_center(self.pts, idx)
+        self._mark("vote_center")
+        pipe.backvote(self.pts, idx)
+        self._mark("backvote_filter")
+        pipe.rot_bins(self.pts, idx)
+        self._mark("rot_bins")
+        pipe.assemble(scales)
+        self._mark("assemble_pose")
+        if self.world > 1:
+            torch.distributed.all_gather(self.gathered, pipe.results)
+        else:
+            self.gathered[0] = pipe.results
+        self._mark("gather")
+        return self.ev
+
+
+def algorithmic_bytes(stage, B, N, T, R, S, G):
+    """Compulsory bytes one launch of the stage's kernel moves for B scenes (SURVEY.md 8d per-scene figures)."""
+    per_scene = {
+        "sample_tuples": T * 5 * 4,
+        "normals": N * 12 + N * 12,
+        "shot352": N * 12 + N * 12 + N * 352 * 4,
+        "encode_tuples": T * 5 * 4 + N * 12 + N * 12 + N * 64 * 4 + T * 360 * 4,
+        "decode_bins": T * 6 * 32 * 4 + T * 6 * 4 + T * 8 + T * (8 + 12 + 24 + 4 + 24),
+        "vote_center": T * 8 + T * 8 + N * 12 + 0 * G,       # grid stays on-chip (LDS slabs); only the peak leaves
+        "backvote_filter": T * 8 + T * 8 + N * 12 + T * (1 + 4 + 4 + 8 + 4),
+        "rot_bins": 2 * (T // 10) * (4 + 8 + 4 + 8 + 12) + 2 * S * 4,
+        "assemble_pose": 160,
+    }
+    return per_scene.get(stage, 0) * B
+
+
+def cpu_baseline(args, step):
+    """Times the oracle (NumPy + C SHOT) on the host for a bounded sample of the same workload."""
+    from oracle import pipeline_oracle as PO
+    from cppf2_amd import synth
+    if args.cpu_scenes <= 0:
+        return None
+    weights = {k: v.detach().cpu().numpy() for k, v in step.model.state_dict().items()}
+    trig = (step.pipe.cs.cpu().numpy(), step.pipe.sn.cpu().numpy())
+    t0 = time.perf_counter()
+    agree = []
+    for b in range(args.cpu_scenes):
+        sc = step.scenes[b]
+        out = PO.run_scene_full(weights, sc["pc"], args.seed, step.scene0 + b, args.tuples, res=Cfg.res,
+                                num_rots=args.rots, trig=trig,
+                                prior_fn=lambda idx, sc=sc: synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6))
+        agree.append(out)
+    dt = time.perf_counter() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return dict(value=args.cpu_scenes / dt, unit="scenes/s", cores=cores, kind="port",
+                sample="%d scene(s) of the same workload (first scenes of rank 0's batch), NumPy oracle + C SHOT "
+                       "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt)), agree
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    step = Step(args, rank, world, dev)
+    for _ in range(args.warmup):
+        step.run()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(args.steps):
+        evs.append(step.run(timed=True))
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # per-stage HIP-event times (ms per launch, averaged over the timed steps) on the stream the kernels ran on
+    stage_ms = {}
+    for ev in evs:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
+
+    if rank == 0:
+        B, N, T, R, S = step.B, step.N, step.T, args.rots, step.pipe.S
+        res = step.pipe.results_to_numpy()
+        G = int(np.mean(res["ncell"]))
+        hip_stages = [s for s in Step.STAGES if "torch" not in s and s != "gather"]
+        dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0))
+        rows = []
+        for s in Step.STAGES:
+            ms = stage_ms.get(s, 0.0)
+            ab = algorithmic_bytes(s, B, N, T, R, S, G)
+            rows.append((s, ms, ab / 1e6, (ab / 1e9) / (ms / 1e3) if ms > 0 and ab else 0.0))
+        dom_ms = stage_ms[dominant]
+        dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G)
+        achieved = (dom_bytes / 1e9) / (dom_ms / 1e3)
+        roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=dom_ms,
+                        algorithmic_bytes_per_launch=dom_bytes,
+                        per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
+        # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
+        ok = 0
+        for b in range(B):
+            sc = step.scenes[b]
+            terr = np.linalg.norm(res["t"][b] - sc["t"])
+            cosang = abs(float(res["R"][b][:, 1] @ sc["R"][:, 1]))
+            if terr < 0.05 and np.degrees(np.arccos(min(cosang, 1.0))) < 5.0:
+                ok += 1
+        cpu = None
+        agree = None
+        if args.cpu_scenes > 0:
+            cpu, outs = cpu_baseline(args, step)
+            agree = dict(scenes=len(outs),
+                         centre_argmax_equal=int(sum(int(res["argmax"][b]) == o["argmax"] for b, o in enumerate(outs))),
+                         up_bin_equal=int(sum(int(res["up_idx"][b]) == o["up_idx"] for b, o in enumerate(outs))),
+                         right_bin_equal=int(sum(int(res["right_idx"][b]) == o["right_idx"] for b, o in enumerate(outs))))
+        total_scenes = B * world * args.steps
+        line = {
+            "metric": "scenes/sec (1/2/4/8 GPU) at 4096 pts x 20k tuples; 5deg5cm match vs ref",
+            "value": total_scenes / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SHOT model, %d scenes/GPU x %d pts x %d tuples x %d rots, "
+                                   "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior"
+                                   % (B, N, T, R),
+                       "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,
+        }
+        if args.breakdown:
+            print("%-22s %10s %12s %10s" % ("stage", "ms/launch", "alg MB", "GB/s"), file=sys.stderr)
+            for r in rows:
+                print("%-22s %10.3f %12.1f %10.1f" % r, file=sys.stderr)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

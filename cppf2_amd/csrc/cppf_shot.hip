@@ -415,3 +415,15 @@ extern "C" int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int6
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
+
+extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
+                                         const float* normals, float shot_r, float* out_shot, float* out_rf,
+                                         void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && normals && out_shot && shot_r > 0.0f);
+  CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
+  if (total_points <= 0) return CPPF_OK;
+  hipLaunchKernelGGL(shot_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
+                     normals, shot_r, out_shot, out_rf);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

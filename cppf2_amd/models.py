@@ -1,0 +1,138 @@
+"""The tuple MLPs of CPPF++ as plain torch modules (left to PyTorch-ROCm by design), with the
+tuple encode (prepare_tuple_inputs) routed through the HIP kernels.
+
+State-dict key layout is the reference's (train_shot.py:19-73, train_dino.py:21-89:
+`shot_encoder.N.fc1.weight`, `tuple_encoder.N.fc0.bias`, `logit_encoder...`, `scale_encoder...`,
+`desc_transform.*`, `desc_pair_transform.*`), so a Lightning checkpoint's `state_dict` loads with
+load_reference_checkpoint().
+"""
+from __future__ import annotations
+
+from itertools import combinations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class ResLayer(nn.Module):
+    """Residual 2-layer block, no norm, no dropout (train_shot.py:19-45 with bn=False, dropout=False)."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.fc1 = nn.Linear(dim_in, dim_out)
+        self.fc2 = nn.Linear(dim_out, dim_out)
+        self.fc0 = nn.Linear(dim_in, dim_out) if dim_in != dim_out else None
+
+    def forward(self, x):
+        skip = x if self.fc0 is None else self.fc0(x)
+        return self.fc2(F.relu(self.fc1(x))) + skip
+
+
+def _stack(dims):
+    return nn.Sequential(*[ResLayer(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+
+class _EncodeShot(torch.autograd.Function):
+    """HIP tuple encode with a backward for the per-point feature table (the only differentiable input:
+    points and normals are data).  d feat[n] = sum over (tuple, slot) with idx == n of d out[:, slot block]."""
+
+    @staticmethod
+    def forward(ctx, points, idx, feat, normal):
+        out = ops.encode_tuples_shot(points, idx, feat.detach(), normal)
+        ctx.save_for_backward(idx)
+        ctx.feat_shape = feat.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        n, f = ctx.feat_shape
+        k = idx.shape[1]
+        head = k * (k - 1) // 2 * 4
+        gf = torch.zeros((n, f), dtype=g.dtype, device=g.device)
+        for s in range(k):
+            gf.index_add_(0, idx[:, s].long(), g[:, head + s * f: head + (s + 1) * f])
+        return None, None, gf, None
+
+
+class BeyondCPPFShot(nn.Module):
+    """train_shot.py:48-122.  forward(points, point_idxs_all, shot_feat, normal) -> (preds_cls [T,6,32], preds_scale [T,3])."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        k = cfg.num_more + 2
+        self.shot_encoder = _stack([352] + [128] * 5 + [64])
+        input_dim = len(list(combinations(range(k), 2))) * 4 + k * 64
+        self.tuple_encoder = _stack([input_dim] + [128] * 5 + [256])
+        self.logit_encoder = _stack([256, 256, 256, 64 * 3])
+        self.scale_encoder = _stack([256, 128, 64, 3])
+
+    def prepare_tuple_inputs(self, points, point_idxs_all, shot_feat, normal):
+        idx = point_idxs_all.to(torch.int32)
+        if shot_feat.requires_grad:
+            return _EncodeShot.apply(points, idx, shot_feat, normal)
+        return ops.encode_tuples_shot(points, idx, shot_feat, normal)
+
+    def heads(self, inputs):
+        feat = self.tuple_encoder(inputs)
+        preds_scale = self.scale_encoder(feat)
+        preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
+        return preds_cls, preds_scale
+
+    def forward(self, points, point_idxs_all, shot_feat, normal):
+        inputs = self.prepare_tuple_inputs(points, point_idxs_all, self.shot_encoder(shot_feat), normal)
+        return self.heads(inputs)
+
+
+class BeyondCPPFDino(nn.Module):
+    """train_dino.py:58-133.  forward(points, point_descs, point_idxs_all).
+    desc_transform is applied per point BEFORE the gather: same Linear on the same rows,
+    1/5 of the FLOPs at T >> N and no [T,5,1024] temporary."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        k = cfg.num_more + 2
+        d = 256
+        self.ncoord = len(list(combinations(range(k), 2))) * 3
+        self.tuple_encoder = _stack([self.ncoord + d] + [128] * 5 + [256])
+        self.logit_encoder = _stack([256, 256, 256, 64 * 3])
+        self.scale_encoder = _stack([256, 128, 64, 3])
+        self.desc_transform = nn.Linear(1024, d)
+        self.desc_pair_transform = nn.Linear(d * k, d)
+
+    def prepare_tuple_inputs(self, points, point_descs, point_idxs_all):
+        idx = point_idxs_all.to(torch.int32)
+        T, k = idx.shape
+        per_point = self.desc_transform(point_descs)                                   # [N,256]
+        gathered = per_point[idx.long().reshape(-1)].reshape(T, k * per_point.shape[1])  # cat_i desc_transform(desc[idx_i])
+        desc_part = self.desc_pair_transform(gathered)
+        if torch.is_grad_enabled() and desc_part.requires_grad:
+            coord = ops.encode_tuples_coord(points, idx)
+            return torch.cat([coord, desc_part], -1)
+        out = torch.empty((T, self.ncoord + desc_part.shape[1]), dtype=torch.float32, device=desc_part.device)
+        ops.encode_tuples_coord(points, idx, out=out)
+        out[:, self.ncoord:] = desc_part
+        return out
+
+    def forward(self, points, point_descs, point_idxs_all):
+        inputs = self.prepare_tuple_inputs(points, point_descs, point_idxs_all)
+        feat = self.tuple_encoder(inputs)
+        preds_scale = self.scale_encoder(feat)
+        preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
+        return preds_cls, preds_scale
+
+
+def load_reference_checkpoint(model, path):
+    """Loads a Lightning checkpoint written by the reference's trainer (train_shot.py:139): weights live under
+    ckpt['state_dict'] with the same key names as this module."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt.get("state_dict", ckpt)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError("checkpoint key mismatch: missing=%s unexpected=%s" % (missing, unexpected))
+    return model

@@ -134,6 +134,16 @@ def _offsets(counts, device):
 # ----------------------------------------------------------------------------------------------
 # a1. sampler
 # ----------------------------------------------------------------------------------------------
+_OFF_CACHE = {}
+
+
+def _uniform_offsets(count, B, device):
+    key = (int(count), int(B), str(device))
+    if key not in _OFF_CACHE:
+        _OFF_CACHE[key] = _offsets([count] * B, device)
+    return _OFF_CACHE[key]
+
+
 def sample_tuples(num_points, num_tuples, k, seed, scene_ids=(0,), device=None):
     """Replaces np.random.randint(0, N, (T, k)) (eval.py:207).  Returns int32 [B*T, k] for the scenes in
     scene_ids (an arithmetic progression: base + b*stride)."""
@@ -141,8 +151,8 @@ def sample_tuples(num_points, num_tuples, k, seed, scene_ids=(0,), device=None):
     B = len(scene_ids)
     stride = (scene_ids[1] - scene_ids[0]) if B > 1 else 1
     assert all(scene_ids[b] == scene_ids[0] + b * stride for b in range(B)), "scene_ids must be arithmetic"
-    pt_off = _offsets([num_points] * B, device)
-    tup_off = _offsets([num_tuples] * B, device)
+    pt_off = _uniform_offsets(num_points, B, device)
+    tup_off = _uniform_offsets(num_tuples, B, device)
     out = torch.empty((B * num_tuples, k), dtype=torch.int32, device=device)
     _lib.check(_L.cppf_sample_tuples(B, _p(pt_off), _p(tup_off), num_tuples, k, C.c_uint64(seed),
                                      int(scene_ids[0]), int(stride), _p(out), _stream()), "cppf_sample_tuples")
@@ -153,7 +163,7 @@ def philox_uniform(num_rows, m, seed, stream_id, scene_ids=(0,), device=None):
     device = device or _dev()
     B = len(scene_ids)
     stride = (scene_ids[1] - scene_ids[0]) if B > 1 else 1
-    tup_off = _offsets([num_rows] * B, device)
+    tup_off = _uniform_offsets(num_rows, B, device)
     out = torch.empty((B * num_rows, m), dtype=torch.float32, device=device)
     _lib.check(_L.cppf_philox_uniform(B, _p(tup_off), num_rows, m, C.c_uint64(seed), int(scene_ids[0]), int(stride),
                                       int(stream_id), _p(out), _stream()), "cppf_philox_uniform")

@@ -37,6 +37,23 @@ def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
     return out_shot, out_normal
 
 
+def normals_device(pts, pt_off, normal_r, out=None):
+    n = pts.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out is None else out
+    _lib.check(_L.cppf_estimate_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r),
+                                        ops._p(out), ops._stream()), "cppf_estimate_normals")
+    return out
+
+
+def descriptors_device(pts, pt_off, normals, shot_r, out=None):
+    n = pts.shape[0]
+    out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
+    _lib.check(_L.cppf_shot352_from_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, ops._p(normals),
+                                            C.c_float(shot_r), ops._p(out), None, ops._stream()),
+               "cppf_shot352_from_normals")
+    return out
+
+
 def compute(pc, normal_r=0.1, shot_r=0.17):
     """shot.compute (src_shot/shot.cpp:45-100): returns [float32[N*352], float32[N*3]]."""
     dev = ops._dev()

@@ -88,6 +88,9 @@ int64_t cppf_shot352_workspace_bytes(int64_t total_points);
 int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r, float shot_r,
                  float* out_shot, float* out_normal, float* out_rf /* optional float32[n,9] local frames */,
                  void* workspace, int64_t workspace_bytes, void* stream);
+/* The descriptor half alone, on normals the caller already has (e.g. from cppf_estimate_normals). */
+int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
+                              const float* normals, float shot_r, float* out_shot, float* out_rf, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42). */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                           float* out_normal, void* stream);
