@@ -151,68 +151,78 @@ extern "C" int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off,
 // row_len % 4 == 0 (360 for the SHOT model), so every store is a coalesced dwordx4; the feature
 // table [n, feat_dim] is small (1 MB/scene) and served by L2.
 // ---------------------------------------------------------------------------------------------
-template <int K>
-struct Combos {
-  static constexpr int NP = K * (K - 1) / 2;
+// q-th pair of itertools.combinations(range(k), 2), tabulated on the host (k <= 8 -> at most 28 pairs)
+struct ComboTable {
+  int8_t i[28];
+  int8_t j[28];
 };
 
-__device__ __forceinline__ void combo_of(int q, int k, int& i, int& j) {
-  // q-th pair of itertools.combinations(range(k), 2)
-  i = 0;
-  int rem = q;
-  while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
-  j = i + 1 + rem;
+static inline ComboTable make_combos(int k) {
+  ComboTable c;
+  int q = 0;
+  for (int i = 0; i < k; ++i)
+    for (int j = i + 1; j < k; ++j) { c.i[q] = (int8_t)i; c.j[q] = (int8_t)j; ++q; }
+  for (; q < 28; ++q) { c.i[q] = 0; c.j[q] = 0; }
+  return c;
 }
 
 __device__ __forceinline__ float encode_scalar(const float* __restrict__ pts, const float* __restrict__ nrm,
-                                               const int32_t* __restrict__ row_idx, int p0, int k, int np, int f) {
+                                               const int32_t* __restrict__ row_idx, int p0, int np, int f,
+                                               const ComboTable& cb) {
   if (f < 3 * np) {
-    int i, j;
-    combo_of(f / 3, k, i, j);
-    const int c = f % 3;
-    return pts[3 * (int64_t)(p0 + row_idx[i]) + c] - pts[3 * (int64_t)(p0 + row_idx[j]) + c];
+    const int q = f / 3, c = f - 3 * q;
+    return pts[3 * (int64_t)(p0 + row_idx[cb.i[q]]) + c] - pts[3 * (int64_t)(p0 + row_idx[cb.j[q]]) + c];
   }
-  int i, j;
-  combo_of(f - 3 * np, k, i, j);
-  const float* ni = nrm + 3 * (int64_t)(p0 + row_idx[i]);
-  const float* nj = nrm + 3 * (int64_t)(p0 + row_idx[j]);
+  const int q = f - 3 * np;
+  const float* ni = nrm + 3 * (int64_t)(p0 + row_idx[cb.i[q]]);
+  const float* nj = nrm + 3 * (int64_t)(p0 + row_idx[cb.j[q]]);
   const float s = (ni[0] * nj[0] + ni[1] * nj[1]) + ni[2] * nj[2];
   // max(sum(n_i*n_j), sum(-n_i*n_j)): the second sum is exactly -s (negation commutes with rounding)
   return fmaxf(s, -s);
 }
 
-__global__ __launch_bounds__(256) void encode_shot_kernel(int B, const float* __restrict__ pts,
+// Work items of a scene: first nt*head_vec "head" float4s (pair differences + normal cosines, a few dependent
+// gathers each), then nt*feat_vec pure gather-copies of the feature table -- so that every wavefront (but one)
+// runs a single kind of item.  blockIdx.y = scene: no per-item scene search.
+__global__ __launch_bounds__(256) void encode_shot_kernel(const float* __restrict__ pts,
                                                           const float* __restrict__ nrm,
                                                           const float* __restrict__ feat, int feat_dim,
                                                           const int32_t* __restrict__ idx, int k,
                                                           const int32_t* __restrict__ pt_off,
-                                                          const int32_t* __restrict__ tup_off, int64_t total,
+                                                          const int32_t* __restrict__ tup_off, ComboTable cb,
                                                           float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int p0 = pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
   const int np = k * (k - 1) / 2;
   const int head = 4 * np;                       // coord (3np) + normal (np) scalars
   const int row_len = head + k * feat_dim;
-  const int vec_per_row = row_len >> 2;          // row_len % 4 == 0 checked by the host
-  const int64_t nvec = total * vec_per_row;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = v / vec_per_row;
-    const int c = (int)(v - t * vec_per_row);
-    const int b = find_scene(tup_off, B, t);
-    const int p0 = pt_off[b];
-    const int32_t* row_idx = idx + t * k;
-    float4 o;
-    const int f0 = c * 4;
-    if (f0 >= head) {
-      const int ff = f0 - head;
-      const int kk = ff / feat_dim;
-      const int col = ff - kk * feat_dim;
-      o = *reinterpret_cast<const float4*>(feat + (int64_t)(p0 + row_idx[kk]) * feat_dim + col);
+  const int head_vec = np;                       // head / 4
+  const int fvec = feat_dim >> 2;                // float4s per feature row
+  const int feat_vec = k * fvec;
+  const int64_t n_head = (int64_t)nt * head_vec;
+  const int64_t n_all = n_head + (int64_t)nt * feat_vec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_all; v += (int64_t)gridDim.x * blockDim.x) {
+    if (v >= n_head) {
+      const int64_t w = v - n_head;
+      const int t = (int)(w / feat_vec);
+      const int c = (int)(w - (int64_t)t * feat_vec);
+      const int kk = c / fvec, col = (c - kk * fvec) << 2;
+      const int64_t row = (int64_t)(t0 + t);
+      const float4 o = *reinterpret_cast<const float4*>(feat + (int64_t)(p0 + idx[row * k + kk]) * feat_dim + col);
+      *reinterpret_cast<float4*>(out + row * row_len + head + kk * feat_dim + col) = o;
     } else {
-      o.x = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 0);
-      o.y = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 1);
-      o.z = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 2);
-      o.w = encode_scalar(pts, nrm, row_idx, p0, k, np, f0 + 3);
+      const int t = (int)(v / head_vec);
+      const int c = (int)(v - (int64_t)t * head_vec);
+      const int64_t row = (int64_t)(t0 + t);
+      const int32_t* row_idx = idx + row * k;
+      float4 o;
+      o.x = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 0, cb);
+      o.y = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 1, cb);
+      o.z = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 2, cb);
+      o.w = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 3, cb);
+      *reinterpret_cast<float4*>(out + row * row_len + 4 * c) = o;
     }
-    *reinterpret_cast<float4*>(out + t * row_len + f0) = o;
   }
 }
 
@@ -222,15 +232,23 @@ extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* nor
   CPPF_CHECK_ARG(B > 0 && pts && normals && feat && idx && pt_off && tup_off && out);
   CPPF_CHECK_ARG(k >= 2 && k <= 8);
   CPPF_CHECK_ARG(feat_dim > 0 && feat_dim % 4 == 0);
-  const int np = k * (k - 1) / 2;
   if (total_tuples <= 0) return CPPF_OK;
-  const int64_t nvec = total_tuples * ((4 * np + k * feat_dim) / 4);
-  const int64_t blocks = (nvec + 255) / 256;
-  const int grid = (int)(blocks < 256 * 64 ? blocks : 256 * 64);
-  hipLaunchKernelGGL(encode_shot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, pts, normals, feat,
-                     feat_dim, idx, k, pt_off, tup_off, total_tuples, out);
+  const int np = k * (k - 1) / 2;
+  const int64_t per_scene = (total_tuples + B - 1) / B * (np + k * (feat_dim / 4));
+  int64_t bx = (per_scene + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(encode_shot_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, feat,
+                     feat_dim, idx, k, pt_off, tup_off, make_combos(k), out);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
+}
+
+__device__ __forceinline__ void combo_of(int q, int k, int& i, int& j) {
+  i = 0;
+  int rem = q;
+  while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+  j = i + 1 + rem;
 }
 
 __global__ __launch_bounds__(256) void encode_coord_kernel(int B, const float* __restrict__ pts,

@@ -5,43 +5,43 @@
 // =============================================================================================
 // a6. vote_center (train_dino.py:171-215)
 //
-// MI355X design: the vote grid of a scene (1.6e5 .. 1e6 uint32 cells) is cut into slabs of
-// VC_SLAB_CELLS consecutive flat cells that fit the 160 KiB LDS of one CU.  Workgroup (scene, slab)
-// regenerates the scene's votes in registers (lane = pair, loop over the wave-uniform rotation
-// table) and counts the ones that land in its slab with LDS atomics; the slab is then streamed out
-// with plain coalesced stores (or not at all when the caller only wants the peak) and its first
-// maximum is reduced in place.  HBM sees the tuple/vote-parameter reads and, optionally, one write of
-// the grid -- no global atomics, no memset.  Vote generation is ~80 VALU ops and is repeated once
-// per slab; that is cheaper than 3.6 M L2 atomics per scene as long as a scene has < ~30 slabs.
-// For small batches the pair list of a slab is additionally split over P workgroups that merge
-// their slabs into the (pre-zeroed) global grid with one atomic per non-zero cell.
-// Mode 2 (global atomics, one thread per pair) is kept for huge grids and as an A/B reference.
+// MI355X design.  The vote grid of a scene (1.6e5 .. 1e6 uint32 cells) is cut into slabs of VC_SLAB_CELLS
+// consecutive flat cells (whole-or-partial x-layers) that fit the 160 KiB LDS of one CU.
+//   1. vote_frames_kernel: once per pair, the circle frame (centre c, in-plane axes x, y, all the IEEE
+//      sqrt/div work of train_dino.py:176-192) goes to a structure-of-arrays workspace, together with the
+//      amplitude/phase of the circle's x-coordinate.
+//   2. vote_center_slab_kernel: workgroup (scene, slab) streams the frames (coalesced), and for every pair
+//      derives the rotation indices that can reach the slab's x-layers (two arcs of the circle, from the
+//      amplitude/phase) -- so the work per scene stays ~one pass over the votes no matter how many slabs the
+//      grid needs.  Votes are counted with LDS atomics; arcs are very uneven in length, so each lane walks at
+//      most VC_LANE_CAP rotations of its own pair and the leftovers are swept by the whole wavefront (pair
+//      broadcast with v_readlane).  The cell of a vote is found without an IEEE division on the fast path
+//      (multiply by the rounded reciprocal, exact division only when the result lands within rounding distance
+//      of a cell boundary), which keeps the grid bit-identical to the reference's float32 pipeline.
+//      The slab is streamed out with plain coalesced stores (or not at all when the caller only wants the
+//      peak) and its first maximum is reduced in place: no global atomics, no memset, no grid re-read.
+//      Workgroups are ordered centre-out over the slabs (heavy slabs first) so the tail of the launch is
+//      filled with the light ones.
+// For small batches the pair list of a slab is additionally split over P workgroups that merge their slabs
+// into the zeroed global grid with one atomic per non-zero cell.
+// Mode 2 (global atomics, one thread per pair, exhaustive sweep) is the independent A/B reference; mode 3 is
+// the slab kernel with the exhaustive rotation sweep and exact divisions.
 // =============================================================================================
 #define VC_THREADS 1024
 #define VC_SLAB_CELLS 36864            // 144 KiB of uint32 counters
 #define VC_ARG_BLOCKS 32
+#define VC_MAX_LDS_ROTS 1024
+#define VC_FRAME_FLOATS 11             // cx cy cz xx xy xz yx yy yz invA phi
+#ifndef VC_LANE_CAP
+#define VC_LANE_CAP 12
+#endif
+#define VC_ARC_MARGIN 0.25f
 
 struct SlabBest {
   int64_t idx;
   uint32_t val;
   uint32_t pad;
 };
-
-// one vote: returns flat cell index or -1 (train_dino.py:195-203)
-__device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
-                                         float yy, float yz, float cs, float sn, float c0x, float c0y, float c0z,
-                                         float res, int gx, int gy, int gz) {
-  const float ox = cs * xx + sn * yx;
-  const float oy = cs * xy + sn * yy;
-  const float oz = cs * xz + sn * yz;
-  const float fx = ((cx + ox) - c0x) / res + 0.5f;
-  const float fy = ((cy + oy) - c0y) / res + 0.5f;
-  const float fz = ((cz + oz) - c0z) / res + 0.5f;
-  // (f).long() > 0  <=>  f >= 1 ; (f).long() < g  <=>  f < g   (NaN/inf fail both, like the int64 cast)
-  const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
-  if (!ok) return -1;
-  return ((int)fx * gy + (int)fy) * gz + (int)fz;
-}
 
 struct VoteSetup {
   float cx, cy, cz, xx, xy, xz, yx, yy, yz;
@@ -61,38 +61,210 @@ __device__ __forceinline__ VoteSetup vote_setup(const float* __restrict__ p, int
   return s;
 }
 
+// exact vote: flat cell index or -1 (train_dino.py:195-203), IEEE divisions
+__device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                         float yy, float yz, float cs, float sn, float c0x, float c0y, float c0z,
+                                         float res, int gx, int gy, int gz) {
+  const float ox = cs * xx + sn * yx;
+  const float oy = cs * xy + sn * yy;
+  const float oz = cs * xz + sn * yz;
+  const float fx = ((cx + ox) - c0x) / res + 0.5f;
+  const float fy = ((cy + oy) - c0y) / res + 0.5f;
+  const float fz = ((cz + oz) - c0z) / res + 0.5f;
+  // (f).long() > 0  <=>  f >= 1 ; (f).long() < g  <=>  f < g   (NaN/inf fail both, like the int64 cast)
+  const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
+  if (!ok) return -1;
+  return ((int)fx * gy + (int)fy) * gz + (int)fz;
+}
+
+// One coordinate without the IEEE division.  num = (c+off)-c0 exactly as the reference computes it; the
+// reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fl(fl(num*rinv) + 0.5) differs from it by at most
+// (|q|+1) * 3e-7 (two roundings of the reciprocal product vs one of the quotient, plus the add), so whenever t
+// is farther than m = (|t|+1)*1e-6 from every integer, trunc(t) == trunc(t_ref) and both validity tests agree.
+// Returns the cell (>= 1) when certain, -1 when certainly invalid, -2 when the exact path must decide.
+__device__ __forceinline__ int cell_fast(float num, float rinv, int g) {
+  const float t = num * rinv + 0.5f;
+  const float m = (fabsf(t) + 1.0f) * 1e-6f;
+  if (t < 1.0f - m || t >= (float)g + m) return -1;
+  const float fl = floorf(t);
+  const float fr = t - fl;
+  if (fr >= m && fr <= 1.0f - m) return (int)fl;     // here 1 <= fl < g
+  return -2;                                        // near a boundary (or NaN): exact division decides
+}
+
+__device__ __forceinline__ int vote_cell_fast(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                              float yy, float yz, float cs, float sn, float c0x, float c0y,
+                                              float c0z, float res, float rinv, int gx, int gy, int gz) {
+  const float ox = cs * xx + sn * yx;
+  const float oy = cs * xy + sn * yy;
+  const float oz = cs * xz + sn * yz;
+  const float nx = (cx + ox) - c0x, ny = (cy + oy) - c0y, nz = (cz + oz) - c0z;
+  const int ix = cell_fast(nx, rinv, gx), iy = cell_fast(ny, rinv, gy), iz = cell_fast(nz, rinv, gz);
+  if ((ix | iy | iz) >= 0) return (ix * gy + iy) * gz + iz;
+  if (ix == -1 || iy == -1 || iz == -1) return -1;
+  // rare: some coordinate sits on a cell boundary -> the reference's exact arithmetic
+  const float fx = nx / res + 0.5f, fy = ny / res + 0.5f, fz = nz / res + 0.5f;
+  const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
+  if (!ok) return -1;
+  return ((int)fx * gy + (int)fy) * gz + (int)fz;
+}
+
+// 1. per-pair frames -> SoA workspace fr[VC_FRAME_FLOATS][total]
+__global__ __launch_bounds__(256) void vote_frames_kernel(const float* __restrict__ pts,
+                                                          const int32_t* __restrict__ pt_off,
+                                                          const int32_t* __restrict__ idx, int k,
+                                                          const int32_t* __restrict__ tup_off,
+                                                          const float* __restrict__ tr, float res, int num_rots,
+                                                          int64_t total, float* __restrict__ fr) {
+  const int b = blockIdx.y;
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const float kappa = (float)num_rots * 0.15915494309189535f;           // R / (2 pi)
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+    const int64_t row = (int64_t)(t0 + t);
+    VoteSetup v = vote_setup(p, idx[row * k], idx[row * k + 1], tr[row * 2], tr[row * 2 + 1], res);
+    if (!v.ok) v.cx = NAN;                                              // NaN centre: every vote is invalid
+    const float A = sqrtf(v.xx * v.xx + v.yx * v.yx);                   // x(theta) - cx = A cos(theta - phi)
+    fr[0 * total + row] = v.cx; fr[1 * total + row] = v.cy; fr[2 * total + row] = v.cz;
+    fr[3 * total + row] = v.xx; fr[4 * total + row] = v.xy; fr[5 * total + row] = v.xz;
+    fr[6 * total + row] = v.yx; fr[7 * total + row] = v.yy; fr[8 * total + row] = v.yz;
+    fr[9 * total + row] = (A > 1e-12f) ? 1.0f / A : 0.0f;
+    fr[10 * total + row] = atan2f(v.yx, v.xx) * kappa;
+  }
+}
+
+// Rotation indices whose vote can fall into x-layers [xl, xh] of the grid: cos(theta - phi) in [L, U]/A gives
+// two arcs symmetric about phi, widened by VC_ARC_MARGIN steps and merged where they touch, so the ranges are
+// disjoint modulo num_rots.  Indices outside them provably vote outside the slab; indices inside are still
+// tested exactly, so the grid is identical to the exhaustive sweep (tests compare modes 1, 2 and 3).
+struct ArcSet {
+  int a0, n0, a1, n1;   // start index (may be negative / exceed num_rots: taken modulo) and length of each arc
+};
+
+__device__ __forceinline__ ArcSet slab_arcs(float cx, float invA, float phi, float c0x, float res, int xl, int xh,
+                                            int num_rots) {
+  ArcSet o;
+  o.a0 = 0; o.n0 = 0; o.a1 = 0; o.n1 = 0;
+  const float slop = 0.01f * res + 4e-7f * (fabsf(cx) + fabsf(c0x));
+  const float L = ((float)xl - 0.5f) * res + c0x - cx - slop;
+  const float U = ((float)xh + 0.5f) * res + c0x - cx + slop;
+  if (!(L <= U)) return o;                                   // NaN / inf centre: every vote is invalid anyway
+  if (invA == 0.0f) {
+    if (L <= 0.0f && 0.0f <= U) o.n0 = num_rots;
+    return o;
+  }
+  const float cl = L * invA - 1e-6f, cu = U * invA + 1e-6f;
+  if (cl > 1.0f || cu < -1.0f) return o;
+  const float kappa = (float)num_rots * 0.15915494309189535f;
+  const float amin = acosf(fminf(cu, 1.0f)) * kappa;
+  const float amax = acosf(fmaxf(cl, -1.0f)) * kappa;
+  const float half = 0.5f * (float)num_rots;
+  const bool near_merge = amin <= VC_ARC_MARGIN + 1.0f;
+  const bool far_merge = (half - amax) <= VC_ARC_MARGIN + 1.0f;
+  if (near_merge && far_merge) { o.n0 = num_rots; return o; }
+  int b0;
+  if (near_merge) {
+    o.a0 = (int)floorf(phi - amax - VC_ARC_MARGIN); b0 = (int)ceilf(phi + amax + VC_ARC_MARGIN);
+  } else if (far_merge) {
+    o.a0 = (int)floorf(phi + amin - VC_ARC_MARGIN); b0 = (int)ceilf(phi + (float)num_rots - amin + VC_ARC_MARGIN);
+  } else {
+    o.a0 = (int)floorf(phi + amin - VC_ARC_MARGIN); b0 = (int)ceilf(phi + amax + VC_ARC_MARGIN);
+    o.a1 = (int)floorf(phi - amax - VC_ARC_MARGIN);
+    o.n1 = (int)ceilf(phi - amin + VC_ARC_MARGIN) - o.a1 + 1;
+  }
+  o.n0 = b0 - o.a0 + 1;
+  if (o.n0 >= num_rots) { o.a0 = 0; o.n0 = num_rots; o.n1 = 0; }
+  return o;
+}
+
+__device__ __forceinline__ float bcast_f(float x, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+
+template <bool ARCS>
 __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
-    const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
-    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, float res, int num_rots,
+    const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
     SlabBest* __restrict__ slab_best, int s_max, int P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
-  const int b = blockIdx.z, s = blockIdx.y, pc = blockIdx.x;
+  float* s_cos = reinterpret_cast<float*>(slab + VC_SLAB_CELLS);      // [num_rots] (ARCS only)
+  float* s_sin = s_cos + VC_MAX_LDS_ROTS;
+  // grid = (scene, P, slab rank): the slab rank is the slowest dimension of the dispatch order
+  const int b = blockIdx.x, pc = blockIdx.y, rank = blockIdx.z;
   const CppfSceneGrid g = grids[b];
   const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
+  const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+  if (rank >= nslab) return;
+  // centre-out permutation of 0..nslab-1: mid, mid-1, mid+1, mid-2, ... (heavy central slabs dispatched first)
+  const int mid = nslab >> 1, dd = (rank + 1) >> 1;
+  const int s = (rank & 1) ? mid - dd : mid + dd;
   const int lo = s * VC_SLAB_CELLS;
-  if (lo >= G) return;
   const int n = min(VC_SLAB_CELLS, G - lo);
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
+  if (ARCS) {
+    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) { s_cos[i] = cos_tab[i]; s_sin[i] = sin_tab[i]; }
+  }
   __syncthreads();
 
-  const float* p = pts + 3 * (int64_t)pt_off[b];
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
   const int per = (nt + P - 1) / P;
   const int ts = pc * per, te = min(nt, ts + per);
   const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
   const float c0x = g.c0[0], c0y = g.c0[1], c0z = g.c0[2];
-  for (int t = ts + threadIdx.x; t < te; t += VC_THREADS) {
-    const int64_t row = (int64_t)(t0 + t);
-    const VoteSetup v = vote_setup(p, idx[row * k], idx[row * k + 1], tr[row * 2], tr[row * 2 + 1], res);
-    if (!v.ok) continue;
-    for (int r = 0; r < num_rots; ++r) {
-      const float cs = cos_tab[r], sn = sin_tab[r];
-      const int lin = vote_cell(v.cx, v.cy, v.cz, v.xx, v.xy, v.xz, v.yx, v.yy, v.yz, cs, sn, c0x, c0y, c0z, res,
-                                gx, gy, gz);
-      const unsigned rel = (unsigned)(lin - lo);
-      if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+  const float rinv = 1.0f / res;
+  const int gyz = gy * gz;
+  const int xl = lo / gyz, xh = (lo + n - 1) / gyz;            // x-layers this slab touches
+  const int lane = wave_lane();
+  for (int tb = ts; tb < te; tb += VC_THREADS) {
+    const int t = tb + threadIdx.x;
+    float cx = NAN, cy = 0, cz = 0, xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0, invA = 0, phi = 0;
+    if (t < te) {
+      const int64_t row = (int64_t)(t0 + t);
+      cx = fr[0 * total + row]; cy = fr[1 * total + row]; cz = fr[2 * total + row];
+      xx = fr[3 * total + row]; xy = fr[4 * total + row]; xz = fr[5 * total + row];
+      yx = fr[6 * total + row]; yy = fr[7 * total + row]; yz = fr[8 * total + row];
+      invA = fr[9 * total + row]; phi = fr[10 * total + row];
+    }
+    if (ARCS) {
+      const ArcSet arcs = slab_arcs(cx, invA, phi, c0x, res, xl, xh, num_rots);
+      const int ntot = arcs.n0 + arcs.n1;
+      const int own = min(ntot, VC_LANE_CAP);
+      for (int j = 0; j < own; ++j) {
+        const int r = (j < arcs.n0) ? arcs.a0 + j : arcs.a1 + (j - arcs.n0);
+        int rr = r % num_rots;
+        rr += (rr < 0) ? num_rots : 0;
+        const int lin = vote_cell_fast(cx, cy, cz, xx, xy, xz, yx, yy, yz, s_cos[rr], s_sin[rr], c0x, c0y, c0z, res,
+                                       rinv, gx, gy, gz);
+        const unsigned rel = (unsigned)(lin - lo);
+        if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+      }
+      unsigned long long left = __ballot(ntot > VC_LANE_CAP);
+      while (left) {
+        const int src = __ffsll((long long)left) - 1;
+        left &= left - 1;
+        const float bcx = bcast_f(cx, src), bcy = bcast_f(cy, src), bcz = bcast_f(cz, src);
+        const float bxx = bcast_f(xx, src), bxy = bcast_f(xy, src), bxz = bcast_f(xz, src);
+        const float byx = bcast_f(yx, src), byy = bcast_f(yy, src), byz = bcast_f(yz, src);
+        const int ba0 = __builtin_amdgcn_readlane(arcs.a0, src), ba1 = __builtin_amdgcn_readlane(arcs.a1, src);
+        const int bn0 = __builtin_amdgcn_readlane(arcs.n0, src), bnt = __builtin_amdgcn_readlane(ntot, src);
+        for (int j = VC_LANE_CAP + lane; j < bnt; j += 64) {
+          const int r = (j < bn0) ? ba0 + j : ba1 + (j - bn0);
+          int rr = r % num_rots;
+          rr += (rr < 0) ? num_rots : 0;
+          const int lin = vote_cell_fast(bcx, bcy, bcz, bxx, bxy, bxz, byx, byy, byz, s_cos[rr], s_sin[rr], c0x, c0y,
+                                         c0z, res, rinv, gx, gy, gz);
+          const unsigned rel = (unsigned)(lin - lo);
+          if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+        }
+      }
+    } else if (cx == cx) {
+      for (int r = 0; r < num_rots; ++r) {
+        const int lin = vote_cell(cx, cy, cz, xx, xy, xz, yx, yy, yz, cos_tab[r], sin_tab[r], c0x, c0y, c0z, res, gx,
+                                  gy, gz);
+        const unsigned rel = (unsigned)(lin - lo);
+        if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+      }
     }
   }
   __syncthreads();
@@ -227,28 +399,33 @@ static inline int vc_parts(int64_t cells_cap) {
   return (int)s_max;
 }
 
-extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap) {
-  if (B <= 0 || cells_cap <= 0) return 0;
+extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples) {
+  if (B <= 0 || cells_cap <= 0 || total_tuples < 0) return 0;
   return align_up((int64_t)B * vc_parts(cells_cap) * (int64_t)sizeof(SlabBest), 256) +
-         align_up((int64_t)B * cells_cap * 4, 256);
+         align_up((int64_t)B * cells_cap * 4, 256) + align_up(total_tuples * VC_FRAME_FLOATS * 4, 256);
 }
 
 extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
-                                const int32_t* tup_off, int max_t, const float* tr, double res, int num_rots,
-                                const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
+                                const int32_t* tup_off, int max_t, int64_t total_tuples, const float* tr, double res,
+                                int num_rots, const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
                                 uint32_t* grid, const int64_t* grid_off, int64_t cells_cap, int mode,
                                 void* workspace, int64_t workspace_bytes, int64_t* out_argmax, uint32_t* out_peak,
                                 double* out_world, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && tr && cos_tab && sin_tab && grids && out_argmax);
   CPPF_CHECK_ARG(k >= 2 && num_rots > 0 && res > 0.0 && cells_cap > 0 && cells_cap <= 0x7fffffffLL);
-  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_vote_center_workspace_bytes(B, cells_cap));
+  CPPF_CHECK_ARG(total_tuples >= 0 && max_t >= 0 && (int64_t)max_t <= total_tuples);
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_vote_center_workspace_bytes(B, cells_cap, total_tuples));
   CPPF_CHECK_ARG(grid == nullptr || grid_off != nullptr);
   hipStream_t st = (hipStream_t)stream;
   const int s_max_parts = vc_parts(cells_cap);
   SlabBest* best = (SlabBest*)workspace;
-  uint32_t* ws_grid = (uint32_t*)((char*)workspace + align_up((int64_t)B * s_max_parts * sizeof(SlabBest), 256));
+  char* wsp = (char*)workspace + align_up((int64_t)B * s_max_parts * sizeof(SlabBest), 256);
+  uint32_t* ws_grid = (uint32_t*)wsp;
+  float* frames = (float*)(wsp + align_up((int64_t)B * cells_cap * 4, 256));
   const int s_max = (int)((cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
   if (mode == 0) mode = (s_max <= 64) ? 1 : 2;
+  int exhaustive = 0;
+  if (mode == 3) { mode = 1; exhaustive = 1; }
   const float res32 = (float)res;
   if (max_t <= 0) mode = 2;
 
@@ -262,12 +439,17 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       if (P > pmax) P = pmax;
       if (P < 1) P = 1;
     }
+    const int lds_bytes = VC_SLAB_CELLS * 4 + 2 * VC_MAX_LDS_ROTS * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   VC_SLAB_CELLS * 4));
+      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       attr_set = true;
     }
+    // arcs need >1 slab to pay off and the table in LDS; mode 3 forces the exhaustive sweep (A/B reference)
+    const bool arcs = (exhaustive == 0) && s_max > 1 && num_rots <= VC_MAX_LDS_ROTS && num_rots >= 8;
     uint32_t* g_use = grid;
     const int64_t* goff_use = grid_off;
     if (P > 1) {
@@ -276,9 +458,17 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
       CPPF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(vote_center_slab_kernel, dim3(P, s_max, B), dim3(VC_THREADS), VC_SLAB_CELLS * 4, st, pts,
-                       pt_off, idx, k, tup_off, tr, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use,
-                       cells_cap, best, s_max_parts, P);
+    hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
+                       tup_off, tr, res32, num_rots, total_tuples, frames);
+    CPPF_LAUNCH_CHECK();
+    if (arcs)
+      hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
+                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
+                         best, s_max_parts, P);
+    else
+      hipLaunchKernelGGL(vote_center_slab_kernel<false>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
+                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
+                         best, s_max_parts, P);
     CPPF_LAUNCH_CHECK();
     if (P == 1) {
       hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap,
@@ -336,22 +526,23 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int* s_wave, int* tota
   return base + within;
 }
 
-// k-th smallest (0-based) of n non-negative floats by 3-pass radix select on the bit pattern.
-// Returns the bit pattern; *n_le = number of elements <= that value.
-__device__ uint32_t radix_select(const float* __restrict__ v, int n, int kth, uint32_t* s_hist, int* s_misc,
-                                 int* n_le) {
+// k-th smallest (0-based) of n uint32 keys by 3-pass (11/11/10 bit) radix select; key(i) yields the i-th key.
+// Returns the key; *n_le = number of keys <= it.  Whole workgroup must call it (blockDim.x multiple of 64).
+template <typename KeyFn>
+__device__ uint32_t radix_select_keys(KeyFn key, int n, int kth, uint32_t* s_hist /*[2048]*/, int* s_misc /*[4]*/,
+                                      int* n_le) {
   uint32_t prefix = 0;      // bits fixed so far
   int remaining = kth;      // rank inside the current candidate set
-  int below = 0;            // elements strictly below the candidate set
+  int below = 0;            // keys strictly below the candidate set
   const int shifts[3] = {21, 10, 0};
   const int widths[3] = {11, 11, 10};
   uint32_t mask_fixed = 0;
   for (int pass = 0; pass < 3; ++pass) {
     const int sh = shifts[pass], nbins = 1 << widths[pass];
-    for (int i = threadIdx.x; i < nbins; i += BV_THREADS) s_hist[i] = 0;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += BV_THREADS) {
-      const uint32_t bits = __float_as_uint(v[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t bits = key(i);
       if ((bits & mask_fixed) == prefix) atomicAdd(&s_hist[(bits >> sh) & (nbins - 1)], 1u);
     }
     __syncthreads();
@@ -373,8 +564,8 @@ __device__ uint32_t radix_select(const float* __restrict__ v, int n, int kth, ui
           const uint32_t c = s_hist[threadIdx.x * per + j];
           if ((uint32_t)remaining < run + c) {
             s_misc[0] = threadIdx.x * per + j;   // chosen bin
-            s_misc[1] = (int)run;                // elements of the candidate set below the chosen bin
-            s_misc[2] = (int)c;                  // elements in the chosen bin
+            s_misc[1] = (int)run;                // keys of the candidate set below the chosen bin
+            s_misc[2] = (int)c;                  // keys in the chosen bin
             break;
           }
           run += c;
@@ -391,6 +582,21 @@ __device__ uint32_t radix_select(const float* __restrict__ v, int n, int kth, ui
     __syncthreads();
   }
   return prefix;
+}
+
+// non-negative floats: bit order == value order, NaN last
+__device__ uint32_t radix_select(const float* __restrict__ v, int n, int kth, uint32_t* s_hist, int* s_misc,
+                                 int* n_le) {
+  return radix_select_keys([v](int i) { return __float_as_uint(v[i]); }, n, kth, s_hist, s_misc, n_le);
+}
+
+// order-preserving map float -> uint32 (negative values included)
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
 __global__ __launch_bounds__(BV_THREADS) void backvote_kernel(
@@ -922,19 +1128,17 @@ __global__ __launch_bounds__(256) void assemble_pose_kernel(
   if (threadIdx.x < 3) s_med[threadIdx.x] = NAN;
   __syncthreads();
   if (pred_scales && kept > 0) {
-    // lower median = element of rank (kept-1)/2 under (value, position) order; rank by counting
+    // lower median (torch.median) = order statistic (kept-1)/2 of each column, by radix select
+    __shared__ uint32_t s_hist[2048];
+    __shared__ int s_misc[4];
     const int t0 = tup_off[b];
     const int target = (kept - 1) / 2;
     for (int col = 0; col < 3; ++col) {
-      for (int i = threadIdx.x; i < kept; i += blockDim.x) {
-        const float vi = pred_scales[(int64_t)(t0 + kept_tuple[t0 + i]) * 3 + col];
-        int rank = 0;
-        for (int j = 0; j < kept; ++j) {
-          const float vj = pred_scales[(int64_t)(t0 + kept_tuple[t0 + j]) * 3 + col];
-          rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0;
-        }
-        if (rank == target) s_med[col] = vi;
-      }
+      int n_le;
+      const uint32_t k = radix_select_keys(
+          [=](int i) { return float_key(pred_scales[(int64_t)(t0 + kept_tuple[t0 + i]) * 3 + col]); }, kept, target,
+          s_hist, s_misc, &n_le);
+      if (threadIdx.x == 0) s_med[col] = key_float(k);
     }
   }
   __syncthreads();

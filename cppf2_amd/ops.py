@@ -285,12 +285,12 @@ def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, vis=None, trig=None,
     G = int(g.ncell)
     grid = torch.empty((G,), dtype=torch.int32, device=dev)
     grid_off = torch.tensor([0, G], dtype=torch.int64, device=dev)
-    ws_bytes = _L.cppf_vote_center_workspace_bytes(1, G)
+    ws_bytes = _L.cppf_vote_center_workspace_bytes(1, G, T)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     argmax = torch.empty((1,), dtype=torch.int64, device=dev)
     peak = torch.empty((1,), dtype=torch.int32, device=dev)
     world = torch.empty((1, 3), dtype=torch.float64, device=dev)
-    _lib.check(_L.cppf_vote_center(1, _p(pts), _p(pt_off), _p(idx), k, _p(tup_off), T, _p(tr), C.c_double(res),
+    _lib.check(_L.cppf_vote_center(1, _p(pts), _p(pt_off), _p(idx), k, _p(tup_off), T, T, _p(tr), C.c_double(res),
                                    num_rots, _p(cs), _p(sn), _p(grids), _p(grid), _p(grid_off), G, mode, _p(ws),
                                    ws_bytes, _p(argmax), _p(peak), _p(world), _stream()), "cppf_vote_center")
     shape = (int(g.g[0]), int(g.g[1]), int(g.g[2]))

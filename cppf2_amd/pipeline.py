@@ -85,7 +85,7 @@ class VotingPipeline:
         self.top_idx = e((2, B), dtype=torch.int32, device=d)
         self.top_cnt = e((2, B), dtype=torch.float32, device=d)
         self.results = e((B, 160), dtype=torch.uint8, device=d)
-        self.ws_vote_bytes = _L.cppf_vote_center_workspace_bytes(B, self.cells_cap)
+        self.ws_vote_bytes = _L.cppf_vote_center_workspace_bytes(B, self.cells_cap, self.Ttot)
         self.ws_bv_bytes = _L.cppf_backvote_workspace_bytes(self.Ntot, B)
         self.ws_rot_bytes = _L.cppf_rot_bins_workspace_bytes(B, self.S, self.max_kept, self.R, self.bmm)
         self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
@@ -102,7 +102,7 @@ class VotingPipeline:
         _lib.check(_L.cppf_scene_bounds(self.B, ops._p(pts), ops._p(self.pt_off), C.c_float(self.res),
                                         ops._p(self.grids), st), "cppf_scene_bounds")
         _lib.check(_L.cppf_vote_center(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
-                                       ops._p(self.tup_off), self.max_t, ops._p(self.tr), C.c_double(self.res),
+                                       ops._p(self.tup_off), self.max_t, self.Ttot, ops._p(self.tr), C.c_double(self.res),
                                        self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.grids), ops._p(grid),
                                        ops._p(grid_off), self.cells_cap, self.vote_mode, ops._p(self.ws),
                                        self.ws_vote_bytes, ops._p(self.argmax), ops._p(self.peak), ops._p(self.world),

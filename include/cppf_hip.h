@@ -133,14 +133,15 @@ int cppf_generate_target_pairs(int B, const float* pairs, const int32_t* tup_off
  *   grid / grid_off: optional uint32 output grid (all scenes concatenated, scene b at grid_off[b],
  *     int64 device offsets); pass NULL to keep the accumulator on-chip only.
  *   cells_cap: upper bound on ncell of any scene in the batch (sizes the launch; scenes above it get
- *     flags bit2 and no votes).  mode: 0 = auto, 1 = LDS-slab accumulation, 2 = global atomics.
- *   workspace: cppf_vote_center_workspace_bytes(B, cells_cap) bytes.
+ *     flags bit2 and no votes).  mode: 0 = auto, 1 = LDS-slab accumulation (per-slab rotation arcs),
+ *     2 = global atomics, 3 = LDS-slab with the exhaustive rotation sweep (A/B reference).
+ *   workspace: cppf_vote_center_workspace_bytes(B, cells_cap, total_tuples) bytes.
  *   out_argmax int64[B], out_peak uint32[B], out_world float64[B,3]. */
 int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off, float res, CppfSceneGrid* out, void* stream);
-int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap);
+int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples);
 int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
-                     const int32_t* tup_off, int max_t, const float* tr, double res, int num_rots,
-                     const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
+                     const int32_t* tup_off, int max_t, int64_t total_tuples, const float* tr, double res,
+                     int num_rots, const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
                      uint32_t* grid, const int64_t* grid_off, int64_t cells_cap, int mode,
                      void* workspace, int64_t workspace_bytes,
                      int64_t* out_argmax, uint32_t* out_peak, double* out_world, void* stream);

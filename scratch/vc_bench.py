@@ -1,0 +1,38 @@
+"""Micro-benchmark of single stages with the bench workload's inputs (not part of the product)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cppf2_amd import ops, synth
+from cppf2_amd.pipeline import VotingPipeline
+
+B, N, T, R = int(os.environ.get("B", 64)), 4096, 20000, 180
+stage = sys.argv[1] if len(sys.argv) > 1 else "vote_center"
+reps = int(os.environ.get("REPS", 10))
+mode = int(os.environ.get("MODE", 0))
+dev = torch.device("cuda")
+scenes = [synth.make_scene(0, b, N) for b in range(B)]
+pts = torch.from_numpy(np.concatenate([s["pc"] for s in scenes])).to(dev)
+pipe = VotingPipeline([N] * B, [T] * B, num_rots=R, vote_mode=mode)
+idx = ops.sample_tuples(N, T, 5, 0, tuple(range(B)))
+canon = torch.from_numpy(np.concatenate([s["pc_canon"] for s in scenes])).to(dev)
+base = (torch.arange(B, device=dev, dtype=torch.int64) * N).repeat_interleave(T)
+coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(B * T, 6)
+pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
+kbin = torch.arange(32, device=dev, dtype=torch.float32)
+logits = (-0.5 * ((kbin[None, None, :] - pos[..., None]) / 0.6) ** 2).contiguous()
+u = ops.philox_uniform(T, 6, 0, 1, tuple(range(B)))
+pipe.decode(pts, idx, logits, u)
+pipe.vote_center(pts, idx)
+pipe.backvote(pts, idx)
+pipe.rot_bins(pts, idx)
+torch.cuda.synchronize()
+fn = {"vote_center": lambda: pipe.vote_center(pts, idx), "backvote": lambda: pipe.backvote(pts, idx),
+      "rot_bins": lambda: pipe.rot_bins(pts, idx), "decode": lambda: pipe.decode(pts, idx, logits, u)}[stage]
+fn(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    fn()
+e1.record(); torch.cuda.synchronize()
+res = pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8)
+print(stage, "mode", mode, "B", B, "ms/launch %.3f" % (e0.elapsed_time(e1) / reps), "mean cells", res[:, 6].mean(), "argmax0", int(pipe.argmax[0]))

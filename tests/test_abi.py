@@ -46,7 +46,7 @@ def test_argument_validation_is_loud():
     assert b"invalid argument" in lib.cppf_last_error_string()
     with pytest.raises(_lib.CppfError):
         _lib.check(st, "cppf_sample_tuples")
-    assert lib.cppf_vote_center_workspace_bytes(4, 1 << 20) > 4 * (1 << 20) * 4
+    assert lib.cppf_vote_center_workspace_bytes(4, 1 << 20, 1000) > 4 * (1 << 20) * 4 + 1000 * 44
     assert lib.cppf_rot_bins_workspace_bytes(2, 720, 2000, 180, 100000) >= 2 * 5 * 720 * 8
 
 

@@ -128,7 +128,7 @@ def test_decode_bins_generic_nb():
 
 
 # ------------------------------------------------------------------------------------------ a6
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_vote_center_golden_small(small, mode):
     grid, cand = ops.vote_center(small["small_pc"], small["small_tr0"], 2e-3, small["small_idx"][:, :2], 36,
                                  trig=(small["small_cos"], small["small_sin"]), mode=mode)
@@ -146,7 +146,7 @@ def _full_inputs(f):
     return scene, pc, idx, scaled, (g["cos180"], g["sin180"]), g["sphere_pts"]
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_vote_center_full_size_golden(full_summary, mode):
     f = full_summary["full"]
     scene, pc, idx, scaled, trig, _ = _full_inputs(f)
