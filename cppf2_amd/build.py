@@ -27,6 +27,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     inc = os.path.join(ROOT, "include")
     hdrs = [os.path.join(inc, "cppf_hip.h"), os.path.join(CSRC, "cppf_common.h")]
+    extra = os.environ.get("CPPF_EXTRA_FLAGS", "").split()
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -34,7 +35,7 @@ def build(force=False, verbose=True):
             continue
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-I", inc, "-I", CSRC, "-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-I", inc, "-I", CSRC, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

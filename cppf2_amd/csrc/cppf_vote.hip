@@ -13,9 +13,9 @@
 //   2. vote_center_slab_kernel: workgroup (scene, slab) streams the frames (coalesced), and for every pair
 //      derives the rotation indices that can reach the slab's x-layers (two arcs of the circle, from the
 //      amplitude/phase) -- so the work per scene stays ~one pass over the votes no matter how many slabs the
-//      grid needs.  Votes are counted with LDS atomics; arcs are very uneven in length, so each lane walks at
-//      most VC_LANE_CAP rotations of its own pair and the leftovers are swept by the whole wavefront (pair
-//      broadcast with v_readlane).  The cell of a vote is found without an IEEE division on the fast path
+//      grid needs.  Votes are counted with LDS atomics; arcs are very uneven in length, so a wavefront cuts its
+//      64 arcs into quanta of VC_QUANTUM rotations and deals the quanta out evenly over its lanes (owner frame
+//      pulled across lanes with ds_bpermute).  The cell of a vote is found without an IEEE division on the fast path
 //      (multiply by the rounded reciprocal, exact division only when the result lands within rounding distance
 //      of a cell boundary), which keeps the grid bit-identical to the reference's float32 pipeline.
 //      The slab is streamed out with plain coalesced stores (or not at all when the caller only wants the
@@ -32,8 +32,8 @@
 #define VC_ARG_BLOCKS 32
 #define VC_MAX_LDS_ROTS 1024
 #define VC_FRAME_FLOATS 11             // cx cy cz xx xy xz yx yy yz invA phi
-#ifndef VC_LANE_CAP
-#define VC_LANE_CAP 12
+#ifndef VC_QUANTUM
+#define VC_QUANTUM 4
 #endif
 #define VC_ARC_MARGIN 0.25f
 
@@ -78,35 +78,48 @@ __device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx,
 }
 
 // One coordinate without the IEEE division.  num = (c+off)-c0 exactly as the reference computes it; the
-// reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fl(fl(num*rinv) + 0.5) differs from it by at most
-// (|q|+1) * 3e-7 (two roundings of the reciprocal product vs one of the quotient, plus the add), so whenever t
-// is farther than m = (|t|+1)*1e-6 from every integer, trunc(t) == trunc(t_ref) and both validity tests agree.
-// Returns the cell (>= 1) when certain, -1 when certainly invalid, -2 when the exact path must decide.
-__device__ __forceinline__ int cell_fast(float num, float rinv, int g) {
-  const float t = num * rinv + 0.5f;
-  const float m = (fabsf(t) + 1.0f) * 1e-6f;
-  if (t < 1.0f - m || t >= (float)g + m) return -1;
+// reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fma(num, rinv, 0.5) differs from it by at most
+// (|q|+1) * 3e-7 (rounded reciprocal + one rounding vs quotient rounding + add rounding), so whenever t is
+// farther than m = (g+2)*1e-6 from every integer, trunc(t) == trunc(t_ref) and both validity tests
+// (cell > 0, cell < g) agree.  Otherwise (t on a cell boundary, NaN, far outside) `sure` is cleared and the
+// caller decides with the exact arithmetic.
+__device__ __forceinline__ int cell_fast(float num, float rinv, float m, bool& sure) {
+  const float t = fmaf(num, rinv, 0.5f);
   const float fl = floorf(t);
   const float fr = t - fl;
-  if (fr >= m && fr <= 1.0f - m) return (int)fl;     // here 1 <= fl < g
-  return -2;                                        // near a boundary (or NaN): exact division decides
+  sure = sure & (fr >= m) & (fr <= 1.0f - m) & (fabsf(t) < 16777216.0f);
+  return (int)fl;
 }
 
-__device__ __forceinline__ int vote_cell_fast(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
-                                              float yy, float yz, float cs, float sn, float c0x, float c0y,
-                                              float c0z, float res, float rinv, int gx, int gy, int gz) {
-  const float ox = cs * xx + sn * yx;
-  const float oy = cs * xy + sn * yy;
-  const float oz = cs * xz + sn * yz;
-  const float nx = (cx + ox) - c0x, ny = (cy + oy) - c0y, nz = (cz + oz) - c0z;
-  const int ix = cell_fast(nx, rinv, gx), iy = cell_fast(ny, rinv, gy), iz = cell_fast(nz, rinv, gz);
-  if ((ix | iy | iz) >= 0) return (ix * gy + iy) * gz + iz;
-  if (ix == -1 || iy == -1 || iz == -1) return -1;
-  // rare: some coordinate sits on a cell boundary -> the reference's exact arithmetic
+__device__ __noinline__ int vote_cell_exact_lin(float nx, float ny, float nz, float res, int gx, int gy, int gz) {
   const float fx = nx / res + 0.5f, fy = ny / res + 0.5f, fz = nz / res + 0.5f;
   const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
   if (!ok) return -1;
   return ((int)fx * gy + (int)fy) * gz + (int)fz;
+}
+
+struct GridConst {
+  float c0x, c0y, c0z, res, rinv, mx, my, mz;
+  int gx, gy, gz;
+};
+
+__device__ __forceinline__ int vote_cell_fast(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                              float yy, float yz, float cs, float sn, const GridConst& gc) {
+  const float ox = cs * xx + sn * yx;
+  const float oy = cs * xy + sn * yy;
+  const float oz = cs * xz + sn * yz;
+  const float nx = (cx + ox) - gc.c0x, ny = (cy + oy) - gc.c0y, nz = (cz + oz) - gc.c0z;
+  bool sure = true;
+  const int ix = cell_fast(nx, gc.rinv, gc.mx, sure);
+  const int iy = cell_fast(ny, gc.rinv, gc.my, sure);
+  const int iz = cell_fast(nz, gc.rinv, gc.mz, sure);
+  if (__builtin_expect(!sure, 0)) {
+    // certainly outside (by more than the rounding margin)?  then no exact arithmetic is needed either
+    return vote_cell_exact_lin(nx, ny, nz, gc.res, gc.gx, gc.gy, gc.gz);
+  }
+  const bool ok = ((unsigned)(ix - 1) < (unsigned)(gc.gx - 1)) & ((unsigned)(iy - 1) < (unsigned)(gc.gy - 1)) &
+                  ((unsigned)(iz - 1) < (unsigned)(gc.gz - 1));
+  return ok ? (ix * gc.gy + iy) * gc.gz + iz : -1;
 }
 
 // 1. per-pair frames -> SoA workspace fr[VC_FRAME_FLOATS][total]
@@ -188,10 +201,10 @@ __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
     SlabBest* __restrict__ slab_best, int s_max, int P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
-  float* s_cos = reinterpret_cast<float*>(slab + VC_SLAB_CELLS);      // [num_rots] (ARCS only)
-  float* s_sin = s_cos + VC_MAX_LDS_ROTS;
+  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
   // grid = (scene, P, slab rank): the slab rank is the slowest dimension of the dispatch order
   const int b = blockIdx.x, pc = blockIdx.y, rank = blockIdx.z;
+  const long long t_start = wall_clock64();
   const CppfSceneGrid g = grids[b];
   const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
   const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
   const int n = min(VC_SLAB_CELLS, G - lo);
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
   if (ARCS) {
-    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) { s_cos[i] = cos_tab[i]; s_sin[i] = sin_tab[i]; }
+    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
   }
   __syncthreads();
 
@@ -212,7 +225,10 @@ __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
   const int ts = pc * per, te = min(nt, ts + per);
   const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
   const float c0x = g.c0[0], c0y = g.c0[1], c0z = g.c0[2];
-  const float rinv = 1.0f / res;
+  GridConst gc;
+  gc.c0x = c0x; gc.c0y = c0y; gc.c0z = c0z; gc.res = res; gc.rinv = 1.0f / res;
+  gc.mx = (float)(gx + 2) * 1e-6f; gc.my = (float)(gy + 2) * 1e-6f; gc.mz = (float)(gz + 2) * 1e-6f;
+  gc.gx = gx; gc.gy = gy; gc.gz = gz;
   const int gyz = gy * gz;
   const int xl = lo / gyz, xh = (lo + n - 1) / gyz;            // x-layers this slab touches
   const int lane = wave_lane();
@@ -227,35 +243,53 @@ __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
       invA = fr[9 * total + row]; phi = fr[10 * total + row];
     }
     if (ARCS) {
+      // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
+      // handful, many none), so the wavefront's 64 arcs are cut into quanta of VC_QUANTUM rotations and the
+      // quanta are dealt out evenly: lane l takes quantum q = base + l, finds its owner pair by binary search
+      // over the inclusive scan of quanta counts and pulls the owner's frame across lanes (ds_bpermute).
       const ArcSet arcs = slab_arcs(cx, invA, phi, c0x, res, xl, xh, num_rots);
       const int ntot = arcs.n0 + arcs.n1;
-      const int own = min(ntot, VC_LANE_CAP);
-      for (int j = 0; j < own; ++j) {
-        const int r = (j < arcs.n0) ? arcs.a0 + j : arcs.a1 + (j - arcs.n0);
-        int rr = r % num_rots;
-        rr += (rr < 0) ? num_rots : 0;
-        const int lin = vote_cell_fast(cx, cy, cz, xx, xy, xz, yx, yy, yz, s_cos[rr], s_sin[rr], c0x, c0y, c0z, res,
-                                       rinv, gx, gy, gz);
-        const unsigned rel = (unsigned)(lin - lo);
-        if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+      const int nq = (ntot + VC_QUANTUM - 1) / VC_QUANTUM;
+      int incl = nq;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
       }
-      unsigned long long left = __ballot(ntot > VC_LANE_CAP);
-      while (left) {
-        const int src = __ffsll((long long)left) - 1;
-        left &= left - 1;
-        const float bcx = bcast_f(cx, src), bcy = bcast_f(cy, src), bcz = bcast_f(cz, src);
-        const float bxx = bcast_f(xx, src), bxy = bcast_f(xy, src), bxz = bcast_f(xz, src);
-        const float byx = bcast_f(yx, src), byy = bcast_f(yy, src), byz = bcast_f(yz, src);
-        const int ba0 = __builtin_amdgcn_readlane(arcs.a0, src), ba1 = __builtin_amdgcn_readlane(arcs.a1, src);
-        const int bn0 = __builtin_amdgcn_readlane(arcs.n0, src), bnt = __builtin_amdgcn_readlane(ntot, src);
-        for (int j = VC_LANE_CAP + lane; j < bnt; j += 64) {
-          const int r = (j < bn0) ? ba0 + j : ba1 + (j - bn0);
-          int rr = r % num_rots;
-          rr += (rr < 0) ? num_rots : 0;
-          const int lin = vote_cell_fast(bcx, bcy, bcz, bxx, bxy, bxz, byx, byy, byz, s_cos[rr], s_sin[rr], c0x, c0y,
-                                         c0z, res, rinv, gx, gy, gz);
-          const unsigned rel = (unsigned)(lin - lo);
-          if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+      const int excl = incl - nq;
+      const int WQ = __builtin_amdgcn_readlane(incl, 63);
+      for (int qb = 0; qb < WQ; qb += 64) {
+        const int q = qb + lane;
+        int pos = 0;                                  // number of lanes whose quanta all precede q
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1) {
+          const int val = __shfl(incl, pos + st - 1);
+          pos += (val <= q) ? st : 0;
+        }
+        const int src = min(pos, 63);
+        const int j0 = (q - __shfl(excl, src)) * VC_QUANTUM;
+        const float ocx = __shfl(cx, src), ocy = __shfl(cy, src), ocz = __shfl(cz, src);
+        const float oxx = __shfl(xx, src), oxy = __shfl(xy, src), oxz = __shfl(xz, src);
+        const float oyx = __shfl(yx, src), oyy = __shfl(yy, src), oyz = __shfl(yz, src);
+        const int oa0 = __shfl(arcs.a0, src), on0 = __shfl(arcs.n0, src), oa1 = __shfl(arcs.a1, src);
+        // NB every cross-lane read sits in wave-uniform control flow: ds_bpermute returns 0 for a source lane
+        // that is masked off, so a shuffle under `if (q < WQ)` would lose the quanta owned by idle lanes.
+        const int ont_all = __shfl(ntot, src);
+        const int ont = (q < WQ) ? ont_all : 0;
+#pragma unroll
+        for (int jj = 0; jj < VC_QUANTUM; ++jj) {
+          const int j = j0 + jj;
+          if (j < ont) {
+            int rr = (j < on0) ? oa0 + j : oa1 + (j - on0);   // in (-2R, 3R): fold without an integer division
+            rr += (rr < 0) ? num_rots : 0;
+            rr += (rr < 0) ? num_rots : 0;
+            rr -= (rr >= num_rots) ? num_rots : 0;
+            rr -= (rr >= num_rots) ? num_rots : 0;
+            const float2 tg = s_trig[rr];
+            const int lin = vote_cell_fast(ocx, ocy, ocz, oxx, oxy, oxz, oyx, oyy, oyz, tg.x, tg.y, gc);
+            const unsigned rel = (unsigned)(lin - lo);
+            if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+          }
         }
       }
     } else if (cx == cx) {
@@ -285,7 +319,8 @@ __global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < VC_THREADS / 64; ++w) argmax_combine(bv, bi, s_v[w], s_i[w]);
-      SlabBest o; o.idx = bi; o.val = bv; o.pad = 0;
+      SlabBest o; o.idx = bi; o.val = bv;
+      o.pad = (uint32_t)(wall_clock64() - t_start);     // workgroup duration in 100 MHz ticks (diagnostics)
       slab_best[(int64_t)b * s_max + s] = o;
     }
   } else {

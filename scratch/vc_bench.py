@@ -36,3 +36,14 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 res = pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8)
 print(stage, "mode", mode, "B", B, "ms/launch %.3f" % (e0.elapsed_time(e1) / reps), "mean cells", res[:, 6].mean(), "argmax0", int(pipe.argmax[0]))
+
+if stage == "vote_center" and mode in (0, 1):
+    import ctypes
+    smp = max((pipe.cells_cap + 36864 - 1) // 36864, 32)
+    raw = pipe.ws[:B * smp * 16].cpu().numpy().view(np.uint32).reshape(B, smp, 4)
+    nsl = (res[:, 6] + 36863) // 36864
+    durs = np.concatenate([raw[b, :nsl[b], 3] for b in range(B)]).astype(np.float64) / 100.0   # us
+    peaks = np.concatenate([raw[b, :nsl[b], 2] for b in range(B)])
+    print("WGs", len(durs), "dur us: mean %.0f  p50 %.0f  p90 %.0f  max %.0f  sum/256 %.0f" % (durs.mean(), np.median(durs), np.percentile(durs, 90), durs.max(), durs.sum() / 256))
+    b0 = raw[0, :nsl[0], 3] / 100.0
+    print("scene0 per-slab us:", np.round(b0).astype(int).tolist())
