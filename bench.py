@@ -111,7 +111,7 @@ class Step:
         self._mark("shot352")
         shot = torch.nan_to_num_(self.shot, nan=0.0)                                       # eval.py:215-216
         normal = torch.nan_to_num_(self.normal, nan=0.0)
-        feat = self.model.shot_encoder(shot)
+        feat = self.model.encode_points(shot)
         self._mark("shot_encoder_torch")
         x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
         self._mark("encode_tuples")

@@ -112,7 +112,7 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         kb = torch.arange(32, device=dev, dtype=torch.float32)
         prior = (-0.5 * ((kb[None, None, :] - pos[..., None]) / 0.6) ** 2)
 
-    feat_shot = shot_model.shot_encoder(shot_feat)
+    feat_shot = shot_model.encode_points(shot_feat)
     results, losses = [], []
     pred_scale = pred_scale_norm = None
     for model_idx in (0, 1):                                                   # eval.py:219
