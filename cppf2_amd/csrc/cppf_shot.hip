@@ -1,11 +1,16 @@
 // cppf_shot.hip -- SHOT352 descriptors + normals on gfx950: replaces shot.compute / estimate_normal
 // (src_shot/shot.cpp:12-100, a pybind11 wrapper over PCL 1.9.1 NormalEstimation + SHOTEstimation).
 //
-// One wavefront per query point (workgroup = 64 threads): the 64 lanes sweep the scene's points with
-// coalesced loads, keep per-lane partial sums (float64) that are reduced with cross-lane shuffles, and
-// compact the radius neighbours (ballot + prefix popcount) into an LDS list so that the expensive
-// per-neighbour histogram interpolation (float64 acos/atan2) runs with every lane busy.  The 352-bin
-// histogram lives in LDS and is filled with ds_add_f32.
+// Pipeline (all per batch of scenes):
+//   shot_cells   workgroup/scene: uniform cell grid with cell edge >= the search radius, counting sort of the
+//                scene's points by cell in LDS, points re-written in cell order (so a radius query reads 9
+//                contiguous runs of points -- 3 x-adjacent cells for each of the 3x3 (y,z) neighbours);
+//   shot_cov     wavefront/query: lanes sweep the 9 runs (coalesced), float64 partial sums of the normal
+//                covariance and of the distance-weighted LRF covariance, column-summed through LDS in a fixed
+//                order;
+//   shot_eig     thread/query: two 3x3 Jacobi eigen-solves (every lane busy), normal orientation;
+//   shot_hist    wavefront/query: radius neighbours compacted (ballot + prefix popcount) into an LDS list, LRF
+//                sign disambiguation by ballots, interpolated 352-bin histogram in LDS (ds_add_f32), L2 norm.
 //
 // Numerics follow PCL 1.9.1's algorithm (features/impl/normal_3d.hpp, shot_lrf.hpp, shot.hpp) with the
 // deviations listed in oracle/shot_oracle.c (float64 covariance about the query point, Jacobi eigen-solver,
@@ -105,46 +110,6 @@ __device__ __forceinline__ float sqdist3(float px, float py, float pz, float qx,
 }
 
 // ---------------------------------------------------------------------------------------------
-// normals: pcl::NormalEstimation (radius search) + flipNormalTowardsViewpoint(origin)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void normals_kernel(int B, const float* __restrict__ pts,
-                                                     const int32_t* __restrict__ pt_off, float radius,
-                                                     float* __restrict__ out) {
-  const int qi = blockIdx.x;
-  const int b = find_scene_pt(pt_off, B, qi);
-  const int p0 = pt_off[b], n = pt_off[b + 1] - p0;
-  const float* sp = pts + 3 * (int64_t)p0;
-  const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
-  const float r2 = radius * radius;
-  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int cnt = 0;
-  for (int j = threadIdx.x; j < n; j += 64) {
-    const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
-    if (sqdist3(px, py, pz, qx, qy, qz) < r2) {
-      const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-      s[0] += x * x; s[1] += x * y; s[2] += x * z; s[3] += y * y; s[4] += y * z; s[5] += z * z;
-      s[6] += x; s[7] += y; s[8] += z;
-      ++cnt;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 9; ++c) s[c] = wave_sum(s[c]);
-  cnt = wave_sum_i(cnt);
-  if (threadIdx.x != 0) return;
-  float* o = out + 3 * (int64_t)qi;
-  if (cnt < 3) { o[0] = o[1] = o[2] = NAN; return; }
-  const double inv = 1.0 / (double)cnt;
-  const double mx = s[6] * inv, my = s[7] * inv, mz = s[8] * inv;
-  const double cov[6] = {s[0] * inv - mx * mx, s[1] * inv - mx * my, s[2] * inv - mx * mz,
-                         s[3] * inv - my * my, s[4] * inv - my * mz, s[5] * inv - mz * mz};
-  const Eig3 e = jacobi3(cov);
-  double nx = e.v[0][0], ny = e.v[1][0], nz = e.v[2][0];
-  const double ct = (0.0 - (double)px) * nx + (0.0 - (double)py) * ny + (0.0 - (double)pz) * nz;
-  if (ct < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
-  o[0] = (float)nx; o[1] = (float)ny; o[2] = (float)nz;
-}
-
-// ---------------------------------------------------------------------------------------------
 // SHOT352
 // ---------------------------------------------------------------------------------------------
 #define RAD_45 0.78539816339744830961566084581988
@@ -225,160 +190,420 @@ __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, fl
   atomicAdd(&shot[volume_index + step_index], (float)w);
 }
 
-__global__ __launch_bounds__(64) void shot_kernel(int B, const float* __restrict__ pts,
-                                                  const int32_t* __restrict__ pt_off, const float* __restrict__ nrm,
-                                                  float radius, float* __restrict__ out_shot,
-                                                  float* __restrict__ out_rf) {
+
+#define CELL_CAP 16384     // cells per scene held in LDS by shot_cells (64 KiB of counters)
+#define NSUM 19            // 9 normal sums + count, 6 LRF sums + weight sum + valid count (+1 pad)
+
+struct CellHdr {
+  float c0[3];
+  float inv;       // 1 / cell edge
+  int32_t d[3];
+  int32_t ncell;
+};
+
+__device__ __forceinline__ int cell_coord(float p, float c0, float inv, int dim) {
+  int c = (int)((p - c0) * inv);
+  c = c < 0 ? 0 : c;
+  return c >= dim ? dim - 1 : c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shot_cells: per scene counting sort by cell.  cell index = (z * dy + y) * dx + x  (x fastest)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void shot_cells_kernel(const float* __restrict__ pts,
+                                                          const int32_t* __restrict__ pt_off, float rmax,
+                                                          CellHdr* __restrict__ hdrs,
+                                                          int32_t* __restrict__ cell_start /* [B][CELL_CAP+1] */,
+                                                          int32_t* __restrict__ sorted_idx,
+                                                          float* __restrict__ sorted_pts) {
+  __shared__ uint32_t s_cnt[CELL_CAP];
+  __shared__ float s_red[16][6];
+  __shared__ uint32_t s_wsum[16];
+  __shared__ CellHdr s_h;
+  const int b = blockIdx.x;
+  const int p0 = pt_off[b], n = pt_off[b + 1] - p0;
+  const float* sp = pts + 3 * (int64_t)p0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n; i += 1024) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = sp[3 * i + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
+    }
+  if (wave_lane() == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_red[threadIdx.x >> 6][c] = mn[c]; s_red[threadIdx.x >> 6][3 + c] = mx[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    CellHdr h;
+    float ext[3];
+    for (int c = 0; c < 3; ++c) {
+      float lo = s_red[0][c], hi = s_red[0][3 + c];
+      for (int w = 1; w < 16; ++w) { lo = fminf(lo, s_red[w][c]); hi = fmaxf(hi, s_red[w][3 + c]); }
+      h.c0[c] = lo;
+      ext[c] = (n > 0) ? hi - lo : 0.0f;
+    }
+    // cell edge >= rmax (with slack for float rounding of the cell coordinate); coarsen until the grid fits LDS
+    float edge = rmax * 1.0005f;
+    for (;;) {
+      int64_t tot = 1;
+      for (int c = 0; c < 3; ++c) { h.d[c] = (int)(ext[c] / edge) + 1; tot *= h.d[c]; }
+      if (tot <= CELL_CAP) { h.ncell = (int)tot; break; }
+      edge *= 1.26f;
+    }
+    h.inv = 1.0f / edge;
+    s_h = h;
+    hdrs[b] = h;
+  }
+  __syncthreads();
+  const CellHdr h = s_h;
+  for (int i = threadIdx.x; i < h.ncell; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int cx = cell_coord(sp[3 * i], h.c0[0], h.inv, h.d[0]);
+    const int cy = cell_coord(sp[3 * i + 1], h.c0[1], h.inv, h.d[1]);
+    const int cz = cell_coord(sp[3 * i + 2], h.c0[2], h.inv, h.d[2]);
+    atomicAdd(&s_cnt[(cz * h.d[1] + cy) * h.d[0] + cx], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of s_cnt[0..ncell): each thread owns a contiguous chunk
+  const int per = (h.ncell + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(h.ncell, lo + per);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += s_cnt[i];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off);
+    if (wave_lane() >= off) incl += o;
+  }
+  if (wave_lane() == 63) s_wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wsum[w];
+  uint32_t run = base + incl - sum;
+  int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t c = s_cnt[i];
+    cs[i] = (int32_t)run;
+    s_cnt[i] = run;            // becomes the scatter cursor
+    run += c;
+  }
+  if (threadIdx.x == 0) cs[h.ncell] = n;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float x = sp[3 * i], y = sp[3 * i + 1], z = sp[3 * i + 2];
+    const int cx = cell_coord(x, h.c0[0], h.inv, h.d[0]);
+    const int cy = cell_coord(y, h.c0[1], h.inv, h.d[1]);
+    const int cz = cell_coord(z, h.c0[2], h.inv, h.d[2]);
+    const uint32_t pos = atomicAdd(&s_cnt[(cz * h.d[1] + cy) * h.d[0] + cx], 1u);
+    sorted_idx[p0 + pos] = i;
+    float* o = sorted_pts + 3 * (int64_t)(p0 + pos);
+    o[0] = x; o[1] = y; o[2] = z;
+  }
+}
+
+// the 9 runs of cell-sorted points that can hold neighbours of a query in cell (cx, cy, cz)
+struct Runs {
+  int beg[9], end[9];
+};
+
+__device__ __forceinline__ void query_runs(const CellHdr& h, const int32_t* __restrict__ cs, float px, float py,
+                                           float pz, Runs& r) {
+  const int cx = cell_coord(px, h.c0[0], h.inv, h.d[0]);
+  const int cy = cell_coord(py, h.c0[1], h.inv, h.d[1]);
+  const int cz = cell_coord(pz, h.c0[2], h.inv, h.d[2]);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.d[0] - 1);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = cy + (k % 3) - 1, zz = cz + (k / 3) - 1;
+    if (yy < 0 || yy >= h.d[1] || zz < 0 || zz >= h.d[2]) { r.beg[k] = 0; r.end[k] = 0; continue; }
+    const int row = (zz * h.d[1] + yy) * h.d[0];
+    r.beg[k] = cs[row + x0];
+    r.end[k] = cs[row + x1 + 1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shot_cov: float64 sums for the normal covariance (radius rn) and the LRF covariance (radius rs)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __restrict__ pts,
+                                                      const int32_t* __restrict__ pt_off,
+                                                      const CellHdr* __restrict__ hdrs,
+                                                      const int32_t* __restrict__ cell_start,
+                                                      const float* __restrict__ sorted_pts, float rn, float rs,
+                                                      double* __restrict__ sums /* [Ntot][NSUM] */) {
+  __shared__ double s_part[NSUM][64];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x;
+  const int b = find_scene_pt(pt_off, B, qi);
+  const int p0 = pt_off[b];
+  const CellHdr h = hdrs[b];
+  const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
+  const float* sp = sorted_pts + 3 * (int64_t)p0;
+  const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
+  const float rn2 = rn * rn, rs2 = rs * rs;
+  Runs runs;
+  query_runs(h, cs, px, py, pz, runs);
+  double a[NSUM];
+#pragma unroll
+  for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    for (int j = runs.beg[k] + lane; j < runs.end[k]; j += 64) {
+      const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
+      const float d2 = sqdist3(px, py, pz, qx, qy, qz);
+      const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
+      if (d2 < rn2) {
+        a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
+        a[6] += x; a[7] += y; a[8] += z; a[9] += 1.0;
+      }
+      if (d2 < rs2) {
+        a[18] += 1.0;                                             // all in-radius points (incl. self)
+        if (!(qx == px && qy == py && qz == pz)) {
+          const double w = (double)rs - (double)__builtin_sqrtf(d2);
+          a[10] += w * (x * x); a[11] += w * (x * y); a[12] += w * (x * z);
+          a[13] += w * (y * y); a[14] += w * (y * z); a[15] += w * (z * z);
+          a[16] += w; a[17] += 1.0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NSUM; ++c) s_part[c][lane] = a[c];
+  __syncthreads();
+  if (lane < NSUM) {
+    double t = 0.0;
+    for (int l = 0; l < 64; ++l) t += s_part[lane][l];            // fixed order: run-to-run reproducible
+    sums[(int64_t)qi * NSUM + lane] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shot_eig: normal (pcl::NormalEstimation + flipNormalTowardsViewpoint(origin)) and the unsigned LRF axes
+// ---------------------------------------------------------------------------------------------
+struct LrfPre {
+  double v1[3], v3[3];
+  int32_t valid, nn;
+};
+
+__global__ __launch_bounds__(256) void shot_eig_kernel(int64_t total, const float* __restrict__ pts,
+                                                       const double* __restrict__ sums, float* __restrict__ normals,
+                                                       LrfPre* __restrict__ pre) {
+  const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= total) return;
+  const double* s = sums + qi * NSUM;
+  if (normals) {
+    float* o = normals + 3 * qi;
+    const int cnt = (int)s[9];
+    if (cnt < 3) {
+      o[0] = o[1] = o[2] = NAN;
+    } else {
+      const double inv = 1.0 / (double)cnt;
+      const double mx = s[6] * inv, my = s[7] * inv, mz = s[8] * inv;
+      const double cov[6] = {s[0] * inv - mx * mx, s[1] * inv - mx * my, s[2] * inv - mx * mz,
+                             s[3] * inv - my * my, s[4] * inv - my * mz, s[5] * inv - mz * mz};
+      const Eig3 e = jacobi3(cov);
+      double nx = e.v[0][0], ny = e.v[1][0], nz = e.v[2][0];
+      const double px = (double)pts[3 * qi], py = (double)pts[3 * qi + 1], pz = (double)pts[3 * qi + 2];
+      const double ct = (0.0 - px) * nx + (0.0 - py) * ny + (0.0 - pz) * nz;
+      if (ct < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+      o[0] = (float)nx; o[1] = (float)ny; o[2] = (float)nz;
+    }
+  }
+  if (pre) {
+    LrfPre p;
+    p.valid = (int)s[17];
+    p.nn = (int)s[18];
+    bool ok = p.valid >= 5;
+    if (ok) {
+      double cov[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) cov[c] = s[10 + c] / s[16];
+      const Eig3 e = jacobi3(cov);
+      ok = isfinite(e.w[0]) && isfinite(e.w[1]) && isfinite(e.w[2]);
+      p.v1[0] = e.v[0][2]; p.v1[1] = e.v[1][2]; p.v1[2] = e.v[2][2];
+      p.v3[0] = e.v[0][0]; p.v3[1] = e.v[1][0]; p.v3[2] = e.v[2][0];
+    }
+    if (!ok) { p.valid = -1; p.v1[0] = p.v1[1] = p.v1[2] = p.v3[0] = p.v3[1] = p.v3[2] = NAN; }
+    pre[qi] = p;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shot_hist: sign disambiguation + interpolated histogram
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __restrict__ pts,
+                                                       const int32_t* __restrict__ pt_off,
+                                                       const CellHdr* __restrict__ hdrs,
+                                                       const int32_t* __restrict__ cell_start,
+                                                       const int32_t* __restrict__ sorted_idx,
+                                                       const float* __restrict__ sorted_pts,
+                                                       const float* __restrict__ nrm, const LrfPre* __restrict__ pre,
+                                                       float radius, float* __restrict__ out_shot,
+                                                       float* __restrict__ out_rf) {
   __shared__ float s_hist[SHOT_LEN];
-  __shared__ int s_list[SH_LCAP];
+  __shared__ int s_list[SH_LCAP];       // positions in the cell-sorted order
   __shared__ float s_rf[9];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const int b = find_scene_pt(pt_off, B, qi);
-  const int p0 = pt_off[b], n = pt_off[b + 1] - p0;
-  const float* sp = pts + 3 * (int64_t)p0;
+  const int p0 = pt_off[b];
+  const CellHdr h = hdrs[b];
+  const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
+  const float* sp = sorted_pts + 3 * (int64_t)p0;
+  const int32_t* sid = sorted_idx + p0;
   const float* sn = nrm + 3 * (int64_t)p0;
   const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
   const float r2 = radius * radius;
   float* o = out_shot + (int64_t)SHOT_LEN * qi;
-
-  // sweep A: neighbour list + weighted covariance of the LRF (shot_lrf.hpp)
-  double cov[6] = {0, 0, 0, 0, 0, 0}, sum = 0.0;
-  int valid = 0, nn = 0, m = 0;   // valid: non-coincident neighbours; nn: all in-radius (incl. self); m: list fill
-  for (int base = 0; base < n; base += 64) {
-    const int j = base + lane;
-    bool in = false;
-    float qx = 0, qy = 0, qz = 0, d2 = 0;
-    if (j < n) {
-      qx = sp[3 * j]; qy = sp[3 * j + 1]; qz = sp[3 * j + 2];
-      d2 = sqdist3(px, py, pz, qx, qy, qz);
-      in = d2 < r2;
+  const LrfPre lp = pre[qi];
+  const int valid = lp.valid;
+  bool ok = valid >= 5;
+  if (!ok || lp.nn < 5) {
+    for (int c = lane; c < SHOT_LEN; c += 64) o[c] = NAN;
+    if (out_rf && lane < 9) out_rf[9 * (int64_t)qi + lane] = NAN;
+    if (!ok) return;
+    // LRF exists but too few points for the descriptor: frame is still reported
+  }
+  // neighbour list (positions in cell order), all points with d2 < r2 incl. self
+  Runs runs;
+  query_runs(h, cs, px, py, pz, runs);
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
+      const int j = jb + lane;
+      bool in = false;
+      if (j < runs.end[k]) in = sqdist3(px, py, pz, sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]) < r2;
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < SH_LCAP) s_list[pos] = j;
+      }
+      m += __popcll(mask);
     }
-    const unsigned long long mask = __ballot(in);
-    if (in) {
-      const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < SH_LCAP) s_list[pos] = j;
+  }
+  __syncthreads();
+  const bool listed = (m <= SH_LCAP);
+  // candidates of the later sweeps: the list, or (overflow) every point of the 9 runs again
+  double v1[3] = {lp.v1[0], lp.v1[1], lp.v1[2]}, v3[3] = {lp.v3[0], lp.v3[1], lp.v3[2]};
+  int plus1 = 0, plus3 = 0, c1 = 0, c3 = 0;
+  const int med = valid / 2;
+  // pass over neighbours: MODE 0 = sign counts, 1 = tie-break (median rule), 2 = histogram
+#define FOR_EACH_NEIGHBOUR(...)                                                             \
+  if (listed) {                                                                              \
+    for (int base = 0; base < m; base += 64) {                                               \
+      const int c = base + lane;                                                             \
+      const bool act = c < m;                                                                \
+      const int j = act ? s_list[c] : 0;                                                     \
+      __VA_ARGS__                                                                                 \
+    }                                                                                        \
+  } else {                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 9; ++k)                                            \
+      for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {                               \
+        const int j = min(jb + lane, runs.end[k] - 1);                                       \
+        const bool act = (jb + lane < runs.end[k]) &&                                        \
+                         (sqdist3(px, py, pz, sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]) < r2); \
+        __VA_ARGS__                                                                               \
+      }                                                                                      \
+  }
+
+  FOR_EACH_NEIGHBOUR({
+    bool p1 = false, p3 = false;
+    if (act) {
+      const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
       if (!(qx == px && qy == py && qz == pz)) {
         const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-        const double w = (double)radius - (double)__builtin_sqrtf(d2);
-        cov[0] += w * (x * x); cov[1] += w * (x * y); cov[2] += w * (x * z);
-        cov[3] += w * (y * y); cov[4] += w * (y * z); cov[5] += w * (z * z);
-        sum += w;
-        ++valid;
+        p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
+        p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
       }
     }
-    m += __popcll(mask);
-  }
-  nn = m;
-  const bool listed = (m <= SH_LCAP);
-  const int M = listed ? m : n;              // candidates of the later sweeps
-#pragma unroll
-  for (int c = 0; c < 6; ++c) cov[c] = wave_sum(cov[c]);
-  sum = wave_sum(sum);
-  valid = wave_sum_i(valid);
-  __syncthreads();
-
-  bool ok = valid >= 5;
-  float rf[9];
-  if (ok) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) cov[c] /= sum;
-    const Eig3 e = jacobi3(cov);
-    ok = isfinite(e.w[0]) && isfinite(e.w[1]) && isfinite(e.w[2]);
-    double v1[3] = {e.v[0][2], e.v[1][2], e.v[2][2]};
-    double v3[3] = {e.v[0][0], e.v[1][0], e.v[2][0]};
-    // sweep B: sign disambiguation
-    int plus1 = 0, plus3 = 0;
-    for (int base = 0; base < M; base += 64) {
-      const int c = base + lane;
-      bool p1 = false, p3 = false;
-      if (c < M) {
-        const int j = listed ? s_list[c] : c;
+    plus1 += __popcll(__ballot(p1));
+    plus3 += __popcll(__ballot(p3));
+  })
+  plus1 = 2 * plus1 - valid;
+  plus3 = 2 * plus3 - valid;
+  if (plus1 == 0 || plus3 == 0) {
+    // tie: the 5 neighbours around the median of the (distance, original index)-sorted valid list decide
+    FOR_EACH_NEIGHBOUR({
+      bool h1 = false, h3 = false;
+      if (act) {
         const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
-        const bool nb = (sqdist3(px, py, pz, qx, qy, qz) < r2) && !(qx == px && qy == py && qz == pz);
-        if (nb) {
-          const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-          p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
-          p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
-        }
-      }
-      plus1 += __popcll(__ballot(p1));
-      plus3 += __popcll(__ballot(p3));
-    }
-    plus1 = 2 * plus1 - valid;
-    plus3 = 2 * plus3 - valid;
-    if (plus1 == 0 || plus3 == 0) {
-      // tie: the 5 neighbours around the median of the (distance, index)-sorted valid list decide
-      const int med = valid / 2;
-      int c1 = 0, c3 = 0;
-      for (int base = 0; base < M; base += 64) {
-        const int c = base + lane;
-        bool h1 = false, h3 = false;
-        if (c < M) {
-          const int j = listed ? s_list[c] : c;
-          const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
+        if (!(qx == px && qy == py && qz == pz)) {
           const float d2 = sqdist3(px, py, pz, qx, qy, qz);
-          if ((d2 < r2) && !(qx == px && qy == py && qz == pz)) {
-            int rank = 0;
-            for (int c2 = 0; c2 < M; ++c2) {
-              const int j2 = listed ? s_list[c2] : c2;
+          const int oj = sid[j];
+          int rank = 0;
+          if (listed) {
+            for (int c2 = 0; c2 < m; ++c2) {
+              const int j2 = s_list[c2];
               const float ux = sp[3 * j2], uy = sp[3 * j2 + 1], uz = sp[3 * j2 + 2];
               const float e2 = sqdist3(px, py, pz, ux, uy, uz);
-              const bool nb2 = (e2 < r2) && !(ux == px && uy == py && uz == pz);
-              rank += (nb2 && (e2 < d2 || (e2 == d2 && j2 < j))) ? 1 : 0;
+              const bool nb2 = !(ux == px && uy == py && uz == pz);
+              rank += (nb2 && (e2 < d2 || (e2 == d2 && sid[j2] < oj))) ? 1 : 0;
             }
-            if (rank >= med - 2 && rank <= med + 2) {
-              const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-              h1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) > 0.0;
-              h3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) > 0.0;
-            }
+          } else {
+            for (int k2 = 0; k2 < 9; ++k2)
+              for (int j2 = runs.beg[k2]; j2 < runs.end[k2]; ++j2) {
+                const float ux = sp[3 * j2], uy = sp[3 * j2 + 1], uz = sp[3 * j2 + 2];
+                const float e2 = sqdist3(px, py, pz, ux, uy, uz);
+                const bool nb2 = (e2 < r2) && !(ux == px && uy == py && uz == pz);
+                rank += (nb2 && (e2 < d2 || (e2 == d2 && sid[j2] < oj))) ? 1 : 0;
+              }
+          }
+          if (rank >= med - 2 && rank <= med + 2) {
+            const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
+            h1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) > 0.0;
+            h3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) > 0.0;
           }
         }
-        c1 += __popcll(__ballot(h1));
-        c3 += __popcll(__ballot(h3));
       }
-      if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
-      if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
-    }
-    if (plus1 < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
-    if (plus3 < 0) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
-    rf[0] = (float)v1[0]; rf[1] = (float)v1[1]; rf[2] = (float)v1[2];
-    rf[6] = (float)v3[0]; rf[7] = (float)v3[1]; rf[8] = (float)v3[2];
-    rf[3] = rf[7] * rf[2] - rf[8] * rf[1];
-    rf[4] = rf[8] * rf[0] - rf[6] * rf[2];
-    rf[5] = rf[6] * rf[1] - rf[7] * rf[0];
+      c1 += __popcll(__ballot(h1));
+      c3 += __popcll(__ballot(h3));
+    })
+    if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
+    if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
   }
-  if (!ok) {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) rf[c] = NAN;
-  }
+  if (plus1 < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
+  if (plus3 < 0) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+  float rf[9];
+  rf[0] = (float)v1[0]; rf[1] = (float)v1[1]; rf[2] = (float)v1[2];
+  rf[6] = (float)v3[0]; rf[7] = (float)v3[1]; rf[8] = (float)v3[2];
+  rf[3] = rf[7] * rf[2] - rf[8] * rf[1];
+  rf[4] = rf[8] * rf[0] - rf[6] * rf[2];
+  rf[5] = rf[6] * rf[1] - rf[7] * rf[0];
   if (out_rf && lane < 9) {
-    // rf is wave-uniform; pick component `lane` without runtime-indexing the register array
     float v = rf[0];
 #pragma unroll
     for (int c = 1; c < 9; ++c) v = (lane == c) ? rf[c] : v;
     out_rf[9 * (int64_t)qi + lane] = v;
   }
-  if (!ok || nn < 5) {
-    for (int c = lane; c < SHOT_LEN; c += 64) o[c] = NAN;
-    return;
-  }
+  if (lp.nn < 5) return;
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) s_rf[c] = rf[c];
   }
   for (int c = lane; c < SHOT_LEN; c += 64) s_hist[c] = 0.0f;
   __syncthreads();
-  // sweep C: interpolated histogram (shot.hpp: interpolateSingleChannel)
-  for (int base = 0; base < M; base += 64) {
-    const int c = base + lane;
-    if (c < M) {
-      const int j = listed ? s_list[c] : c;
+  FOR_EACH_NEIGHBOUR({
+    if (act) {
       const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
       const float d2 = sqdist3(px, py, pz, qx, qy, qz);
-      if (d2 < r2) shot_accumulate(px, py, pz, qx, qy, qz, d2, sn[3 * j], sn[3 * j + 1], sn[3 * j + 2], s_rf, (double)radius, s_hist);
+      const int oj = sid[j];
+      shot_accumulate(px, py, pz, qx, qy, qz, d2, sn[3 * oj], sn[3 * oj + 1], sn[3 * oj + 2], s_rf, (double)radius, s_hist);
     }
-  }
+  })
+#undef FOR_EACH_NEIGHBOUR
   __syncthreads();
   double acc = 0.0;
   for (int c = lane; c < SHOT_LEN; c += 64) acc += (double)s_hist[c] * (double)s_hist[c];
@@ -387,17 +612,66 @@ __global__ __launch_bounds__(64) void shot_kernel(int B, const float* __restrict
   for (int c = lane; c < SHOT_LEN; c += 64) o[c] = s_hist[c] / facc;
 }
 
-extern "C" int64_t cppf_shot352_workspace_bytes(int64_t total_points) { return total_points > 0 ? 256 : 0; }
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
+
+struct ShotWs {
+  CellHdr* hdr; int32_t* cell_start; int32_t* sorted_idx; float* sorted_pts; double* sums; LrfPre* pre;
+};
+
+static ShotWs carve(void* ws, int B, int64_t n) {
+  char* p = (char*)ws;
+  ShotWs w;
+  w.hdr = (CellHdr*)p; p += up256((int64_t)B * sizeof(CellHdr));
+  w.cell_start = (int32_t*)p; p += up256((int64_t)B * (CELL_CAP + 1) * 4);
+  w.sorted_idx = (int32_t*)p; p += up256(n * 4);
+  w.sorted_pts = (float*)p; p += up256(n * 12);
+  w.sums = (double*)p; p += up256(n * NSUM * 8);
+  w.pre = (LrfPre*)p;
+  return w;
+}
+
+extern "C" int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points) {
+  if (B <= 0 || total_points <= 0) return 0;
+  return up256((int64_t)B * sizeof(CellHdr)) + up256((int64_t)B * (CELL_CAP + 1) * 4) + up256(total_points * 4) +
+         up256(total_points * 12) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre));
+}
+
+static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, float normal_r, float shot_r,
+                    const float* normals_in, float* out_normal, float* out_shot, float* out_rf, void* workspace,
+                    int64_t workspace_bytes, hipStream_t st) {
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, n));
+  const ShotWs w = carve(workspace, B, n);
+  const bool want_n = out_normal != nullptr, want_s = out_shot != nullptr;
+  const float rn = want_n ? normal_r : 0.0f, rs = want_s ? shot_r : 0.0f;
+  hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(rn, rs), w.hdr, w.cell_start,
+                     w.sorted_idx, w.sorted_pts);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+                     w.sorted_pts, rn, rs, w.sums);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums,
+                     out_normal, want_s ? w.pre : (LrfPre*)nullptr);
+  CPPF_LAUNCH_CHECK();
+  if (want_s) {
+    hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+                       w.sorted_idx, w.sorted_pts, normals_in ? normals_in : out_normal, w.pre, shot_r, out_shot,
+                       out_rf);
+    CPPF_LAUNCH_CHECK();
+  }
+  return CPPF_OK;
+}
 
 extern "C" int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
-                                     float normal_r, float* out_normal, void* stream) {
+                                     float normal_r, float* out_normal, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_normal && normal_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
-  hipLaunchKernelGGL(normals_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     normal_r, out_normal);
-  CPPF_LAUNCH_CHECK();
-  return CPPF_OK;
+  return shot_run(B, pts, pt_off, total_points, normal_r, 0.0f, nullptr, out_normal, nullptr, nullptr, workspace,
+                  workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
@@ -405,25 +679,17 @@ extern "C" int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int6
                             int64_t workspace_bytes, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_shot && out_normal && normal_r > 0.0f && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
-  (void)workspace; (void)workspace_bytes;
   if (total_points <= 0) return CPPF_OK;
-  hipLaunchKernelGGL(normals_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     normal_r, out_normal);
-  CPPF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shot_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     out_normal, shot_r, out_shot, out_rf);
-  CPPF_LAUNCH_CHECK();
-  return CPPF_OK;
+  return shot_run(B, pts, pt_off, total_points, normal_r, shot_r, nullptr, out_normal, out_shot, out_rf, workspace,
+                  workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
                                          const float* normals, float shot_r, float* out_shot, float* out_rf,
-                                         void* stream) {
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && normals && out_shot && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
-  hipLaunchKernelGGL(shot_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     normals, shot_r, out_shot, out_rf);
-  CPPF_LAUNCH_CHECK();
-  return CPPF_OK;
+  return shot_run(B, pts, pt_off, total_points, 0.0f, shot_r, normals, nullptr, out_shot, out_rf, workspace,
+                  workspace_bytes, (hipStream_t)stream);
 }

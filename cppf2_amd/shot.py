@@ -19,6 +19,18 @@ from . import _lib, ops
 
 _L = _lib.load()
 
+_WS = {}
+
+
+def _workspace(B, n, dev):
+    """One cached scratch buffer per (device): grown on demand, reused by every call on that device."""
+    need = _L.cppf_shot352_workspace_bytes(B, n)
+    ws = _WS.get(str(dev))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _WS[str(dev)] = ws
+    return ws
+
 
 def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
     """Batched device API: pts float32 [Ntot,3] (device), pt_off int32 [B+1] (device).
@@ -29,9 +41,10 @@ def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
     out_shot = torch.empty((n, 352), dtype=torch.float32, device=dev)
     out_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
     out_rf = torch.empty((n, 9), dtype=torch.float32, device=dev) if want_rf else None
+    ws = _workspace(B, n, dev)
     _lib.check(_L.cppf_shot352(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
-                               ops._p(out_shot), ops._p(out_normal), ops._p(out_rf), None, 0, ops._stream()),
-               "cppf_shot352")
+                               ops._p(out_shot), ops._p(out_normal), ops._p(out_rf), ops._p(ws), ws.numel(),
+                               ops._stream()), "cppf_shot352")
     if want_rf:
         return out_shot, out_normal, out_rf
     return out_shot, out_normal
@@ -40,17 +53,19 @@ def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
 def normals_device(pts, pt_off, normal_r, out=None):
     n = pts.shape[0]
     out = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out is None else out
+    ws = _workspace(pt_off.numel() - 1, n, pts.device)
     _lib.check(_L.cppf_estimate_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r),
-                                        ops._p(out), ops._stream()), "cppf_estimate_normals")
+                                        ops._p(out), ops._p(ws), ws.numel(), ops._stream()), "cppf_estimate_normals")
     return out
 
 
 def descriptors_device(pts, pt_off, normals, shot_r, out=None):
     n = pts.shape[0]
     out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
+    ws = _workspace(pt_off.numel() - 1, n, pts.device)
     _lib.check(_L.cppf_shot352_from_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, ops._p(normals),
-                                            C.c_float(shot_r), ops._p(out), None, ops._stream()),
-               "cppf_shot352_from_normals")
+                                            C.c_float(shot_r), ops._p(out), None, ops._p(ws), ws.numel(),
+                                            ops._stream()), "cppf_shot352_from_normals")
     return out
 
 
@@ -68,7 +83,4 @@ def estimate_normal(pc, normal_r):
     dev = ops._dev()
     pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
     pt_off = ops._offsets([pts.shape[0]], dev)
-    out = torch.empty((pts.shape[0], 3), dtype=torch.float32, device=dev)
-    _lib.check(_L.cppf_estimate_normals(1, ops._p(pts), ops._p(pt_off), pts.shape[0], C.c_float(normal_r), ops._p(out),
-                                        ops._stream()), "cppf_estimate_normals")
-    return out.reshape(-1).cpu().numpy()
+    return normals_device(pts, pt_off, float(normal_r)).reshape(-1).cpu().numpy()

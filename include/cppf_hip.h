@@ -83,17 +83,18 @@ int cppf_philox_uniform(int B, const int32_t* tup_off, int max_t, int m, uint64_
 /* ---- a2. SHOT352 + normals: replaces shot.compute(pc, normal_r, shot_r) (src_shot/shot.cpp:45-100,
  * PCL 1.9.1 NormalEstimation + SHOTEstimation).  out_shot: float32[n,352], out_normal: float32[n,3];
  * rows PCL would leave NaN are written as NaN (callers zero them, eval.py:215-216).
- * workspace: cppf_shot352_workspace_bytes(total_points) bytes. */
-int64_t cppf_shot352_workspace_bytes(int64_t total_points);
+ * workspace: cppf_shot352_workspace_bytes(B, total_points) bytes. */
+int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points);
 int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r, float shot_r,
                  float* out_shot, float* out_normal, float* out_rf /* optional float32[n,9] local frames */,
                  void* workspace, int64_t workspace_bytes, void* stream);
 /* The descriptor half alone, on normals the caller already has (e.g. from cppf_estimate_normals). */
 int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
-                              const float* normals, float shot_r, float* out_shot, float* out_rf, void* stream);
-/* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42). */
+                              const float* normals, float shot_r, float* out_shot, float* out_rf,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+/* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
-                          float* out_normal, void* stream);
+                          float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- a3. tuple encode: replaces BeyondCPPF.prepare_tuple_inputs.
  * SHOT model (train_shot.py:75-83): row = [p_i-p_j for i<j (C(k,2)*3) | max(n_i.n_j, -n_i.n_j) (C(k,2)) |
