@@ -58,7 +58,7 @@ def parse():
 class Step:
     """Holds the resident inputs and runs one pass of the path."""
 
-    STAGES = ["sample_tuples", "normals", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
+    STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
               "decode_bins", "vote_center", "backvote_filter", "rot_bins", "assemble_pose", "gather"]
 
     def __init__(self, args, rank, world, dev):
@@ -105,9 +105,9 @@ class Step:
         self._mark("start")
         idx = ops.sample_tuples(N, T, 5, a.seed, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         self._mark("sample_tuples")
-        shotmod.normals_device(self.pts, pipe.pt_off, Cfg.res * 10, out=self.normal)       # eval.py:210
-        self._mark("normals")
-        shotmod.descriptors_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot)
+        shotmod.prepare_device(self.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, self.normal)   # eval.py:210
+        self._mark("shot_frames")
+        shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot)
         self._mark("shot352")
         shot = torch.nan_to_num_(self.shot, nan=0.0)                                       # eval.py:215-216
         normal = torch.nan_to_num_(self.normal, nan=0.0)
@@ -141,8 +141,8 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
     """Compulsory bytes one launch of the stage's kernel moves for B scenes (SURVEY.md 8d per-scene figures)."""
     per_scene = {
         "sample_tuples": T * 5 * 4,
-        "normals": N * 12 + N * 12,
-        "shot352": N * 12 + N * 12 + N * 352 * 4,
+        "shot_frames": N * 12 * 2 + N * 12 + N * 19 * 8 * 2 + N * 56,   # points in+sorted, normals out, sums w+r, frames
+        "shot352": N * 12 + N * 12 + N * 56 + N * 352 * 4,
         "encode_tuples": T * 5 * 4 + N * 12 + N * 12 + N * 64 * 4 + T * 360 * 4,
         "decode_bins": T * 6 * 32 * 4 + T * 6 * 4 + T * 8 + T * (8 + 12 + 24 + 4 + 24),
         "vote_center": T * 8 + T * 8 + N * 12 + 0 * G,       # grid stays on-chip (LDS slabs); only the peak leaves

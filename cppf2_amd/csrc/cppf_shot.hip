@@ -693,3 +693,42 @@ extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t*
   return shot_run(B, pts, pt_off, total_points, 0.0f, shot_r, normals, nullptr, out_shot, out_rf, workspace,
                   workspace_bytes, (hipStream_t)stream);
 }
+
+// Two-call form of cppf_shot352 sharing one workspace: prepare = cells + covariances + eigen-solves (normals out,
+// local-frame axes kept in the workspace), describe = histogram kernel only.  describe must follow a prepare on
+// the same inputs, same stream, same workspace.
+extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
+                                 float shot_r, float* out_normal, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_normal && normal_r > 0.0f && shot_r > 0.0f);
+  CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
+  if (total_points <= 0) return CPPF_OK;
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, total_points));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = total_points;
+  const ShotWs w = carve(workspace, B, n);
+  hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(normal_r, shot_r), w.hdr,
+                     w.cell_start, w.sorted_idx, w.sorted_pts);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+                     w.sorted_pts, normal_r, shot_r, w.sums);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
+                     w.pre);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
+                                  const float* normals, float shot_r, float* out_shot, float* out_rf, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && normals && out_shot && shot_r > 0.0f);
+  CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
+  if (total_points <= 0) return CPPF_OK;
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, total_points));
+  const ShotWs w = carve(workspace, B, total_points);
+  hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
+                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, normals, w.pre, shot_r, out_shot, out_rf);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

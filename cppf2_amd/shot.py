@@ -69,6 +69,28 @@ def descriptors_device(pts, pt_off, normals, shot_r, out=None):
     return out
 
 
+def prepare_device(pts, pt_off, normal_r, shot_r, out_normal=None):
+    """First half of compute_device (cell sort, covariances, eigen-solves): returns the normals."""
+    n = pts.shape[0]
+    B = pt_off.numel() - 1
+    out_normal = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out_normal is None else out_normal
+    ws = _workspace(B, n, pts.device)
+    _lib.check(_L.cppf_shot_prepare(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
+                                    ops._p(out_normal), ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_prepare")
+    return out_normal
+
+
+def describe_device(pts, pt_off, normals, shot_r, out=None):
+    """Second half of compute_device (histogram kernel); must directly follow prepare_device on the same inputs."""
+    n = pts.shape[0]
+    B = pt_off.numel() - 1
+    out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
+    ws = _workspace(B, n, pts.device)
+    _lib.check(_L.cppf_shot_describe(B, ops._p(pts), ops._p(pt_off), n, ops._p(normals), C.c_float(shot_r),
+                                     ops._p(out), None, ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_describe")
+    return out
+
+
 def compute(pc, normal_r=0.1, shot_r=0.17):
     """shot.compute (src_shot/shot.cpp:45-100): returns [float32[N*352], float32[N*3]]."""
     dev = ops._dev()

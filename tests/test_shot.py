@@ -91,6 +91,11 @@ def test_hip_shot_vs_oracle():
         ok = ~np.isnan(os_).any(1)
         assert np.abs(hs[o:o + n][ok] - os_[ok]).max() < 2e-5
         o += n
+    # two-call form == one-call form (same kernels, same workspace)
+    n2 = shot.prepare_device(pts, pt_off, 0.02, 0.02)
+    s2 = shot.describe_device(pts, pt_off, n2, 0.02)
+    assert np.array_equal(n2.cpu().numpy(), hn, equal_nan=True)
+    assert np.allclose(s2.cpu().numpy(), hs, atol=1e-6, equal_nan=True)
     # drop-in module call convention (src_shot/shot.cpp:45): list of two flat float32 arrays
     r = shot.compute(scs[1]["pc"].astype(np.float64), 0.02, 0.02)
     assert isinstance(r, list) and r[0].shape == (777 * 352,) and r[1].shape == (777 * 3,) and r[0].dtype == np.float32
