@@ -153,6 +153,27 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
     return per_scene.get(stage, 0) * B
 
 
+STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_cov_kernel", "shot352": "shot_hist_kernel",
+                "encode_tuples": "encode_shot_kernel", "decode_bins": "decode_bins_kernel<32>",
+                "vote_center": "vote_center_slab_kernel<true>", "backvote_filter": "backvote_kernel",
+                "rot_bins": "rot_bins_window_kernel", "assemble_pose": "assemble_pose_kernel"}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r1_pmc_traffic.json, produced by scratch/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
+    KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f).get(STAGE_KERNEL.get(stage, ""), None)
+        if not d:
+            return None
+        return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, step):
     """Times the oracle (NumPy + C SHOT) on the host for a bounded sample of the same workload."""
     from oracle import pipeline_oracle as PO
@@ -235,7 +256,8 @@ def main():
         dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G)
         achieved = (dom_bytes / 1e9) / (dom_ms / 1e3)
         roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=dom_ms,
+                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms,
+                        kernel_name=STAGE_KERNEL.get(dominant),
                         algorithmic_bytes_per_launch=dom_bytes,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
