@@ -270,7 +270,7 @@ def main():
                 ok += 1
         cpu = None
         agree = None
-        if args.cpu_scenes > 0:
+        if args.cpu_scenes > 0 and world == 1:     # CPU baseline: rank 0 at N=1 only
             cpu, outs = cpu_baseline(args, step)
             agree = dict(scenes=len(outs),
                          centre_argmax_equal=int(sum(int(res["argmax"][b]) == o["argmax"] for b, o in enumerate(outs))),
