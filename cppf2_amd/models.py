@@ -41,16 +41,27 @@ def fused_stack(seq, x):
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
       out = x W0^T + (b0 + b2)           one GEMM, bias epilogue          (layers with a projection skip)
       out += h W2^T                      one GEMM, beta = 1, in place
-    Identity-skip layers accumulate h W2^T into x in place and add b2 with one broadcast pass.
-    `x` may be overwritten."""
+    Identity-skip layers accumulate h W2^T into x in place; their output bias b2 is not added to the activation
+    but carried as a pending per-channel offset c (true activation = x + c) and folded into the biases of the
+    next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
+    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`."""
+    c = None
     for layer in seq:
         w1, b1, w2, b2 = layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias
+        if c is not None:
+            b1 = torch.addmv(b1, w1, c)
         h = torch._addmm_activation(b1, x, w1.t())
         if layer.fc0 is not None:
-            out = torch.addmm(layer.fc0.bias + b2, x, layer.fc0.weight.t())
+            b0 = layer.fc0.bias + b2
+            if c is not None:
+                b0 = torch.addmv(b0, layer.fc0.weight, c)
+            x = torch.addmm(b0, x, layer.fc0.weight.t())
+            c = None
         else:
-            out = x.add_(b2)
-        x = out.addmm_(h, w2.t())
+            c = b2 if c is None else c + b2
+        x = x.addmm_(h, w2.t())
+    if c is not None:
+        x = x.add_(c)
     return x
 
 
@@ -99,8 +110,8 @@ class BeyondCPPFShot(nn.Module):
     def heads(self, inputs):
         if not torch.is_grad_enabled() and inputs.is_cuda:
             feat = fused_stack(self.tuple_encoder, inputs)
-            preds_scale = fused_stack(self.scale_encoder, feat.clone())
-            preds_cls = fused_stack(self.logit_encoder, feat)
+            preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
+            preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
             return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
         feat = self.tuple_encoder(inputs)
         preds_scale = self.scale_encoder(feat)
