@@ -272,7 +272,16 @@ def main():
         agree = None
         if args.cpu_scenes > 0 and world == 1:     # CPU baseline: rank 0 at N=1 only
             cpu, outs = cpu_baseline(args, step)
-            agree = dict(scenes=len(outs),
+            from cppf2_amd.metrics import rt_degree_cm
+
+            def rt(R, t):
+                m = np.eye(4)
+                m[:3, :3], m[:3, 3] = R, t
+                return m
+            errs = [rt_degree_cm(rt(res["R"][b], res["t"][b]), rt(o["R_est"], o["T_est"]), "bottle")
+                    for b, o in enumerate(outs)]
+            agree = dict(scenes=len(outs), match_5deg5cm=float(np.mean([e[0] <= 5 and e[1] <= 5 for e in errs])),
+                         max_rot_err_deg=float(max(e[0] for e in errs)), max_shift_cm=float(max(e[1] for e in errs)),
                          centre_argmax_equal=int(sum(int(res["argmax"][b]) == o["argmax"] for b, o in enumerate(outs))),
                          up_bin_equal=int(sum(int(res["up_idx"][b]) == o["up_idx"] for b, o in enumerate(outs))),
                          right_bin_equal=int(sum(int(res["right_idx"][b]) == o["right_idx"] for b, o in enumerate(outs))))

@@ -28,9 +28,16 @@
 // the slab kernel with the exhaustive rotation sweep and exact divisions.
 // =============================================================================================
 #define VC_THREADS 1024
+#ifndef VC_SLAB_CELLS
 #define VC_SLAB_CELLS 36864            // 144 KiB of uint32 counters
+#endif
 #define VC_ARG_BLOCKS 32
+#ifndef VC_MAX_LDS_ROTS
 #define VC_MAX_LDS_ROTS 1024
+#endif
+#ifndef VC_MIN_WAVES
+#define VC_MIN_WAVES 4
+#endif
 #define VC_FRAME_FLOATS 11             // cx cy cz xx xy xz yx yy yz invA phi
 #ifndef VC_QUANTUM
 #define VC_QUANTUM 4
@@ -195,7 +202,7 @@ __device__ __forceinline__ float bcast_f(float x, int src) {
 }
 
 template <bool ARCS>
-__global__ __launch_bounds__(VC_THREADS) void vote_center_slab_kernel(
+__global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_kernel(
     const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,

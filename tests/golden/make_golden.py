@@ -190,6 +190,29 @@ def main():
 
     np.savez_compressed(os.path.join(HERE, "small.npz"), **g)
 
+    # ---- 5 deg / 5 cm criterion (utils/util.py:588-663) on seeded similarity transforms -------
+    mr = np.random.RandomState(3)
+
+    def rand_rt():
+        q, _ = np.linalg.qr(mr.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        RT = np.eye(4)
+        RT[:3, :3] = q * mr.uniform(0.5, 2)
+        RT[:3, 3] = mr.randn(3) * 0.1
+        return RT
+    A = np.stack([rand_rt() for _ in range(12)])
+    Bm = np.stack([rand_rt() for _ in range(12)])
+    Bm[:4] = A[:4]
+    Bm[:4, :3, 3] += 0.01
+    names = ["BG", "bottle", "bowl", "camera", "can", "laptop", "mug"]
+    table = []
+    for i in range(12):
+        cid = 1 + i % 6
+        for hv in (0, 1):
+            table.append((i, cid, hv, *ref.util.compute_RT_degree_cm_symmetry(A[i], Bm[i], cid, hv, names)))
+    np.savez(os.path.join(HERE, "metric_5deg5cm.npz"), A=A, B=Bm, table=np.array(table))
+
     # ---- example_data plumbing (config 1): backproject stats, utils/util.py:2586-2607 ------
     summ = {}
     try:

@@ -86,3 +86,12 @@ def test_synthetic_scene_invariants():
     from oracle import cppf_oracle as O
     assert np.array_equal(idx, O.sample_tuples(3, 5, 100, 5, 512))
     assert np.array_equal(synth.uniforms(3, 5, 1, 50, 6).astype(np.float32), O.philox_uniform(3, 5, 1, 50, 6))
+
+
+def test_5deg5cm_criterion_golden():
+    """cppf2_amd.metrics.rt_degree_cm against utils/util.py:588-663 run on seeded poses (tests/golden/metric_5deg5cm.npz)."""
+    from cppf2_amd.metrics import SYNSET_NAMES, rt_degree_cm
+    g = np.load(os.path.join(GOLDEN, "metric_5deg5cm.npz"))
+    for i, cid, hv, theta, shift in g["table"]:
+        got = rt_degree_cm(g["A"][int(i)], g["B"][int(i)], SYNSET_NAMES[int(cid)], int(hv))
+        assert np.isclose(got[0], theta, atol=1e-9) and np.isclose(got[1], shift, atol=1e-12)
