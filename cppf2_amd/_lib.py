@@ -63,7 +63,7 @@ SIGNATURES = {
     "cppf_backvote_filter": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _p, _p,
                                   _p, _i64, _p]),
     "cppf_rot_bins_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
-    "cppf_rot_bins": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _i,
+    "cppf_rot_bins": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
                            _p, _p, _p, _p, _i64, _p]),
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),

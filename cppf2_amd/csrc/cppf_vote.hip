@@ -877,73 +877,167 @@ __global__ __launch_bounds__(RB_THREADS) void rot_bins_dense_kernel(
   }
 }
 
-// Windowed kernel for fibonacci_sphere bins (utils/util.py:191-207): bin i sits at y_i = 1 - 2 i/(S-1), so a
-// candidate with |angle| <= cone to bin i satisfies |y - y_i| <= 2 sin(cone/2) <= cone; only the bins whose
-// index is within `win` of (1-y)(S-1)/2 can pass the cosine test.  One thread per candidate, hits (about
-// 0.2 per candidate) go to LDS float64 accumulators.
+// Lookup-table kernel.  The caller tabulates, for every cell of an (equal-area rows in y) x (azimuth) partition of
+// the sphere, the bins whose cone can contain a direction of that cell (cppf2_amd.ops.build_bin_lut: bins within
+// cone + cell circumradius of the cell centre; <= RL_K per cell, 0.46 on average for the 720 fibonacci bins).
+// One thread per candidate axis: cell of the candidate -> one 16-byte table row -> exact cosine test of those few
+// bins only.  Works for any bin set; counts are identical to the dense kernel's (tests compare them).
+// Hits go to LDS float64 accumulators; each workgroup's two per-chunk partial sums leave with plain coalesced
+// stores and are folded in a fixed order by rot_bins_fold_kernel (no global atomics, run-to-run reproducible).
 #define RW_THREADS 256
-__global__ __launch_bounds__(RW_THREADS) void rot_bins_window_kernel(
+#define RW_PPB 32          // pairs per workgroup
+#define RL_K 8             // table slots per cell (int16 bin ids, -1 = empty)
+struct RwFrame {
+  float xx, xy, xz, yx, yy, yz, sux, suy, suz, tn;   // in-plane axes, sign(tan)*u, tan
+  int row0;
+  double inv_wt;
+};
+
+__global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
     const int32_t* __restrict__ tup_off, const float* __restrict__ rot, int rot_col,
     const int32_t* __restrict__ kept_tuple, const int32_t* __restrict__ kept_count,
     const double* __restrict__ kept_wt, const int32_t* __restrict__ kept_row0, int pairs_per_block, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const float* __restrict__ sphere, int S,
-    float cos_thr, int win, int bmm_size, int max_chunks, double* __restrict__ sums) {
+    float cos_thr, const int4* __restrict__ lut, int lut_rows, int lut_cols, int bmm_size,
+    double* __restrict__ partial /* [B][nblk][2][S] */, int32_t* __restrict__ block_chunk /* [B][nblk] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_sph = (float*)smem;                       // [S][3]
-  double* s_acc = (double*)(smem + ((size_t)S * 12 + 15) / 16 * 16);   // [2][S]
+  float4* s_sph = (float4*)smem;                                     // [S] (x, y, z, -)
+  double* s_acc = (double*)(smem + (size_t)S * 16);                  // [2][S]
+  __shared__ RwFrame s_fr[RW_PPB];
   __shared__ int s_cb;
   const int b = blockIdx.y;
   const int kept = kept_count[b];
   const int j0 = blockIdx.x * pairs_per_block;
-  if (j0 >= kept) return;
+  const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
+  if (j0 >= kept) {
+    if (threadIdx.x == 0) block_chunk[blk] = -1;
+    return;
+  }
   const int npairs = min(pairs_per_block, kept - j0);
   const int ncand = npairs * num_rots;
   const int t0 = tup_off[b];
   const float* p = pts + 3 * (int64_t)pt_off[b];
-  for (int i = threadIdx.x; i < 3 * S; i += RW_THREADS) s_sph[i] = sphere[i];
+  for (int i = threadIdx.x; i < S; i += RW_THREADS)
+    s_sph[i] = make_float4(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2], 0.0f);
   for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) s_acc[i] = 0.0;
-  if (threadIdx.x == 0) {
-    // chunk of the first valid pair of the block (rows increase with j)
-    int cb = 0x7fffffff;
-    for (int pj = 0; pj < npairs; ++pj) {
-      const int row0 = kept_row0[t0 + j0 + pj];
-      if (row0 >= 0) { cb = row0 / bmm_size; break; }
+  if (threadIdx.x == 0) s_cb = 0x7fffffff;
+  __syncthreads();
+  // phase 1: one thread per pair -- frame of the pair (train_dino.py:219-232), tan of its angle, weight
+  if (threadIdx.x < npairs) {
+    const int j = j0 + threadIdx.x;
+    RwFrame fr;
+    fr.row0 = kept_row0[t0 + j];
+    fr.inv_wt = 0.0;
+    fr.xx = fr.xy = fr.xz = fr.yx = fr.yy = fr.yz = fr.sux = fr.suy = fr.suz = fr.tn = 0.0f;
+    if (fr.row0 >= 0) {
+      const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+      const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
+      const float den = fmaxf(f.nco, 1e-7f);
+      fr.xx = f.cox / den; fr.xy = f.coy / den; fr.xz = f.coz / den;
+      fr.yx = cross_term(fr.xy, f.uz, fr.xz, f.uy);
+      fr.yy = cross_term(fr.xz, f.ux, fr.xx, f.uz);
+      fr.yz = cross_term(fr.xx, f.uy, fr.xy, f.ux);
+      fr.tn = tanf(rot[row * 3 + rot_col]);
+      const float sg = (fr.tn > 0.0f) ? 1.0f : -1.0f;
+      fr.sux = sg * f.ux; fr.suy = sg * f.uy; fr.suz = sg * f.uz;
+      fr.inv_wt = 1.0 / kept_wt[t0 + j];
+      atomicMin(&s_cb, fr.row0 / bmm_size);          // chunk of the block's first row
     }
-    s_cb = cb;
+    s_fr[threadIdx.x] = fr;
   }
   __syncthreads();
   const int cb = s_cb;
-  if (cb == 0x7fffffff) return;
-  const float half = 0.5f * (float)(S - 1);
+  if (cb == 0x7fffffff) {
+    if (threadIdx.x == 0) block_chunk[blk] = -1;
+    return;
+  }
+  const float row_scale = 0.5f * (float)lut_rows, col_scale = (float)lut_cols * 0.15915494309189535f;
+  // phase 2: one thread per candidate axis (train_dino.py:233-237)
   for (int c = threadIdx.x; c < ncand; c += RW_THREADS) {
     const int pj = c / num_rots, r = c - pj * num_rots;
-    const int j = j0 + pj;
-    const int row0 = kept_row0[t0 + j];
-    if (row0 < 0) continue;
-    const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
-    const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
-    const float tn = tanf(rot[row * 3 + rot_col]);
-    float x, y, z;
-    rot_candidate(f, tn, cos_tab[r], sin_tab[r], x, y, z);
-    if (!(y == y)) continue;                                           // NaN candidate never passes the test
-    const int slot = (row0 + r) / bmm_size - cb;
-    const double inv_wt = 1.0 / kept_wt[t0 + j];
-    const int ic = (int)((1.0f - y) * half + 0.5f);
-    const int lo = max(0, ic - win), hi = min(S - 1, ic + win);
-    for (int s = lo; s <= hi; ++s) {
-      const float d = fmaf(z, s_sph[3 * s + 2], fmaf(y, s_sph[3 * s + 1], x * s_sph[3 * s]));
-      if (d > cos_thr) atomicAdd(&s_acc[slot * S + s], inv_wt);
+    const RwFrame fr = s_fr[pj];
+    if (fr.row0 < 0) continue;
+    const float cs = cos_tab[r], sn = sin_tab[r];
+    const float offx = cs * fr.xx + sn * fr.yx, offy = cs * fr.xy + sn * fr.yy, offz = cs * fr.xz + sn * fr.yz;
+    const float ux = fr.tn * offx + fr.sux, uy = fr.tn * offy + fr.suy, uz = fr.tn * offz + fr.suz;
+    const float nn = fmaxf(norm3_fused(ux, uy, uz), 1e-7f);
+    const float x = ux / nn, y = uy / nn, z = uz / nn;
+    if (!(y == y) || !(x == x) || !(z == z)) continue;                 // NaN candidate never passes the test
+    const int slot = (fr.row0 + r) / bmm_size - cb;
+    float phi = atan2f(z, x);
+    phi += (phi < 0.0f) ? 6.2831853071795865f : 0.0f;
+    int ci = (int)((1.0f - y) * row_scale), cj = (int)(phi * col_scale);
+    ci = min(max(ci, 0), lut_rows - 1);
+    cj = min(max(cj, 0), lut_cols - 1);
+    const int4 e = lut[ci * lut_cols + cj];
+    const int ids[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+      for (int lo16 = 0; lo16 < 2; ++lo16) {
+        const int s = lo16 ? (ids[h] >> 16) : (int)(short)(ids[h] & 0xffff);
+        if (s >= 0) {
+          const float4 q = s_sph[s];
+          const float d = fmaf(z, q.z, fmaf(y, q.y, x * q.x));
+          if (d > cos_thr) atomicAdd(&s_acc[slot * S + s], fr.inv_wt);
+        }
+      }
     }
   }
   __syncthreads();
-  double* out = sums + ((int64_t)b * max_chunks) * S;
-  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) {
-    const double v = s_acc[i];
-    if (v != 0.0) {
-      const int slot = i / S, s = i - slot * S;
-      atomicAdd(&out[(int64_t)(cb + slot) * S + s], v);
+  double* out = partial + blk * 2 * S;
+  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) out[i] = s_acc[i];
+  if (threadIdx.x == 0) block_chunk[blk] = cb;
+}
+
+// per-chunk float64 sum = sum over the workgroups that touched the chunk, in workgroup order (their chunk ids are
+// non-decreasing), folded into float32 counts chunk by chunk (eval.py:45), then first maximum
+__global__ __launch_bounds__(1024) void rot_bins_fold_kernel(const double* __restrict__ partial,
+                                                             const int32_t* __restrict__ block_chunk, int nblk, int S,
+                                                             float* __restrict__ counts, int32_t* __restrict__ top_idx,
+                                                             float* __restrict__ top_count) {
+  const int b = blockIdx.x;
+  const double* part = partial + (int64_t)b * nblk * 2 * S;
+  const int32_t* bc = block_chunk + (int64_t)b * nblk;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    float c = 0.0f;
+    double a_cur = 0.0, a_next = 0.0;
+    int cur = -1;
+    for (int i = 0; i < nblk; ++i) {
+      const int cb = bc[i];                       // wave-uniform
+      if (cb < 0) continue;
+      const double v0 = part[((int64_t)i * 2 + 0) * S + s], v1 = part[((int64_t)i * 2 + 1) * S + s];
+      if (cur < 0) cur = cb;
+      while (cur < cb) {                           // close chunk `cur`: one float32 rounding per chunk
+        c = (float)((double)c + a_cur);
+        a_cur = a_next; a_next = 0.0; ++cur;
+      }
+      a_cur += v0; a_next += v1;
     }
+    c = (float)((double)c + a_cur);
+    c = (float)((double)c + a_next);
+    counts[(int64_t)b * S + s] = c;
+    if (c > best || (c == best && s < besti)) { best = c; besti = s; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(besti, off);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  __shared__ float s_b[16];
+  __shared__ int s_i[16];
+  if (wave_lane() == 0) { s_b[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (s_b[w] > best || (s_b[w] == best && s_i[w] < besti)) { best = s_b[w]; besti = s_i[w]; }
+    if (besti == 0x7fffffff) besti = 0;
+    if (top_idx) top_idx[b] = besti;
+    if (top_count) top_count[b] = best;
   }
 }
 
@@ -985,52 +1079,64 @@ static inline int rb_max_chunks(int max_kept, int num_rots, int bmm_size) {
   return (int)((rows + bmm_size - 1) / bmm_size) + 1;
 }
 
+static inline int rw_ppb(int num_rots, int bmm_size) {
+  int ppb = RW_PPB;
+  if ((int64_t)ppb * num_rots > bmm_size) ppb = bmm_size / num_rots;
+  return ppb < 1 ? 1 : ppb;
+}
+
 extern "C" int64_t cppf_rot_bins_workspace_bytes(int B, int S, int max_kept, int num_rots, int bmm_size) {
   if (B <= 0 || S <= 0 || max_kept < 0 || num_rots <= 0 || bmm_size <= 0) return 0;
-  return align_up((int64_t)B * rb_max_chunks(max_kept, num_rots, bmm_size) * S * 8, 256);
+  const int64_t dense = align_up((int64_t)B * rb_max_chunks(max_kept, num_rots, bmm_size) * S * 8, 256);
+  const int64_t nblk = (max_kept + rw_ppb(num_rots, bmm_size) - 1) / rw_ppb(num_rots, bmm_size) + 1;
+  const int64_t window = align_up((int64_t)B * nblk * 2 * S * 8, 256) + align_up((int64_t)B * nblk * 4, 256);
+  return dense > window ? dense : window;
 }
 
 extern "C" int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
                              const int32_t* tup_off, const float* rot, int rot_col, const int32_t* kept_tuple,
                              const int32_t* kept_count, const double* kept_wt, const int32_t* kept_row0, int max_kept,
                              int num_rots, const float* cos_tab, const float* sin_tab, const float* sphere, int S,
-                             float cos_thr, int bmm_size, int fibonacci, float* counts, int32_t* top_idx,
-                             float* top_count, void* workspace, int64_t workspace_bytes, void* stream) {
+                             float cos_thr, int bmm_size, const int16_t* bin_lut, int lut_rows, int lut_cols,
+                             float* counts, int32_t* top_idx, float* top_count, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && rot && kept_tuple && kept_count && kept_wt && kept_row0);
   CPPF_CHECK_ARG(cos_tab && sin_tab && sphere && counts);
   CPPF_CHECK_ARG(rot_col >= 0 && rot_col < 3 && S > 0 && num_rots > 0 && num_rots <= RB_MAX_CAND && bmm_size > 0);
+  CPPF_CHECK_ARG(bin_lut == nullptr || (lut_rows > 0 && lut_cols > 0 && S <= 32767));
   CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size));
   hipStream_t st = (hipStream_t)stream;
   const int max_chunks = rb_max_chunks(max_kept, num_rots, bmm_size);
+  if (num_rots > bmm_size) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_rot_bins: bmm_size %d < num_rots %d unsupported", bmm_size, num_rots);
+    return CPPF_EUNSUPPORTED;
+  }
+  const size_t lut_lds = (size_t)S * 16 + (size_t)2 * S * 8;
+  if (bin_lut && lut_lds <= 60000 && max_kept > 0) {
+    const int ppb = rw_ppb(num_rots, bmm_size);
+    const int nblk = (max_kept + ppb - 1) / ppb;
+    double* partial = (double*)workspace;
+    int32_t* block_chunk = (int32_t*)((char*)workspace + align_up((int64_t)B * nblk * 2 * S * 8, 256));
+    hipLaunchKernelGGL(rot_bins_lut_kernel, dim3(nblk, B), dim3(RW_THREADS), lut_lds, st, pts, pt_off, idx, k, tup_off,
+                       rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab, sin_tab,
+                       sphere, S, cos_thr, (const int4*)bin_lut, lut_rows, lut_cols, bmm_size, partial, block_chunk);
+    CPPF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rot_bins_fold_kernel, dim3(B), dim3(1024), 0, st, partial, block_chunk, nblk, S, counts,
+                       top_idx, top_count);
+    CPPF_LAUNCH_CHECK();
+    return CPPF_OK;
+  }
   double* sums = (double*)workspace;
   CPPF_HIP(hipMemsetAsync(sums, 0, (size_t)B * max_chunks * S * 8, st));
   if (max_kept > 0) {
     int ppb = RB_MAX_CAND / num_rots;
     if (ppb > 4) ppb = 4;
     if (ppb < 1) ppb = 1;
-    // a block's rows must not straddle more than two chunks
-    if ((int64_t)ppb * num_rots > bmm_size) {
-      ppb = bmm_size / num_rots;
-      if (ppb < 1) {
-        snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_rot_bins: bmm_size %d < num_rots %d unsupported", bmm_size,
-                 num_rots);
-        return CPPF_EUNSUPPORTED;
-      }
-    }
+    if ((int64_t)ppb * num_rots > bmm_size) ppb = bmm_size / num_rots;   // a block's rows span at most two chunks
     const int blocks = (max_kept + ppb - 1) / ppb;
-    const size_t win_lds = ((size_t)S * 12 + 15) / 16 * 16 + (size_t)2 * S * 8;
-    if (fibonacci && cos_thr > 0.5f && S >= 16 && win_lds <= 60000) {
-      // |dy| <= cone angle (+1e-4 rad slack for f32 rounding of dot/normalisation), in index units, +1
-      const double cone = acos((double)cos_thr) + 1e-4;
-      const int win = (int)ceil(cone * 0.5 * (double)(S - 1)) + 1;
-      hipLaunchKernelGGL(rot_bins_window_kernel, dim3(blocks, B), dim3(RW_THREADS), win_lds, st, pts, pt_off, idx, k,
-                         tup_off, rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab,
-                         sin_tab, sphere, S, cos_thr, win, bmm_size, max_chunks, sums);
-    } else {
-      hipLaunchKernelGGL(rot_bins_dense_kernel, dim3(blocks, B), dim3(RB_THREADS), 0, st, pts, pt_off, idx, k, tup_off,
-                         rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab, sin_tab,
-                         sphere, S, cos_thr, bmm_size, max_chunks, sums);
-    }
+    hipLaunchKernelGGL(rot_bins_dense_kernel, dim3(blocks, B), dim3(RB_THREADS), 0, st, pts, pt_off, idx, k, tup_off,
+                       rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab, sin_tab,
+                       sphere, S, cos_thr, bmm_size, max_chunks, sums);
     CPPF_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(rot_bins_final_kernel, dim3(B), dim3(256), 0, st, sums, S, max_chunks, counts, top_idx,

@@ -86,6 +86,64 @@ def is_fibonacci(sphere_pts):
     return bool(np.array_equal(s.astype(np.float32), np.array(fibonacci_sphere(s.shape[0]), dtype=np.float32)))
 
 
+LUT_ROWS, LUT_COLS, LUT_K = 256, 256, 8
+_LUT_CACHE = {}
+
+
+def build_bin_lut(sphere_pts, cos_thr, rows=LUT_ROWS, cols=LUT_COLS):
+    """Cell -> candidate-bin table for cppf_rot_bins (host, NumPy, once per bin set).
+
+    The sphere is cut into rows of equal height in y and `cols` azimuth sectors; cell (i, j) lists every bin whose
+    cone {v : v.bin > cos_thr} can contain a direction of the cell: bins within (cone angle + circumradius of the
+    cell + 2e-3 rad) of the cell centre.  The kernel then tests only those bins exactly, so the counts are the ones
+    of the exhaustive sweep for ANY bin set.  Returns int16 [rows, cols, LUT_K] (-1 = empty) or None if some cell
+    needs more than LUT_K slots (wide cones): the caller then uses the exhaustive kernel."""
+    sph = np.asarray(sphere_pts, dtype=np.float64)
+    sph = sph / np.maximum(np.linalg.norm(sph, axis=1, keepdims=True), 1e-30)
+    alpha = float(np.arccos(np.clip(cos_thr, -1.0, 1.0)))
+    i = np.arange(rows)
+    y_hi, y_lo = 1 - i / (rows / 2), 1 - (i + 1) / (rows / 2)
+    yc = 0.5 * (y_hi + y_lo)
+    dphi = 2 * np.pi / cols
+    phic = (np.arange(cols) + 0.5) * dphi
+
+    def vec(y, phi):
+        r = np.sqrt(np.maximum(0.0, 1 - y * y))
+        return np.stack([r * np.cos(phi), y + 0 * phi, r * np.sin(phi)], -1)
+    c0 = vec(yc, phic[0])
+    rho = np.zeros(rows)
+    for yy in (y_lo, y_hi):
+        for dp in (-dphi / 2, dphi / 2):
+            rho = np.maximum(rho, np.arccos(np.clip((vec(yy, phic[0] + dp) * c0).sum(-1), -1, 1)))
+    rho[0] = max(rho[0], np.arccos(np.clip(yc[0], -1, 1)))          # the polar cells contain the pole
+    rho[-1] = max(rho[-1], np.arccos(np.clip(-yc[-1], -1, 1)))
+    lim = np.cos(np.minimum(np.pi, alpha + 1.02 * rho + 2e-3))
+    masks = []
+    for r in range(rows):
+        masks.append(vec(np.full(cols, yc[r]), phic) @ sph.T >= lim[r])
+    kmax = max(int(m.sum(1).max()) for m in masks)
+    if kmax > LUT_K:
+        return None
+    lut = np.full((rows, cols, LUT_K), -1, dtype=np.int16)
+    for r, m in enumerate(masks):
+        cc, ss = np.nonzero(m)
+        slot = np.zeros(cols, dtype=np.int64)
+        for c, sidx in zip(cc, ss):
+            lut[r, c, slot[c]] = sidx
+            slot[c] += 1
+    return lut
+
+
+def bin_lut_device(sphere_pts, cos_thr, device):
+    """Cached device copy of build_bin_lut (None if the table does not fit LUT_K)."""
+    sph = np.ascontiguousarray(sphere_pts, dtype=np.float32)
+    key = (sph.tobytes(), float(cos_thr), str(device))
+    if key not in _LUT_CACHE:
+        lut = build_bin_lut(sph, cos_thr)
+        _LUT_CACHE[key] = None if lut is None else torch.from_numpy(lut).to(device)
+    return _LUT_CACHE[key]
+
+
 _TRIG_CACHE = {}
 
 

@@ -55,9 +55,9 @@ class VotingPipeline:
         sph = ops.sphere_bins(angle_tol) if sphere_pts is None else np.asarray(sphere_pts, dtype=np.float32)
         self.sphere_np = sph
         self.S = sph.shape[0]
-        self.fib = 1 if ops.is_fibonacci(sph) else 0
         self.sphere = torch.from_numpy(sph).to(self.dev)
         self.cos_thr = ops.cone_threshold(angle_tol)
+        self.lut = ops.bin_lut_device(sph, self.cos_thr, self.dev)    # None -> exhaustive bin sweep
         self.cs, self.sn = ops._trig(self.R, trig, self.dev)
         kg = [ops.percentile_params(n, self.ratio) for n in self.nt_]
         self.kidx = torch.tensor([a for a, _ in kg], dtype=torch.int32, device=self.dev)
@@ -117,14 +117,15 @@ class VotingPipeline:
                                            ops._p(self.thr), ops._p(self.ws), self.ws_bv_bytes, ops._stream()),
                    "cppf_backvote_filter")
 
-    def rot_bins(self, pts, idx, fibonacci=None):
-        fib = self.fib if fibonacci is None else int(fibonacci)
+    def rot_bins(self, pts, idx, use_lut=True):
+        lut = self.lut if use_lut else None
         for a, col in ((0, 0), (1, 2)):            # up <- targets_rot[:,0], "right" <- targets_rot[:,2] (eval.py:278,287)
             _lib.check(_L.cppf_rot_bins(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
                                         ops._p(self.tup_off), ops._p(self.rot), col, ops._p(self.kept_tuple),
                                         ops._p(self.kept_count), ops._p(self.kept_wt), ops._p(self.kept_row0),
                                         self.max_kept, self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.sphere),
-                                        self.S, C.c_float(self.cos_thr), self.bmm, fib, ops._p(self.counts[a]),
+                                        self.S, C.c_float(self.cos_thr), self.bmm, ops._p(lut), ops.LUT_ROWS,
+                                        ops.LUT_COLS, ops._p(self.counts[a]),
                                         ops._p(self.top_idx[a]), ops._p(self.top_cnt[a]), ops._p(self.ws),
                                         self.ws_rot_bytes, ops._stream()), "cppf_rot_bins")
 

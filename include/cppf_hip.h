@@ -178,8 +178,10 @@ int cppf_backvote_filter(int B, const float* pts, const int32_t* pt_off, const i
  *   rot: float32[T,3] (targets_rot); rot_col: which column holds the angle (0 = up, 2 = "right", eval.py:278,287);
  *   the kept_* arrays come from cppf_backvote_filter; max_kept >= max_b kept_count[b];
  *   sphere: float32[S,3]; cos_thr = float32(cos(2*angle_tol deg)); bmm_size: rows per float32
- *   accumulation chunk (eval.py:81, 100000).  fibonacci != 0 promises sphere is fibonacci_sphere(S)
- *   (utils/util.py:191-207) and enables the windowed search.
+ *   accumulation chunk (eval.py:81, 100000).  bin_lut (optional, device int16[lut_rows*lut_cols*8]): for each cell of
+ *   the partition {row = floor((1-y)*lut_rows/2), col = floor(atan2(z,x) mod 2pi * lut_cols/2pi)} of the unit sphere,
+ *   up to 8 bin ids (-1 = empty) covering every bin whose cone can contain a direction of the cell
+ *   (cppf2_amd.ops.build_bin_lut builds it for any bin set); NULL selects the exhaustive bin sweep.
  *   Outputs: counts float32[B,S], top_idx int32[B], top_count float32[B].
  *   workspace: cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size). */
 int64_t cppf_rot_bins_workspace_bytes(int B, int S, int max_kept, int num_rots, int bmm_size);
@@ -187,7 +189,8 @@ int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t*
                   const int32_t* tup_off, const float* rot, int rot_col,
                   const int32_t* kept_tuple, const int32_t* kept_count, const double* kept_wt,
                   const int32_t* kept_row0, int max_kept, int num_rots, const float* cos_tab, const float* sin_tab,
-                  const float* sphere, int S, float cos_thr, int bmm_size, int fibonacci,
+                  const float* sphere, int S, float cos_thr, int bmm_size,
+                  const int16_t* bin_lut, int lut_rows, int lut_cols,
                   float* counts, int32_t* top_idx, float* top_count,
                   void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -95,3 +95,28 @@ def test_5deg5cm_criterion_golden():
     for i, cid, hv, theta, shift in g["table"]:
         got = rt_degree_cm(g["A"][int(i)], g["B"][int(i)], SYNSET_NAMES[int(cid)], int(hv))
         assert np.isclose(got[0], theta, atol=1e-9) and np.isclose(got[1], shift, atol=1e-12)
+
+
+def test_bin_lut_is_conservative():
+    """Every (direction, bin) pair inside the cone must be listed in the direction's cell -- for the fibonacci bins
+    and for an arbitrary bin set -- and a wide cone makes the builder decline (exhaustive kernel is used then)."""
+    from cppf2_amd import ops
+    rng = np.random.RandomState(0)
+    for sph, thr in ((ops.sphere_bins(1.0), ops.cone_threshold(1.0)),
+                     (rng.randn(300, 3).astype(np.float32), ops.cone_threshold(1.0))):
+        sph = sph / np.linalg.norm(sph, axis=1, keepdims=True)
+        lut = ops.build_bin_lut(sph, thr)
+        assert lut is not None and lut.shape == (ops.LUT_ROWS, ops.LUT_COLS, ops.LUT_K)
+        v = rng.randn(200000, 3)
+        v[:2000] = sph[rng.randint(0, len(sph), 2000)] + rng.randn(2000, 3) * 0.01     # many directions near bins
+        v[2000:2100] = [0, 1, 0] + rng.randn(100, 3) * 0.02                              # near the poles
+        v[2100:2200] = [0, -1, 0] + rng.randn(100, 3) * 0.02
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+        hit_v, hit_s = np.nonzero(v @ sph.T.astype(np.float32) > np.float32(thr))
+        phi = np.arctan2(v[:, 2], v[:, 0]).astype(np.float32)
+        phi = np.where(phi < 0, phi + np.float32(2 * np.pi), phi)
+        ci = np.clip(((1 - v[:, 1]) * np.float32(ops.LUT_ROWS / 2)).astype(int), 0, ops.LUT_ROWS - 1)
+        cj = np.clip((phi * np.float32(ops.LUT_COLS / (2 * np.pi))).astype(int), 0, ops.LUT_COLS - 1)
+        listed = (lut[ci[hit_v], cj[hit_v]] == hit_s[:, None]).any(1)
+        assert len(hit_v) > 1000 and listed.all()
+    assert ops.build_bin_lut(ops.sphere_bins(1.0), np.cos(np.radians(30))) is None
