@@ -184,43 +184,50 @@ __device__ __forceinline__ float encode_scalar(const float* __restrict__ pts, co
 // Work items of a scene: first nt*head_vec "head" float4s (pair differences + normal cosines, a few dependent
 // gathers each), then nt*feat_vec pure gather-copies of the feature table -- so that every wavefront (but one)
 // runs a single kind of item.  blockIdx.y = scene: no per-item scene search.
+// KC / FV > 0: tuple size and float4s per feature row known at compile time (divisions by constants);
+// 0: runtime values.  Item indices are 32-bit (a scene has < 2^31 float4 items).
+template <int KC, int FV>
 __global__ __launch_bounds__(256) void encode_shot_kernel(const float* __restrict__ pts,
                                                           const float* __restrict__ nrm,
-                                                          const float* __restrict__ feat, int feat_dim,
-                                                          const int32_t* __restrict__ idx, int k,
+                                                          const float* __restrict__ feat, int feat_dim_rt,
+                                                          const int32_t* __restrict__ idx, int k_rt,
                                                           const int32_t* __restrict__ pt_off,
                                                           const int32_t* __restrict__ tup_off, ComboTable cb,
                                                           float* __restrict__ out) {
-  const int b = blockIdx.y;
+  // (tried: mapping all workgroups of a scene onto one XCD so its feature table stays in one L2 -- 10 % slower,
+  //  the kernel is bound by the 1.8 GB of streaming writes, not by the gathers)
+  const unsigned b = blockIdx.y, bx = blockIdx.x, bps = gridDim.x;
   const int p0 = pt_off[b];
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
-  const int np = k * (k - 1) / 2;
-  const int head = 4 * np;                       // coord (3np) + normal (np) scalars
-  const int row_len = head + k * feat_dim;
-  const int head_vec = np;                       // head / 4
-  const int fvec = feat_dim >> 2;                // float4s per feature row
-  const int feat_vec = k * fvec;
-  const int64_t n_head = (int64_t)nt * head_vec;
-  const int64_t n_all = n_head + (int64_t)nt * feat_vec;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_all; v += (int64_t)gridDim.x * blockDim.x) {
+  const unsigned k = KC > 0 ? KC : (unsigned)k_rt;
+  const unsigned fvec = FV > 0 ? FV : (unsigned)(feat_dim_rt >> 2);   // float4s per feature row
+  const unsigned feat_dim = fvec << 2;
+  const unsigned np = k * (k - 1) / 2;
+  const unsigned head = 4 * np;                  // coord (3np) + normal (np) scalars
+  const unsigned row_len = head + k * feat_dim;
+  const unsigned head_vec = np;                  // head / 4
+  const unsigned feat_vec = k * fvec;
+  const unsigned n_head = (unsigned)nt * head_vec;
+  const unsigned n_all = n_head + (unsigned)nt * feat_vec;
+  for (unsigned v = bx * blockDim.x + threadIdx.x; v < n_all; v += bps * blockDim.x) {
     if (v >= n_head) {
-      const int64_t w = v - n_head;
-      const int t = (int)(w / feat_vec);
-      const int c = (int)(w - (int64_t)t * feat_vec);
-      const int kk = c / fvec, col = (c - kk * fvec) << 2;
-      const int64_t row = (int64_t)(t0 + t);
+      const unsigned w = v - n_head;
+      const unsigned t = w / feat_vec;
+      const unsigned c = w - t * feat_vec;
+      const unsigned kk = c / fvec, col = (c - kk * fvec) << 2;
+      const int64_t row = (int64_t)t0 + t;
       const float4 o = *reinterpret_cast<const float4*>(feat + (int64_t)(p0 + idx[row * k + kk]) * feat_dim + col);
       *reinterpret_cast<float4*>(out + row * row_len + head + kk * feat_dim + col) = o;
     } else {
-      const int t = (int)(v / head_vec);
-      const int c = (int)(v - (int64_t)t * head_vec);
-      const int64_t row = (int64_t)(t0 + t);
+      const unsigned t = v / head_vec;
+      const unsigned c = v - t * head_vec;
+      const int64_t row = (int64_t)t0 + t;
       const int32_t* row_idx = idx + row * k;
       float4 o;
-      o.x = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 0, cb);
-      o.y = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 1, cb);
-      o.z = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 2, cb);
-      o.w = encode_scalar(pts, nrm, row_idx, p0, np, 4 * c + 3, cb);
+      o.x = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 0), cb);
+      o.y = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 1), cb);
+      o.z = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 2), cb);
+      o.w = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 3), cb);
       *reinterpret_cast<float4*>(out + row * row_len + 4 * c) = o;
     }
   }
@@ -238,8 +245,16 @@ extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* nor
   int64_t bx = (per_scene + 255) / 256;
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(encode_shot_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, feat,
-                     feat_dim, idx, k, pt_off, tup_off, make_combos(k), out);
+  if (per_scene >= 0x7fffffffLL) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_encode_tuples_shot: more than 2^31 items per scene");
+    return CPPF_EUNSUPPORTED;
+  }
+  if (k == 5 && feat_dim == 64)
+    hipLaunchKernelGGL((encode_shot_kernel<5, 16>), dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts,
+                       normals, feat, feat_dim, idx, k, pt_off, tup_off, make_combos(k), out);
+  else
+    hipLaunchKernelGGL((encode_shot_kernel<0, 0>), dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts,
+                       normals, feat, feat_dim, idx, k, pt_off, tup_off, make_combos(k), out);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
