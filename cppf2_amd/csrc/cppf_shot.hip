@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   for (int c = lane; c < SHOT_LEN; c += 64) acc += (double)s_hist[c] * (double)s_hist[c];
   acc = sqrt(wave_sum(acc));
   const float facc = (float)acc;
-  for (int c = lane; c < SHOT_LEN; c += 64) o[c] = s_hist[c] / facc;
+  for (int c = lane; c < SHOT_LEN; c += 64) __builtin_nontemporal_store(s_hist[c] / facc, &o[c]);
 }
 
 // ---------------------------------------------------------------------------------------------
