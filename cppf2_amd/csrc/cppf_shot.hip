@@ -117,68 +117,92 @@ __device__ __forceinline__ float sqdist3(float px, float py, float pz, float qx,
 #define RAD_135 2.3561944901923449288469825374596
 #define RAD_PI_7_8 2.7488935718910690836548129603691
 
+// Per-neighbour interpolation arithmetic type.  PCL 1.9.1 evaluates it in double and rounds every addend to float
+// when it is accumulated; the default here is float with the two angles taken from atan2 (accurate at the poles,
+// where acosf of a float cosine is not), which differs from the double evaluation by ~1e-7 per addend -- the size
+// of the float rounding PCL applies to the same addends -- and costs a third of the instructions on the GPU
+// (float64 runs at half rate and its acos/atan2 are ~5x longer).  -DSHOT_REAL=double restores the double path.
+#ifndef SHOT_REAL
+#define SHOT_REAL float
+#endif
+typedef SHOT_REAL real_t;
+
+__device__ __forceinline__ real_t r_inclination(real_t zf, real_t rho, real_t distance) {
+  if (sizeof(real_t) == 8) {
+    double c = (double)zf / (double)distance;
+    c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+    return (real_t)acos(c);
+  }
+  return (real_t)atan2f((float)rho, (float)zf);      // in [0, pi], well conditioned everywhere
+}
+__device__ __forceinline__ real_t r_atan2(real_t y, real_t x) {
+  return sizeof(real_t) == 8 ? (real_t)atan2((double)y, (double)x) : (real_t)atan2f((float)y, (float)x);
+}
+__device__ __forceinline__ real_t r_sqrt(real_t x) {
+  return sizeof(real_t) == 8 ? (real_t)sqrt((double)x) : (real_t)__builtin_sqrtf((float)x);
+}
+
 __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, float qx, float qy, float qz, float d2,
-                                                float nqx, float nqy, float nqz, const float* rf, double radius,
+                                                float nqx, float nqy, float nqz, const float* rf, real_t radius,
                                                 float* shot) {
+  const real_t ONE = 1, HALF = (real_t)0.5;
   if (!isfinite(nqx) || !isfinite(nqy) || !isfinite(nqz)) return;
-  double cosd = (double)((nqx * rf[6] + nqy * rf[7]) + nqz * rf[8]);
-  if (cosd > 1.0) cosd = 1.0;
-  if (cosd < -1.0) cosd = -1.0;
-  double bin_distance = ((1.0 + cosd) * NR_BINS) / 2;
-  const double distance = sqrt((double)d2);
-  if (fabs(distance) < 1e-15) return;
+  real_t cosd = (real_t)((nqx * rf[6] + nqy * rf[7]) + nqz * rf[8]);
+  if (cosd > ONE) cosd = ONE;
+  if (cosd < -ONE) cosd = -ONE;
+  real_t bin_distance = ((ONE + cosd) * NR_BINS) / 2;
+  const real_t distance = r_sqrt((real_t)d2);
+  if (fabs(distance) < (real_t)1e-15) return;
   const float dx = qx - px, dy = qy - py, dz = qz - pz;
-  double xf = (double)((dx * rf[0] + dy * rf[1]) + dz * rf[2]);
-  double yf = (double)((dx * rf[3] + dy * rf[4]) + dz * rf[5]);
-  double zf = (double)((dx * rf[6] + dy * rf[7]) + dz * rf[8]);
-  if (fabs(yf) < 1e-30) yf = 0;
-  if (fabs(xf) < 1e-30) xf = 0;
-  if (fabs(zf) < 1e-30) zf = 0;
-  const double r12 = radius / 2.0, r14 = radius / 4.0, r34 = radius * 3.0 / 4.0;
-  const int bit4 = ((yf > 0) || ((yf == 0.0) && (xf < 0))) ? 1 : 0;
-  const int bit3 = ((xf > 0) || ((xf == 0.0) && (yf > 0))) ? !bit4 : bit4;
+  real_t xf = (real_t)((dx * rf[0] + dy * rf[1]) + dz * rf[2]);
+  real_t yf = (real_t)((dx * rf[3] + dy * rf[4]) + dz * rf[5]);
+  real_t zf = (real_t)((dx * rf[6] + dy * rf[7]) + dz * rf[8]);
+  if (fabs(yf) < (real_t)1e-30) yf = 0;
+  if (fabs(xf) < (real_t)1e-30) xf = 0;
+  if (fabs(zf) < (real_t)1e-30) zf = 0;
+  const real_t r12 = radius / 2, r14 = radius / 4, r34 = radius * 3 / 4;
+  const int bit4 = ((yf > 0) || ((yf == 0) && (xf < 0))) ? 1 : 0;
+  const int bit3 = ((xf > 0) || ((xf == 0) && (yf > 0))) ? !bit4 : bit4;
   int desc_index = ((bit4 << 3) + (bit3 << 2)) << 1;
-  if ((xf * yf > 0) || (xf == 0.0))
+  if ((xf * yf > 0) || (xf == 0))
     desc_index += (fabs(xf) >= fabs(yf)) ? 0 : 4;
   else
     desc_index += (fabs(xf) > fabs(yf)) ? 4 : 0;
   desc_index += zf > 0 ? 1 : 0;
   desc_index += (distance > r12) ? 2 : 0;
-  const int step_index = (int)floor(bin_distance + 0.5);
+  const int step_index = (int)floor(bin_distance + HALF);
   const int volume_index = desc_index * (NR_BINS + 1);
   bin_distance -= step_index;
-  double w = 1.0 - fabs(bin_distance);
+  real_t w = ONE - fabs(bin_distance);
   if (bin_distance > 0)
     atomicAdd(&shot[volume_index + ((step_index + 1) % NR_BINS)], (float)bin_distance);
   else
     atomicAdd(&shot[volume_index + ((step_index - 1 + NR_BINS) % NR_BINS)], -(float)bin_distance);
   if (distance > r12) {
-    const double rd = (distance - r34) / r12;
+    const real_t rd = (distance - r34) / r12;
     if (distance > r34) w += 1 - rd;
     else { w += 1 + rd; atomicAdd(&shot[(desc_index - 2) * (NR_BINS + 1) + step_index], -(float)rd); }
   } else {
-    const double rd = (distance - r14) / r12;
+    const real_t rd = (distance - r14) / r12;
     if (distance < r14) w += 1 + rd;
     else { w += 1 - rd; atomicAdd(&shot[(desc_index + 2) * (NR_BINS + 1) + step_index], (float)rd); }
   }
-  double inc_cos = zf / distance;
-  if (inc_cos < -1.0) inc_cos = -1.0;
-  if (inc_cos > 1.0) inc_cos = 1.0;
-  const double inc = acos(inc_cos);
-  if (inc > RAD_90 || (fabs(inc - RAD_90) < 1e-30 && zf <= 0)) {
-    const double id = (inc - RAD_135) / RAD_90;
-    if (inc > RAD_135) w += 1 - id;
+  const real_t inc = r_inclination(zf, r_sqrt(xf * xf + yf * yf), distance);
+  const real_t R45 = (real_t)RAD_45, R90 = (real_t)RAD_90, R135 = (real_t)RAD_135;
+  if (inc > R90 || (fabs(inc - R90) < (real_t)1e-30 && zf <= 0)) {
+    const real_t id = (inc - R135) / R90;
+    if (inc > R135) w += 1 - id;
     else { w += 1 + id; atomicAdd(&shot[(desc_index + 1) * (NR_BINS + 1) + step_index], -(float)id); }
   } else {
-    const double id = (inc - RAD_45) / RAD_90;
-    if (inc < RAD_45) w += 1 + id;
+    const real_t id = (inc - R45) / R90;
+    if (inc < R45) w += 1 + id;
     else { w += 1 - id; atomicAdd(&shot[(desc_index - 1) * (NR_BINS + 1) + step_index], (float)id); }
   }
-  if (yf != 0.0 || xf != 0.0) {
-    const double az = atan2(yf, xf);
+  if (yf != 0 || xf != 0) {
+    const real_t az = r_atan2(yf, xf);
     const int sel = desc_index >> 2;
-    double ad = (az - (-RAD_PI_7_8 + RAD_45 * sel)) / RAD_45;
-    ad = fmax(-0.5, fmin(ad, 0.5));
+    real_t ad = (az - (-(real_t)RAD_PI_7_8 + R45 * sel)) / R45;
+    ad = ad < -HALF ? -HALF : (ad > HALF ? HALF : ad);
     if (ad > 0) {
       w += 1 - ad;
       atomicAdd(&shot[((desc_index + 4) % MAX_SECTORS) * (NR_BINS + 1) + step_index], (float)ad);
@@ -215,7 +239,8 @@ __global__ __launch_bounds__(1024) void shot_cells_kernel(const float* __restric
                                                           CellHdr* __restrict__ hdrs,
                                                           int32_t* __restrict__ cell_start /* [B][CELL_CAP+1] */,
                                                           int32_t* __restrict__ sorted_idx,
-                                                          float* __restrict__ sorted_pts) {
+                                                          float* __restrict__ sorted_pts,
+                                                          int32_t* __restrict__ scene_of) {
   __shared__ uint32_t s_cnt[CELL_CAP];
   __shared__ float s_red[16][6];
   __shared__ uint32_t s_wsum[16];
@@ -307,6 +332,7 @@ __global__ __launch_bounds__(1024) void shot_cells_kernel(const float* __restric
     const int cy = cell_coord(y, h.c0[1], h.inv, h.d[1]);
     const int cz = cell_coord(z, h.c0[2], h.inv, h.d[2]);
     const uint32_t pos = atomicAdd(&s_cnt[(cz * h.d[1] + cy) * h.d[0] + cx], 1u);
+    scene_of[p0 + i] = b;
     sorted_idx[p0 + pos] = i;
     float* o = sorted_pts + 3 * (int64_t)(p0 + pos);
     o[0] = x; o[1] = y; o[2] = z;
@@ -341,12 +367,13 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
-                                                      const float* __restrict__ sorted_pts, float rn, float rs,
+                                                      const float* __restrict__ sorted_pts,
+                                                      const int32_t* __restrict__ scene_of, float rn, float rs,
                                                       double* __restrict__ sums /* [Ntot][NSUM] */) {
   __shared__ double s_part[NSUM][64];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
-  const int b = find_scene_pt(pt_off, B, qi);
+  const int b = scene_of[qi];
   const int p0 = pt_off[b];
   const CellHdr h = hdrs[b];
   const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
@@ -449,6 +476,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const int32_t* __restrict__ cell_start,
                                                        const int32_t* __restrict__ sorted_idx,
                                                        const float* __restrict__ sorted_pts,
+                                                       const int32_t* __restrict__ scene_of,
                                                        const float* __restrict__ nrm, const LrfPre* __restrict__ pre,
                                                        float radius, float* __restrict__ out_shot,
                                                        float* __restrict__ out_rf) {
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   __shared__ float s_rf[9];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
-  const int b = find_scene_pt(pt_off, B, qi);
+  const int b = scene_of[qi];
   const int p0 = pt_off[b];
   const CellHdr h = hdrs[b];
   const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
@@ -600,7 +628,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
       const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
       const float d2 = sqdist3(px, py, pz, qx, qy, qz);
       const int oj = sid[j];
-      shot_accumulate(px, py, pz, qx, qy, qz, d2, sn[3 * oj], sn[3 * oj + 1], sn[3 * oj + 2], s_rf, (double)radius, s_hist);
+      shot_accumulate(px, py, pz, qx, qy, qz, d2, sn[3 * oj], sn[3 * oj + 1], sn[3 * oj + 2], s_rf, (real_t)radius, s_hist);
     }
   })
 #undef FOR_EACH_NEIGHBOUR
@@ -619,6 +647,7 @@ static inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct ShotWs {
   CellHdr* hdr; int32_t* cell_start; int32_t* sorted_idx; float* sorted_pts; double* sums; LrfPre* pre;
+  int32_t* scene_of;
 };
 
 static ShotWs carve(void* ws, int B, int64_t n) {
@@ -629,14 +658,16 @@ static ShotWs carve(void* ws, int B, int64_t n) {
   w.sorted_idx = (int32_t*)p; p += up256(n * 4);
   w.sorted_pts = (float*)p; p += up256(n * 12);
   w.sums = (double*)p; p += up256(n * NSUM * 8);
-  w.pre = (LrfPre*)p;
+  w.pre = (LrfPre*)p; p += up256(n * (int64_t)sizeof(LrfPre));
+  w.scene_of = (int32_t*)p;
   return w;
 }
 
 extern "C" int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points) {
   if (B <= 0 || total_points <= 0) return 0;
   return up256((int64_t)B * sizeof(CellHdr)) + up256((int64_t)B * (CELL_CAP + 1) * 4) + up256(total_points * 4) +
-         up256(total_points * 12) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre));
+         up256(total_points * 12) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre)) +
+         up256(total_points * 4);
 }
 
 static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, float normal_r, float shot_r,
@@ -647,17 +678,17 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
   const bool want_n = out_normal != nullptr, want_s = out_shot != nullptr;
   const float rn = want_n ? normal_r : 0.0f, rs = want_s ? shot_r : 0.0f;
   hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(rn, rs), w.hdr, w.cell_start,
-                     w.sorted_idx, w.sorted_pts);
+                     w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, rn, rs, w.sums);
+                     w.sorted_pts, w.scene_of, rn, rs, w.sums);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums,
                      out_normal, want_s ? w.pre : (LrfPre*)nullptr);
   CPPF_LAUNCH_CHECK();
   if (want_s) {
     hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                       w.sorted_idx, w.sorted_pts, normals_in ? normals_in : out_normal, w.pre, shot_r, out_shot,
+                       w.sorted_idx, w.sorted_pts, w.scene_of, normals_in ? normals_in : out_normal, w.pre, shot_r, out_shot,
                        out_rf);
     CPPF_LAUNCH_CHECK();
   }
@@ -708,10 +739,10 @@ extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off,
   const int64_t n = total_points;
   const ShotWs w = carve(workspace, B, n);
   hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(normal_r, shot_r), w.hdr,
-                     w.cell_start, w.sorted_idx, w.sorted_pts);
+                     w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, normal_r, shot_r, w.sums);
+                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
                      w.pre);
@@ -728,7 +759,7 @@ extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off
   CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, total_points));
   const ShotWs w = carve(workspace, B, total_points);
   hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, normals, w.pre, shot_r, out_shot, out_rf);
+                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, normals, w.pre, shot_r, out_shot, out_rf);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
