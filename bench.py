@@ -154,9 +154,9 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
 
 
 STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_cov_kernel", "shot352": "shot_hist_kernel",
-                "encode_tuples": "encode_shot_kernel", "decode_bins": "decode_bins_kernel<32>",
+                "encode_tuples": "encode_shot_kernel<5, 16>", "decode_bins": "decode_bins_kernel<32>",
                 "vote_center": "vote_center_slab_kernel<true>", "backvote_filter": "backvote_kernel",
-                "rot_bins": "rot_bins_window_kernel", "assemble_pose": "assemble_pose_kernel"}
+                "rot_bins": "rot_bins_lut_kernel", "assemble_pose": "assemble_pose_kernel"}
 
 
 def pmc_traffic(stage):
@@ -246,14 +246,15 @@ def main():
         res = step.pipe.results_to_numpy()
         G = int(np.mean(res["ncell"]))
         hip_stages = [s for s in Step.STAGES if "torch" not in s and s != "gather"]
-        dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0))
+        launches = {"rot_bins": 2}            # the stage launches its dominant kernel once per voted axis
+        dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0) / launches.get(s, 1))
         rows = []
         for s in Step.STAGES:
             ms = stage_ms.get(s, 0.0)
             ab = algorithmic_bytes(s, B, N, T, R, S, G)
             rows.append((s, ms, ab / 1e6, (ab / 1e9) / (ms / 1e3) if ms > 0 and ab else 0.0))
-        dom_ms = stage_ms[dominant]
-        dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G)
+        dom_ms = stage_ms[dominant] / launches.get(dominant, 1)
+        dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G) / launches.get(dominant, 1)
         achieved = (dom_bytes / 1e9) / (dom_ms / 1e3)
         roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms,
@@ -278,7 +279,7 @@ def main():
                 m = np.eye(4)
                 m[:3, :3], m[:3, 3] = R, t
                 return m
-            errs = [rt_degree_cm(rt(res["R"][b], res["t"][b]), rt(o["R_est"], o["T_est"]), "bottle")
+            errs = [rt_degree_cm(rt(res["R"][b], res["t"][b]), rt(o["R_est"], o["T_est"]), "bottle", clip=True)
                     for b, o in enumerate(outs)]
             agree = dict(scenes=len(outs), match_5deg5cm=float(np.mean([e[0] <= 5 and e[1] <= 5 for e in errs])),
                          max_rot_err_deg=float(max(e[0] for e in errs)), max_shift_cm=float(max(e[1] for e in errs)),
