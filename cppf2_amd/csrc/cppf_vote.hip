@@ -409,7 +409,8 @@ __global__ __launch_bounds__(64) void grid_argmax_final_kernel(const SlabBest* _
   if (threadIdx.x == 0) {
     if (bi == INT64_MAX) bi = 0;
     out_argmax[b] = bi;
-    if (out_peak) out_peak[b] = bv;
+    // a scene whose grid exceeds cells_cap received no votes: its peak is the sentinel 0xFFFFFFFF
+    if (out_peak) out_peak[b] = ((int64_t)g.ncell > cells_cap) ? 0xFFFFFFFFu : bv;
     if (out_world) {
       const int64_t gyz = (int64_t)g.g[1] * g.g[2];
       const int64_t ix = gyz > 0 ? bi / gyz : 0;
@@ -1299,7 +1300,7 @@ __global__ __launch_bounds__(256) void assemble_pose_kernel(
   r.up_count = up_count ? up_count[b] : 0.0f;
   r.right_count = right_count ? right_count[b] : 0.0f;
   r.kept = kept;
-  r.flags = grids ? grids[b].flags : 0;
+  r.flags = (grids ? grids[b].flags : 0) | ((peak && peak[b] == 0xFFFFFFFFu) ? 4 : 0);
   r.ncell = grids ? grids[b].ncell : 0;
   r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
   r.scale[0] = s_med[0]; r.scale[1] = s_med[1]; r.scale[2] = s_med[2];

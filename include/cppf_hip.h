@@ -146,7 +146,7 @@ int cppf_generate_target_pairs(int B, const float* pairs, const int32_t* tup_off
  *     flags bit2 and no votes).  mode: 0 = auto, 1 = LDS-slab accumulation (per-slab rotation arcs),
  *     2 = global atomics, 3 = LDS-slab with the exhaustive rotation sweep (A/B reference).
  *   workspace: cppf_vote_center_workspace_bytes(B, cells_cap, total_tuples) bytes.
- *   out_argmax int64[B], out_peak uint32[B], out_world float64[B,3]. */
+ *   out_argmax int64[B], out_peak uint32[B] (0xFFFFFFFF for a scene above cells_cap), out_world float64[B,3]. */
 int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off, float res, CppfSceneGrid* out, void* stream);
 int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples);
 int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,

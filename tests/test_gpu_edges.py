@@ -1,0 +1,91 @@
+"""Edge cases the reference's own code paths imply (empty / tiny / ragged / oversized inputs), on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+from oracle import cppf_oracle as O            # noqa: E402
+from oracle import shot_oracle as S            # noqa: E402
+from cppf2_amd import ops, shot, synth         # noqa: E402
+from cppf2_amd.pipeline import VotingPipeline  # noqa: E402
+
+DEV = torch.device("cuda")
+
+
+def _inputs(seed, sid, N, T):
+    sc = synth.make_scene(seed, sid, N)
+    idx = synth.host_sample_tuples(seed, sid, T, 5, N)
+    lg = synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6)
+    u = O.philox_uniform(seed, sid, 1, T, 6)
+    return sc, idx, lg, u
+
+
+def _run(Ns, Ts, parts, R=36, **kw):
+    pipe = VotingPipeline(Ns, Ts, num_rots=R, **kw)
+    cat = lambda i, dt, shape: torch.as_tensor(np.concatenate([p[i].reshape(shape) for p in parts]) if parts else
+                                               np.zeros(shape, dtype=np.float32)).to(DEV, dt)
+    pts = cat(0, torch.float32, (-1, 3))
+    idx = cat(1, torch.int32, (-1, 5))
+    lg = cat(2, torch.float32, (-1, 6, 32))
+    u = cat(3, torch.float32, (-1, 6))
+    return pipe, pipe.results_to_numpy(pipe.vote(pts, idx, lg, u))
+
+
+def test_empty_and_tiny_scenes_inside_a_batch():
+    a = _inputs(4, 0, 700, 3000)
+    tiny_pc = synth.make_scene(4, 1, 5)["pc"]
+    tiny_idx = np.array([[0, 1, 2, 3, 4], [1, 1, 2, 3, 4], [4, 3, 2, 1, 0]], np.int32)
+    tiny_lg = np.zeros((3, 6, 32), np.float32)
+    tiny_u = np.full((3, 6), 0.5, np.float32)
+    z3, z5 = np.zeros((0, 3), np.float32), np.zeros((0, 5), np.int32)
+    parts = [(a[0]["pc"], a[1], a[2], a[3]), (z3, z5, np.zeros((0, 6, 32), np.float32), np.zeros((0, 6), np.float32)),
+             (tiny_pc, tiny_idx, tiny_lg, tiny_u)]
+    pipe, res = _run([700, 0, 5], [3000, 0, 3], parts)
+    _, solo = _run([700], [3000], parts[:1])
+    for f in ("argmax", "t", "peak", "up_idx", "right_idx", "kept", "R"):
+        assert np.array_equal(res[f][0], solo[f][0]), f          # neighbours in the batch do not leak
+    assert res["flags"][1] & 1 and res["kept"][1] == 0 and res["peak"][1] == 0
+    assert np.all(np.isfinite(res["R"][2])) and res["kept"][2] <= 3
+
+
+def test_grid_above_cells_cap_is_flagged_not_voted():
+    a = _inputs(5, 0, 400, 1000)
+    pipe, res = _run([400], [1000], [(a[0]["pc"], a[1], a[2], a[3])], cells_cap=1000)
+    assert res["ncell"][0] > 1000 and res["flags"][0] & 4 and res["argmax"][0] == 0
+
+
+def test_huge_grid_takes_the_global_atomic_path_and_matches_oracle():
+    # res = 0.5 mm -> ~2e7 cells: more than 64 LDS slabs, mode 0 selects global atomics
+    sc, idx, lg, u = _inputs(6, 0, 300, 800)
+    tr, _ = O.generate_target_pairs(sc["pc_canon"][idx[:, :2]] * np.float32(sc["diag"]), [0, 1, 0], [0, 0, 1], [1, 0, 0])
+    cs, sn = ops.rotation_table(24)
+    grid, cand = ops.vote_center(sc["pc"], tr, 5e-4, idx[:, :2], 24)
+    g2, c2 = O.vote_center(sc["pc"], tr, 5e-4, idx[:, :2], 24, trig=(cs.cpu().numpy(), sn.cpu().numpy()))
+    assert grid.size > 64 * 36864 and np.array_equal(grid, g2) and np.array_equal(cand, c2)
+
+
+def test_shot_large_sparse_cloud_coarsened_cells():
+    # a cloud spanning far more than CELL_CAP cells of edge r: the cell edge is coarsened, results must not change
+    rng = np.random.RandomState(0)
+    pc = (rng.rand(6000, 3) * np.float32([1.0, 1.5, 1.2])).astype(np.float32)
+    pc[:3000] = pc[:3000] * 0.05 + 0.4                     # one dense blob so that descriptors exist
+    hs, hn = shot.compute(pc, 0.02, 0.02)
+    os_, on, _ = S.compute(pc, 0.02, 0.02)
+    hs, hn = hs.reshape(-1, 352), hn.reshape(-1, 3)
+    assert np.array_equal(np.isnan(os_), np.isnan(hs)) and np.array_equal(np.isnan(on), np.isnan(hn))
+    ok = ~np.isnan(os_).any(1)
+    assert ok.sum() > 1000
+    assert np.abs(hs[ok] - os_[ok]).max() < 2e-5
+    assert np.allclose(hn, on, atol=2e-6, equal_nan=True)
+
+
+def test_shot_different_radii():
+    sc = synth.make_scene(8, 0, 900)
+    hs, hn = shot.compute(sc["pc"], 0.012, 0.025)
+    os_, on, _ = S.compute(sc["pc"], 0.012, 0.025)
+    ok = ~np.isnan(os_).any(1)
+    assert np.allclose(hn.reshape(-1, 3), on, atol=2e-6, equal_nan=True)
+    assert np.abs(hs.reshape(-1, 352)[ok] - os_[ok]).max() < 2e-5
