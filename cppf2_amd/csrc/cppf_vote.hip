@@ -210,7 +210,10 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
   float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
   // grid = (scene, P, slab rank): the slab rank is the slowest dimension of the dispatch order
-  const int b = blockIdx.x, pc = blockIdx.y, rank = blockIdx.z;
+  const int pc = blockIdx.y, rank = blockIdx.z;
+  // workgroup id % 8 selects the XCD: rotating the scene by the slab rank spreads a scene's slabs (and the uneven
+  // scene sizes) over all XCDs instead of pinning 8 whole scenes to each (measured 5 % faster)
+  const int b = (blockIdx.x + rank) % gridDim.x;
   const long long t_start = wall_clock64();
   const CppfSceneGrid g = grids[b];
   const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
