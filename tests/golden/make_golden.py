@@ -217,6 +217,7 @@ def main():
     summ = {}
     try:
         from PIL import Image
+        # the two PNGs are copied (as data) to tests/golden/example_data/ so the GPU box can replay config 1
         depth = np.array(Image.open("/root/reference/example_data/depth.png")).astype(np.float64) / 10000.0
         mask = np.array(Image.open("/root/reference/example_data/mask.png"))
         if mask.ndim == 3:
@@ -224,7 +225,9 @@ def main():
         mask = mask > 0
         K = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]])  # notebook cell 11
         pts, idxs = ref.backproject(depth, K, mask)
-        summ["example_backproject"] = dict(n=int(pts.shape[0]), min=pts.min(0).tolist(), max=pts.max(0).tolist())
+        summ["example_backproject"] = dict(n=int(pts.shape[0]), min=pts.min(0).tolist(), max=pts.max(0).tolist(),
+                                           sha=sha(pts), rows_sha=sha(np.stack(idxs, -1)), depth_scale=10000.0,
+                                           K=K.tolist())
     except Exception as e:  # pragma: no cover
         summ["example_backproject_error"] = repr(e)
 

@@ -96,3 +96,19 @@ def test_train_entry_points_run(tmp_path, monkeypatch):
     assert all(torch.isfinite(p).all() for p in m2.parameters())
     # the reference imports the voting callables from train_dino (eval.py:16)
     assert callable(train_dino.vote_center) and callable(train_dino.vote_rotation) and callable(train_dino.generate_target_pairs)
+
+
+def test_eval_main_on_reference_example_depth(monkeypatch):
+    """BASELINE config 1: the reference's example scene (depth + mask) through backproject -> voxel down-sample ->
+    SHOT -> both models -> votes, via the eval.py entry point (random-init weights: plumbing, shapes, finiteness)."""
+    import json
+    monkeypatch.chdir(ROOT)
+    sys.path.insert(0, ROOT)
+    import eval as ev
+    e = json.load(open(os.path.join(GOLDEN, "full_summary.json")))["example_backproject"]
+    rep = ev.main(data="depth", depth=os.path.join(GOLDEN, "example_data", "depth.png"),
+                  mask=os.path.join(GOLDEN, "example_data", "mask.png"), depth_scale=e["depth_scale"],
+                  intrinsics=e["K"], num_pairs=5000, num_rots=36, opt=False, debug=True)
+    assert rep["instances"] == 1 and len(rep["results"]) == 1
+    RT = np.array(rep["results"][0]["pred_RT"])
+    assert np.all(np.isfinite(RT)) and 0.8 < RT[2, 3] < 1.2          # the object sits ~1 m in front of the camera

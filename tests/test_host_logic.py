@@ -120,3 +120,24 @@ def test_bin_lut_is_conservative():
         listed = (lut[ci[hit_v], cj[hit_v]] == hit_s[:, None]).any(1)
         assert len(hit_v) > 1000 and listed.all()
     assert ops.build_bin_lut(ops.sphere_bins(1.0), np.cos(np.radians(30))) is None
+
+
+def test_example_data_backproject_golden(full_summary):
+    """BASELINE config 1 plumbing: back-projection of the reference's example depth+mask equals the reference's
+    utils/util.py:2586 output bit for bit; voxel down-sample gives the 4 251 voxels SURVEY.md reports."""
+    import hashlib
+    from PIL import Image
+    from cppf2_amd import geometry
+    e = full_summary["example_backproject"]
+    ex = os.path.join(GOLDEN, "example_data")
+    depth = np.array(Image.open(os.path.join(ex, "depth.png"))).astype(np.float64) / e["depth_scale"]
+    mask = np.array(Image.open(os.path.join(ex, "mask.png")))
+    mask = (mask[..., 0] if mask.ndim == 3 else mask) > 0
+    pts, (rows, cols) = geometry.backproject(depth, np.array(e["K"]), mask)
+    assert pts.shape[0] == e["n"]
+    assert hashlib.sha256(np.ascontiguousarray(pts).tobytes()).hexdigest() == e["sha"]
+    assert hashlib.sha256(np.ascontiguousarray(np.stack([rows, cols], -1)).tobytes()).hexdigest() == e["rows_sha"]
+    pc = pts.copy()
+    pc[:, :2] = -pc[:, :2]
+    keep = geometry.downsample(pc.astype(np.float32), 2e-3, np.random.RandomState(0))
+    assert len(keep) == 4251
