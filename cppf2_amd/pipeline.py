@@ -147,6 +147,26 @@ class VotingPipeline:
         self.assemble(pred_scales)
         return self.results
 
+    def capture(self, pts, idx, logits, uniforms, pred_scales=None):
+        """Captures decode -> ... -> pose into one HIP graph (torch.cuda.CUDAGraph) bound to the given (static) input
+        tensors; returns a callable that replays it.  The stages allocate nothing and never sync, so the whole
+        post-MLP path becomes a single graph launch -- what matters at B = 1 (the reference's one-instance-at-a-time
+        use), where ~15 kernel launches of a few microseconds each are otherwise host-bound."""
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.vote(pts, idx, logits, uniforms, pred_scales)          # warm-up outside capture (attribute calls)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.vote(pts, idx, logits, uniforms, pred_scales)
+        self._graph = g
+
+        def replay():
+            g.replay()
+            return self.results
+        return replay
+
     def results_to_numpy(self, results=None):
         r = self.results if results is None else results
         return np.frombuffer(r.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).copy()

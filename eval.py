@@ -52,7 +52,7 @@ def alignment_loss(pc, T_est, R_est, scale_norm, idx_kept, pred_pairs_kept, up_s
 def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, num_rots=180, opt=True, debug=False,
          use_grounded_sam=False, geo_branch=True, visual_branch=True, data="synthetic", num_scenes=8, num_points=4096,
          category="bottle", seed=0, ckpt_shot=None, ckpt_dino=None, depth=None, mask=None, intrinsics=None,
-         depth_scale=1000.0, out=None):
+         depth_scale=1000.0, out=None, out_pkl=None):
     cfg = load_config("config", "config", ["category=%s" % category])
     dev = ops._dev()
     up_sym = bool(cfg.get("up_sym", False))
@@ -175,6 +175,18 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
     if out:
         with open(out, "w") as f:
             json.dump(report, f)
+    if out_pkl:
+        # the reference's per-image result record (eval.py:143-147, 370-372, 399): pred_RTs [n,4,4] (rotation scaled by
+        # the scale norm), pred_scales [n,3] (normalised); identity / ones for instances no enabled branch produced
+        import pickle
+        res = dict(pred_RTs=np.stack([np.eye(4) for _ in range(B)]), pred_scales=np.ones((B, 3)),
+                   pred_class_ids=np.full((B,), int(cfg.get("category", 0))))
+        for item in summary:
+            res["pred_RTs"][item["scene"]] = np.array(item["pred_RT"])
+            if item["pred_scale"] is not None:
+                res["pred_scales"][item["scene"]] = np.array(item["pred_scale"])
+        with open(out_pkl, "wb") as f:
+            pickle.dump(res, f)
     return report
 
 

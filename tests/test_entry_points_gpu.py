@@ -70,8 +70,13 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     monkeypatch.chdir(ROOT)
     sys.path.insert(0, ROOT)
     import eval as ev
-    rep = ev.main(num_pairs=6000, num_rots=72, num_scenes=3, num_points=1024, opt=False, out=str(tmp_path / "r.json"))
+    rep = ev.main(num_pairs=6000, num_rots=72, num_scenes=3, num_points=1024, opt=False, out=str(tmp_path / "r.json"),
+                  out_pkl=str(tmp_path / "r.pkl"))
     assert rep["instances"] == 3 and len(rep["results"]) == 3
+    import pickle
+    res = pickle.load(open(tmp_path / "r.pkl", "rb"))
+    assert res["pred_RTs"].shape == (3, 4, 4) and res["pred_scales"].shape == (3, 3)
+    assert np.allclose(res["pred_RTs"][:, 3], [0, 0, 0, 1])
     assert rep["acc_5deg_5cm"] >= 2 / 3
     for r in rep["results"]:
         assert r["model"] in ("dino", "shot") and np.isfinite(r["loss"])
@@ -112,3 +117,23 @@ def test_eval_main_on_reference_example_depth(monkeypatch):
     assert rep["instances"] == 1 and len(rep["results"]) == 1
     RT = np.array(rep["results"][0]["pred_RT"])
     assert np.all(np.isfinite(RT)) and 0.8 < RT[2, 3] < 1.2          # the object sits ~1 m in front of the camera
+
+
+def test_hip_graph_replay_of_the_vote_pipeline():
+    """The post-MLP path allocates nothing and never syncs: it captures into one HIP graph and replays identically."""
+    from cppf2_amd import ops, synth
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    N, T = 800, 4000
+    sc = synth.make_scene(2, 0, N)
+    pts = torch.from_numpy(sc["pc"]).to(dev)
+    idx = ops.sample_tuples(N, T, 5, 2, (0,))
+    lg = torch.from_numpy(synth.teacher_logits(sc["pc_canon"], idx.cpu().numpy(), 32)).to(dev)
+    u = ops.philox_uniform(T, 6, 2, 1, (0,))
+    pipe = VotingPipeline([N], [T], num_rots=48)
+    want = pipe.vote(pts, idx, lg, u).clone()
+    replay = pipe.capture(pts, idx, lg, u)
+    pipe.results.zero_()
+    got = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
