@@ -57,7 +57,7 @@ SIGNATURES = {
     "cppf_generate_target_pairs": (_i, [_i, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "cppf_scene_bounds": (_i, [_i, _p, _p, _f, _p, _p]),
     "cppf_vote_center_workspace_bytes": (_i64, [_i, _i64, _i64]),
-    "cppf_vote_center": (_i, [_i, _p, _p, _p, _i, _p, _i, _i64, _p, _d, _i, _p, _p, _p, _p, _p, _i64, _i, _p, _i64,
+    "cppf_vote_center": (_i, [_i, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _d, _i, _p, _p, _p, _p, _p, _i64, _i, _p, _i64,
                               _p, _p, _p, _p]),
     "cppf_backvote_workspace_bytes": (_i64, [_i64, _i]),
     "cppf_backvote_filter": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _p, _p,

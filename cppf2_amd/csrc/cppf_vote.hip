@@ -38,7 +38,8 @@
 #ifndef VC_MIN_WAVES
 #define VC_MIN_WAVES 4
 #endif
-#define VC_FRAME_FLOATS 11             // cx cy cz xx xy xz yx yy yz invA phi
+#define VC_FRAME_FLOATS 12             // cx cy cz xx xy xz yx yy yz invA phi weight(uint bits)
+#define VC_WT_SCALE 256.0f             // fixed-point unit of weighted votes (weights in [0, 4])
 #ifndef VC_QUANTUM
 #define VC_QUANTUM 4
 #endif
@@ -129,12 +130,22 @@ __device__ __forceinline__ int vote_cell_fast(float cx, float cy, float cz, floa
   return ok ? (ix * gc.gy + iy) * gc.gz + iz : -1;
 }
 
+// Vote weight in accumulator units: 1 per vote when no weights are given (the reference, train_dino.py:204);
+// otherwise round(w * 256), w clamped to [0, 4] (deterministic integer accumulation: the "uncertainty-weighted"
+// accumulator of BASELINE config 5; not in the reference -- w == 1 gives exactly 256 x the reference grid).
+__device__ __forceinline__ uint32_t vote_weight(const float* __restrict__ vote_wt, int64_t row) {
+  if (!vote_wt) return 1u;
+  const float w = fminf(fmaxf(vote_wt[row], 0.0f), 4.0f);
+  return (uint32_t)(w * VC_WT_SCALE + 0.5f);
+}
+
 // 1. per-pair frames -> SoA workspace fr[VC_FRAME_FLOATS][total]
 __global__ __launch_bounds__(256) void vote_frames_kernel(const float* __restrict__ pts,
                                                           const int32_t* __restrict__ pt_off,
                                                           const int32_t* __restrict__ idx, int k,
                                                           const int32_t* __restrict__ tup_off,
-                                                          const float* __restrict__ tr, float res, int num_rots,
+                                                          const float* __restrict__ tr,
+                                                          const float* __restrict__ vote_wt, float res, int num_rots,
                                                           int64_t total, float* __restrict__ fr) {
   const int b = blockIdx.y;
   const float* p = pts + 3 * (int64_t)pt_off[b];
@@ -150,6 +161,7 @@ __global__ __launch_bounds__(256) void vote_frames_kernel(const float* __restric
     fr[6 * total + row] = v.yx; fr[7 * total + row] = v.yy; fr[8 * total + row] = v.yz;
     fr[9 * total + row] = (A > 1e-12f) ? 1.0f / A : 0.0f;
     fr[10 * total + row] = atan2f(v.yx, v.xx) * kappa;
+    fr[11 * total + row] = __uint_as_float(vote_weight(vote_wt, row));
   }
 }
 
@@ -245,12 +257,14 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   for (int tb = ts; tb < te; tb += VC_THREADS) {
     const int t = tb + threadIdx.x;
     float cx = NAN, cy = 0, cz = 0, xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0, invA = 0, phi = 0;
+    uint32_t wv = 0;
     if (t < te) {
       const int64_t row = (int64_t)(t0 + t);
       cx = fr[0 * total + row]; cy = fr[1 * total + row]; cz = fr[2 * total + row];
       xx = fr[3 * total + row]; xy = fr[4 * total + row]; xz = fr[5 * total + row];
       yx = fr[6 * total + row]; yy = fr[7 * total + row]; yz = fr[8 * total + row];
       invA = fr[9 * total + row]; phi = fr[10 * total + row];
+      wv = __float_as_uint(fr[11 * total + row]);
     }
     if (ARCS) {
       // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
         // NB every cross-lane read sits in wave-uniform control flow: ds_bpermute returns 0 for a source lane
         // that is masked off, so a shuffle under `if (q < WQ)` would lose the quanta owned by idle lanes.
         const int ont_all = __shfl(ntot, src);
+        const uint32_t owv = (uint32_t)__shfl((int)wv, src);
         const int ont = (q < WQ) ? ont_all : 0;
 #pragma unroll
         for (int jj = 0; jj < VC_QUANTUM; ++jj) {
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
             const float2 tg = s_trig[rr];
             const int lin = vote_cell_fast(ocx, ocy, ocz, oxx, oxy, oxz, oyx, oyy, oyz, tg.x, tg.y, gc);
             const unsigned rel = (unsigned)(lin - lo);
-            if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+            if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], owv);
           }
         }
       }
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
         const int lin = vote_cell(cx, cy, cz, xx, xy, xz, yx, yy, yz, cos_tab[r], sin_tab[r], c0x, c0y, c0z, res, gx,
                                   gy, gz);
         const unsigned rel = (unsigned)(lin - lo);
-        if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], 1u);
+        if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], wv);
       }
     }
   }
@@ -343,9 +358,10 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
 
 __global__ __launch_bounds__(256) void vote_center_global_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
-    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, float res, int num_rots,
-    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
-    uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap) {
+    const int32_t* __restrict__ tup_off, const float* __restrict__ tr, const float* __restrict__ vote_wt, float res,
+    int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+    const CppfSceneGrid* __restrict__ grids, uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off,
+    int64_t cells_cap) {
   const int b = blockIdx.y;
   const CppfSceneGrid g = grids[b];
   if ((int64_t)g.ncell > cells_cap || g.ncell <= 0) return;
@@ -356,10 +372,11 @@ __global__ __launch_bounds__(256) void vote_center_global_kernel(
     const int64_t row = (int64_t)(t0 + t);
     const VoteSetup v = vote_setup(p, idx[row * k], idx[row * k + 1], tr[row * 2], tr[row * 2 + 1], res);
     if (!v.ok) continue;
+    const uint32_t wv = vote_weight(vote_wt, row);
     for (int r = 0; r < num_rots; ++r) {
       const int lin = vote_cell(v.cx, v.cy, v.cz, v.xx, v.xy, v.xz, v.yx, v.yy, v.yz, cos_tab[r], sin_tab[r],
                                 g.c0[0], g.c0[1], g.c0[2], res, g.g[0], g.g[1], g.g[2]);
-      if (lin >= 0) atomicAdd(&gb[lin], 1u);
+      if (lin >= 0) atomicAdd(&gb[lin], wv);
     }
   }
 }
@@ -452,8 +469,8 @@ extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, in
 }
 
 extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
-                                const int32_t* tup_off, int max_t, int64_t total_tuples, const float* tr, double res,
-                                int num_rots, const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
+                                const int32_t* tup_off, int max_t, int64_t total_tuples, const float* tr,
+                                const float* vote_wt, double res, int num_rots, const float* cos_tab, const float* sin_tab, const CppfSceneGrid* grids,
                                 uint32_t* grid, const int64_t* grid_off, int64_t cells_cap, int mode,
                                 void* workspace, int64_t workspace_bytes, int64_t* out_argmax, uint32_t* out_peak,
                                 double* out_world, void* stream) {
@@ -505,7 +522,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       CPPF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
-                       tup_off, tr, res32, num_rots, total_tuples, frames);
+                       tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
     CPPF_LAUNCH_CHECK();
     if (arcs)
       hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
@@ -535,7 +552,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
     CPPF_LAUNCH_CHECK();
     if (max_t > 0) {
       hipLaunchKernelGGL(vote_center_global_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx,
-                         k, tup_off, tr, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap);
+                         k, tup_off, tr, vote_wt, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap);
       CPPF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(grid_argmax_partial_kernel, dim3(VC_ARG_BLOCKS, B), dim3(256), 0, st, g_use, goff_use,

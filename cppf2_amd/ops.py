@@ -327,8 +327,10 @@ def grids_to_host(grids):
     return (SceneGrid * n).from_buffer_copy(raw)
 
 
-def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, vis=None, trig=None, mode=0, return_device=False):
-    """train_dino.py:171-215.  Returns (grid_obj int64 ndarray [gx,gy,gz], cand_world float64 ndarray [3])."""
+def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, vis=None, trig=None, mode=0, return_device=False,
+                weights=None):
+    """train_dino.py:171-215.  Returns (grid_obj int64 ndarray [gx,gy,gz], cand_world float64 ndarray [3]).
+    weights (extension, BASELINE config 5): per-pair vote weights in [0, 4], accumulated as round(w*256)."""
     dev = _dev()
     pts = _t(pc, torch.float32, dev)
     tr = _t(preds_tr, torch.float32, dev)
@@ -348,7 +350,8 @@ def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, vis=None, trig=None,
     argmax = torch.empty((1,), dtype=torch.int64, device=dev)
     peak = torch.empty((1,), dtype=torch.int32, device=dev)
     world = torch.empty((1, 3), dtype=torch.float64, device=dev)
-    _lib.check(_L.cppf_vote_center(1, _p(pts), _p(pt_off), _p(idx), k, _p(tup_off), T, T, _p(tr), C.c_double(res),
+    wt = None if weights is None else _t(weights, torch.float32, dev).reshape(-1)
+    _lib.check(_L.cppf_vote_center(1, _p(pts), _p(pt_off), _p(idx), k, _p(tup_off), T, T, _p(tr), _p(wt), C.c_double(res),
                                    num_rots, _p(cs), _p(sn), _p(grids), _p(grid), _p(grid_off), G, mode, _p(ws),
                                    ws_bytes, _p(argmax), _p(peak), _p(world), _stream()), "cppf_vote_center")
     shape = (int(g.g[0]), int(g.g[1]), int(g.g[2]))

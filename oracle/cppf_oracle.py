@@ -292,8 +292,10 @@ def grid_geometry(pc, res):
     return c0, grid_res
 
 
-def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, trig=None):
-    """Returns (grid_obj int64[gx,gy,gz], cand_world float64[3]) like the reference."""
+def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, trig=None, weights=None):
+    """Returns (grid_obj int64[gx,gy,gz], cand_world float64[3]) like the reference.
+    weights (NOT in the reference; the build's BASELINE-config-5 extension, pinned only by this restatement): per-pair
+    weight w in [0,4]; every vote of the pair adds round(w*256) instead of 1."""
     pc = np.asarray(pc, dtype=F32)
     preds_tr = np.asarray(preds_tr, dtype=F32)
     point_idxs = np.asarray(point_idxs)
@@ -302,6 +304,10 @@ def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, trig=None):
     proj_len, odist = preds_tr[:, 0], preds_tr[:, 1]
     a, ab, nrm = _pair_frame(pc, point_idxs)
     mask = (nrm > F32(1e-7)) & (odist > res32)
+    wfix = None
+    if weights is not None:
+        w = np.clip(np.asarray(weights, dtype=F32), F32(0), F32(4))
+        wfix = ((w * F32(256)).astype(F32) + F32(0.5)).astype(F32).astype(np.int64)[mask]
     proj_len, odist, a, ab, nrm = proj_len[mask], odist[mask], a[mask], ab[mask], nrm[mask]
     ab = (ab / np.maximum(nrm, F32(1e-7))[:, None]).astype(F32)
     c = (a - ab * proj_len[:, None]).astype(F32)
@@ -322,7 +328,10 @@ def vote_center(pc, preds_tr, res, point_idxs, num_rots=36, trig=None):
         valid = np.all(ci > 0, -1) & np.all(ci < gr, -1) & np.all(np.isfinite(cg), -1)
         ci = ci[valid]
         lin = ci[:, 0] * gr[1] * gr[2] + ci[:, 1] * gr[2] + ci[:, 2]
-        grid += np.bincount(lin, minlength=G)
+        if wfix is None:
+            grid += np.bincount(lin, minlength=G)
+        else:
+            grid += np.bincount(lin, weights=wfix[valid].astype(np.float64), minlength=G).astype(np.int64)
     grid_obj = grid.reshape(*[int(g) for g in gr])
     cand = np.array(np.unravel_index([np.argmax(grid_obj, axis=None)], grid_obj.shape)).T[::-1][0]
     cand_world = c0 + cand * res                              # f32 + int64*float -> f64

@@ -345,3 +345,21 @@ def test_vote_center_properties_full_size(full_summary):
     g3, _ = ops.vote_center(pc, tr[perm], 2e-3, idx[perm][:, :2], f["R"], trig=trig, mode=1)
     assert np.array_equal(g1, g3)
     assert int(g1.sum()) == f["grid_total"]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_weighted_centre_votes_extension(full_summary, mode):
+    """BASELINE config 5's uncertainty-weighted accumulator (not in the reference): w == 1 gives exactly 256 x the
+    pinned integer grid; random weights match the oracle's fixed-point restatement cell for cell."""
+    f = full_summary["full"]
+    scene, pc, idx, scaled, trig, _ = _full_inputs(f)
+    tr, _ = ops.generate_target_pairs(scaled, UP, FRONT, RIGHT)
+    g0, c0 = ops.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, mode=mode)
+    g1, c1 = ops.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, mode=mode, weights=np.ones(f["T"], np.float32))
+    assert np.array_equal(g1, g0 * 256) and np.array_equal(c0, c1)
+    w = np.random.RandomState(1).rand(f["T"]).astype(np.float32) * 2
+    w[::7] = 0
+    w[3] = 9.0                      # clamped to 4
+    gw, cw = ops.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, mode=mode, weights=w)
+    go, co = O.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, weights=w)
+    assert np.array_equal(gw, go) and np.array_equal(cw, co)
