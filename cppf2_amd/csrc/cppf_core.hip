@@ -1,6 +1,7 @@
 // cppf_core.hip -- sampler, scene bounds, tuple encode, bin decode, vote-parameter decode.
 // gfx950 only.  See include/cppf_hip.h for the contract of each entry point.
 #include "cppf_common.h"
+#include <hip/hip_fp16.h>
 
 thread_local char g_cppf_err[256] = "";
 
@@ -240,6 +241,67 @@ __global__ __launch_bounds__(256) void encode_shot_kernel(const float* __restric
       store_stream(out + row * row_len + 4 * c, o);
     }
   }
+}
+
+// Half-precision feature table (BASELINE config 5: "fp16 features"): same row layout, float32 output; one item =
+// 8 halfs (16-byte load) -> two streaming float4 stores.  Head items are identical to the float32 kernel's.
+__global__ __launch_bounds__(256) void encode_shot_f16_kernel(const float* __restrict__ pts,
+                                                              const float* __restrict__ nrm,
+                                                              const __half* __restrict__ feat, int feat_dim,
+                                                              const int32_t* __restrict__ idx, int k_rt,
+                                                              const int32_t* __restrict__ pt_off,
+                                                              const int32_t* __restrict__ tup_off, ComboTable cb,
+                                                              float* __restrict__ out) {
+  const unsigned b = blockIdx.y, bx = blockIdx.x, bps = gridDim.x;
+  const int p0 = pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const unsigned k = (unsigned)k_rt, fvec = (unsigned)feat_dim >> 3;       // 8-half groups per feature row
+  const unsigned np = k * (k - 1) / 2, head = 4 * np, row_len = head + k * (unsigned)feat_dim;
+  const unsigned feat_vec = k * fvec;
+  const unsigned n_head = (unsigned)nt * np, n_all = n_head + (unsigned)nt * feat_vec;
+  for (unsigned v = bx * blockDim.x + threadIdx.x; v < n_all; v += bps * blockDim.x) {
+    if (v >= n_head) {
+      const unsigned w = v - n_head, t = w / feat_vec, c = w - t * feat_vec;
+      const unsigned kk = c / fvec, col = (c - kk * fvec) << 3;
+      const int64_t row = (int64_t)t0 + t;
+      const uint4 raw = *reinterpret_cast<const uint4*>(feat + (int64_t)(p0 + idx[row * k + kk]) * feat_dim + col);
+      const __half2* h2 = reinterpret_cast<const __half2*>(&raw);
+      const float2 f0 = __half22float2(h2[0]), f1 = __half22float2(h2[1]), f2 = __half22float2(h2[2]),
+                   f3 = __half22float2(h2[3]);
+      float* dst = out + row * row_len + head + kk * feat_dim + col;
+      store_stream(dst, make_float4(f0.x, f0.y, f1.x, f1.y));
+      store_stream(dst + 4, make_float4(f2.x, f2.y, f3.x, f3.y));
+    } else {
+      const unsigned t = v / np, c = v - t * np;
+      const int64_t row = (int64_t)t0 + t;
+      const int32_t* row_idx = idx + row * k;
+      float4 o;
+      o.x = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 0), cb);
+      o.y = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 1), cb);
+      o.z = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 2), cb);
+      o.w = encode_scalar(pts, nrm, row_idx, p0, (int)np, (int)(4 * c + 3), cb);
+      store_stream(out + row * row_len + 4 * c, o);
+    }
+  }
+}
+
+extern "C" int cppf_encode_tuples_shot_f16(int B, const float* pts, const float* normals, const void* feat_half,
+                                           int feat_dim, const int32_t* idx, int k, const int32_t* pt_off,
+                                           const int32_t* tup_off, int64_t total_tuples, float* out, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && normals && feat_half && idx && pt_off && tup_off && out);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  CPPF_CHECK_ARG(feat_dim > 0 && feat_dim % 8 == 0);
+  if (total_tuples <= 0) return CPPF_OK;
+  const int np = k * (k - 1) / 2;
+  const int64_t per_scene = (total_tuples + B - 1) / B * (np + k * (feat_dim / 8));
+  if (per_scene >= 0x7fffffffLL) return CPPF_EUNSUPPORTED;
+  int64_t bx = (per_scene + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(encode_shot_f16_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals,
+                     (const __half*)feat_half, feat_dim, idx, k, pt_off, tup_off, make_combos(k), out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
 }
 
 extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* normals, const float* feat,

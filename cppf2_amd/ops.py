@@ -236,7 +236,8 @@ def encode_tuples_shot(points, point_idxs_all, shot_feat, normal, pt_off=None, t
     dev = _dev()
     pts = _t(points, torch.float32, dev)
     idx = _t(point_idxs_all, torch.int32, dev)
-    feat = _t(shot_feat, torch.float32, dev)
+    half = isinstance(shot_feat, torch.Tensor) and shot_feat.dtype == torch.float16
+    feat = _t(shot_feat, torch.float16 if half else torch.float32, dev)
     nrm = _t(normal, torch.float32, dev)
     T, k = idx.shape
     F = feat.shape[1]
@@ -244,6 +245,10 @@ def encode_tuples_shot(points, point_idxs_all, shot_feat, normal, pt_off=None, t
     if pt_off is None:
         pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
     out = torch.empty((T, k * (k - 1) // 2 * 4 + k * F), dtype=torch.float32, device=dev)
+    if half:      # float16 feature table (BASELINE config 5): same layout, float32 rows out
+        _lib.check(_L.cppf_encode_tuples_shot_f16(B, _p(pts), _p(nrm), _p(feat), F, _p(idx), k, _p(pt_off), _p(tup_off),
+                                                  T, _p(out), _stream()), "cppf_encode_tuples_shot_f16")
+        return out
     _lib.check(_L.cppf_encode_tuples_shot(B, _p(pts), _p(nrm), _p(feat), F, _p(idx), k, _p(pt_off), _p(tup_off), T,
                                           _p(out), _stream()), "cppf_encode_tuples_shot")
     return out

@@ -114,6 +114,11 @@ int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_
 int cppf_encode_tuples_shot(int B, const float* pts, const float* normals, const float* feat, int feat_dim,
                             const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                             int64_t total_tuples, float* out, void* stream);
+/* Same row layout from a half-precision feature table (float16 [n, feat_dim], feat_dim % 8 == 0), float32 output
+ * (BASELINE config 5, "fp16 features"; not in the reference -- equals the float32 entry on half-rounded features). */
+int cppf_encode_tuples_shot_f16(int B, const float* pts, const float* normals, const void* feat_half, int feat_dim,
+                                const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                                int64_t total_tuples, float* out, void* stream);
 int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
                              const int32_t* tup_off, int64_t total_tuples, float* out, int out_stride,
                              void* stream);

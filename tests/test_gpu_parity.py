@@ -363,3 +363,36 @@ def test_weighted_centre_votes_extension(full_summary, mode):
     gw, cw = ops.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, mode=mode, weights=w)
     go, co = O.vote_center(pc, tr, 2e-3, idx[:, :2], f["R"], trig=trig, weights=w)
     assert np.array_equal(gw, go) and np.array_equal(cw, co)
+
+
+def test_encode_fp16_feature_table_extension(small):
+    """BASELINE config 5 "fp16 features": rows built from a float16 table equal the float32 path on the rounded table."""
+    feat16 = torch.from_numpy(small["small_feat"]).half()
+    got = ops.encode_tuples_shot(small["small_pc"], small["small_idx"], feat16.cuda(), small["small_normal"]).cpu().numpy()
+    want = O.prepare_tuple_inputs_shot(small["small_pc"], small["small_idx"], feat16.float().numpy(), small["small_normal"])
+    assert np.array_equal(got, want)
+
+
+def test_dense_pairs_65536_properties():
+    """BASELINE config 5 size (64 k pairs / scene): accumulation strategies agree cell for cell and the lookup-table
+    rotation search equals the exhaustive one."""
+    rng = np.random.RandomState(2)
+    N, T, R = 2048, 65536, 90
+    sc, idx, lg, u = (lambda s: (s, synth.host_sample_tuples(11, 0, T, 5, N), None, None))(synth.make_scene(11, 0, N))
+    lg = synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6).astype(np.float32)
+    u = O.philox_uniform(11, 0, 1, T, 6)
+    pipe = VotingPipeline([N], [T], num_rots=R)
+    pts, di = dev(sc["pc"], torch.float32), dev(idx, torch.int32)
+    pipe.decode(pts, di, dev(lg, torch.float32), dev(u, torch.float32))
+    tr = pipe.tr.cpu().numpy()
+    g1, c1 = ops.vote_center(sc["pc"], tr, 2e-3, idx[:, :2], R, mode=1)
+    g2, c2 = ops.vote_center(sc["pc"], tr, 2e-3, idx[:, :2], R, mode=2)
+    assert np.array_equal(g1, g2) and np.array_equal(c1, c2)
+    pipe.vote_center(pts, di)
+    assert int(pipe.argmax.item()) == int(np.argmax(g1)) and np.linalg.norm(c1 - sc["t"]) < 5e-3
+    pipe.backvote(pts, di)
+    assert int(pipe.kept_count.item()) in (6553, 6554)
+    pipe.rot_bins(pts, di, use_lut=False)
+    dense = pipe.counts.cpu().numpy().copy()
+    pipe.rot_bins(pts, di, use_lut=True)
+    assert np.array_equal(dense, pipe.counts.cpu().numpy())
