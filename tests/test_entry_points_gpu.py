@@ -137,3 +137,24 @@ def test_hip_graph_replay_of_the_vote_pipeline():
     got = replay()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_integration_md_raw_binding_snippet_runs(small):
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed verbatim (library path substituted) and must
+    reproduce the packaged ops: the documentation cannot drift from the ABI."""
+    import re
+    from cppf2_amd import _lib, ops, shot
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.findall(r"## 2\..*?```python\n(.*?)```", md, flags=re.S)[0]
+    code = code.replace('C.CDLL("libcppf_hip.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    pc = torch.from_numpy(small["small_pc"]).cuda()
+    tr = torch.from_numpy(small["small_tr0"]).cuda()
+    idx = torch.from_numpy(small["small_idx"][:, :2]).cuda()
+    g1, c1 = ns["vote_center"](pc, tr, 2e-3, idx, 36)
+    g2, c2 = ops.vote_center(pc, tr, 2e-3, idx, 36)
+    assert np.array_equal(g1, g2) and np.array_equal(c1, c2)
+    a = ns["compute"](small["small_pc"], 0.02, 0.02)
+    b = shot.compute(small["small_pc"], 0.02, 0.02)
+    assert np.allclose(a[0], b[0], atol=1e-6, equal_nan=True) and np.allclose(a[1], b[1], atol=1e-7, equal_nan=True)
