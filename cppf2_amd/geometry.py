@@ -1,5 +1,6 @@
-"""Host-side steps either side of the hot path (SURVEY.md section 8f "next" rows, NumPy for now):
-back-projection of a masked depth map and the voxel down-sample that feeds the voting path."""
+"""NumPy restatements of the steps in front of the hot path: back-projection of a masked
+depth map and the voxel down-sample.  The product path uses the HIP kernels (cppf2_amd.ops.backproject / downsample);
+these stay as the checkers the tests pin to the reference, plus the pose-error helper."""
 from __future__ import annotations
 
 import numpy as np

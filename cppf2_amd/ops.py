@@ -410,3 +410,48 @@ def get_topk_dir(pred, sphere_pts, bmm_size, angle_tol, wt=None, topk=1):
     topk_idx = torch.topk(counts, topk)[1].cpu().numpy()
     sphere_np = np.asarray(sphere_pts)
     return np.array(sphere_np[topk_idx]), counts.cpu().numpy()[topk_idx]
+
+
+# ----------------------------------------------------------------------------------------------
+# steps in front of the path
+# ----------------------------------------------------------------------------------------------
+def backproject(depth, intrinsics, instance_mask, return_device=False):
+    """Masked depth map -> float32 camera-frame points on the GPU: utils/util.py:2586-2607 followed by the sign flip
+    and float32 cast every caller applies (eval.py:185-189), i.e. the cloud eval.py actually uses.  Pixel order is
+    np.where's (row-major).  Returns (pc float32[n,3], (rows, cols)); NumPy arrays unless return_device."""
+    dev = _dev()
+    d = _t(depth, torch.float32, dev)
+    m = _t(np.asarray(instance_mask) != 0 if not isinstance(instance_mask, torch.Tensor) else instance_mask != 0,
+           torch.uint8, dev)
+    if d.dim() != 2 or d.shape != m.shape:
+        raise CppfError("backproject: depth and mask must be 2-D and of equal shape")
+    H, W = d.shape
+    kinv = (C.c_double * 9)(*np.linalg.inv(np.asarray(intrinsics, dtype=np.float64).reshape(3, 3)).reshape(9))
+    cap = H * W
+    pts = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    rc = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_L.cppf_backproject(_p(d), _p(m), H, W, kinv, cap, _p(pts), _p(rc), _p(cnt), _stream()),
+               "cppf_backproject")
+    n = int(cnt.item())
+    pts, rc = pts[:n], rc[:n]
+    if return_device:
+        return pts, (rc[:, 0], rc[:, 1])
+    rc = rc.cpu().numpy().astype(np.int64)
+    return pts.cpu().numpy(), (rc[:, 0], rc[:, 1])
+
+
+def downsample(pc, res, seed=0, return_device=False):
+    """Indices of one uniformly random point per `res` voxel (utils/util.py:39-46), ascending.  The draw is
+    Philox(seed, point index) instead of NumPy's global RandomState, so it is reproducible on any device."""
+    dev = _dev()
+    pts = _t(pc, torch.float32, dev).reshape(-1, 3)
+    n = pts.shape[0]
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = _L.cppf_voxel_downsample_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    _lib.check(_L.cppf_voxel_downsample(_p(pts), n, float(res), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(idx), _p(cnt),
+                                        _p(ws), wsb, _stream()), "cppf_voxel_downsample")
+    idx = idx[: int(cnt.item())].long()
+    return idx if return_device else idx.cpu().numpy()

@@ -73,11 +73,8 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         m = (m[..., 0] if m.ndim == 3 else m) > 0
         K = np.array(intrinsics if intrinsics is not None else
                      [[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float64).reshape(3, 3)
-        pc, _ = geometry.backproject(d, K, m)
-        pc[:, 0] = -pc[:, 0]
-        pc[:, 1] = -pc[:, 1]                                                   # eval.py:187-188
-        pc = pc.astype(np.float32)
-        pc = pc[geometry.downsample(pc, cfg.res, np.random.RandomState(seed))]  # eval.py:192
+        pc, _ = ops.backproject(d, K, m, return_device=True)               # eval.py:185-189 (flip + f32 cast folded in)
+        pc = pc[ops.downsample(pc, cfg.res, seed, return_device=True)].cpu().numpy()   # eval.py:192
         if pc.shape[0] > 50000:
             pc = pc[np.random.RandomState(seed).randint(pc.shape[0], size=50000)]
         scenes = [dict(pc=pc, pc_canon=None, R=None, t=None)]

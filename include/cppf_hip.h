@@ -224,6 +224,21 @@ int cppf_assemble_pose(int B, const float* sphere, const int32_t* up_idx, const 
                        const int32_t* kept_tuple, const int32_t* kept_count,
                        CppfSceneResult* out, void* stream);
 
+/* ---- steps in front of the path ---------------------------------------------------------------
+ * Back-projection of a masked depth map: replaces backproject() (utils/util.py:2586-2607) + the sign flip and
+ * float32 cast at eval.py:185-189.  depth float32[H,W] in metres, mask uint8[H,W]; h_kinv = inverse intrinsics
+ * (9 doubles, host).  Pixels are emitted in row-major order (np.where order): out_pts float32[cap,3],
+ * out_rowcol int32[cap,2] (optional), out_count int32 (number of valid pixels; may exceed cap). */
+int cppf_backproject(const float* depth, const uint8_t* mask, int H, int W, const double* h_kinv, int cap,
+                     float* out_pts, int32_t* out_rowcol, int32_t* out_count, void* stream);
+/* One uniformly random point per `res` voxel (anchored at the cloud's min corner): replaces downsample()
+ * (utils/util.py:39-46, open3d voxel_down_sample_and_trace + np.random.choice).  The draw is Philox(seed, point
+ * index), so the kept set does not depend on thread order; out_idx int32[n] holds the kept point indices in
+ * ascending order, out_count their number. */
+int64_t cppf_voxel_downsample_workspace_bytes(int64_t n);
+int cppf_voxel_downsample(const float* pts, int n, float res, uint64_t seed, int32_t* out_idx, int32_t* out_count,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

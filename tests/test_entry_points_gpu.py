@@ -158,3 +158,76 @@ def test_integration_md_raw_binding_snippet_runs(small):
     a = ns["compute"](small["small_pc"], 0.02, 0.02)
     b = shot.compute(small["small_pc"], 0.02, 0.02)
     assert np.allclose(a[0], b[0], atol=1e-6, equal_nan=True) and np.allclose(a[1], b[1], atol=1e-7, equal_nan=True)
+
+
+def _example_inputs():
+    import json
+    from PIL import Image
+    e = json.load(open(os.path.join(GOLDEN, "full_summary.json")))["example_backproject"]
+    d = np.array(Image.open(os.path.join(GOLDEN, "example_data", "depth.png"))).astype(np.float64) / e["depth_scale"]
+    m = np.array(Image.open(os.path.join(GOLDEN, "example_data", "mask.png")))
+    m = (m[..., 0] if m.ndim == 3 else m) > 0
+    return e, d, m, np.array(e["K"])
+
+
+def test_backproject_kernel_matches_the_reference_pinned_host_path():
+    """cppf_backproject == utils/util.py:2586-2607 + eval.py:185-189 on the reference's example scene.  The host
+    restatement (geometry.backproject) is pinned to the reference's float64 output by SHA in test_host_logic; the
+    kernel must reproduce its float32 cast bit for bit, in np.where order."""
+    import hashlib
+    from cppf2_amd import geometry, ops
+    e, d, m, K = _example_inputs()
+    want64, (rows, cols) = geometry.backproject(d, K, m)
+    assert hashlib.sha256(np.ascontiguousarray(want64).tobytes()).hexdigest() == e["sha"]
+    want = want64.copy()
+    want[:, :2] = -want[:, :2]
+    want = want.astype(np.float32)
+    got, (r, c) = ops.backproject(d.astype(np.float32), K, m)
+    assert got.shape == (e["n"], 3)
+    assert np.array_equal(r, rows) and np.array_equal(c, cols)
+    # depth is handed over as float32 metres: the kernel's z differs from the float64 path by that one rounding
+    z32 = d.astype(np.float32)[rows, cols]
+    assert np.array_equal(got[:, 2], z32)
+    rel = np.abs(got.astype(np.float64) - want) / np.abs(want).max()
+    assert rel.max() < 2.5e-7
+    # and it is bit-exact against the same float64 arithmetic fed the float32 depth
+    w2, _ = geometry.backproject(d.astype(np.float32).astype(np.float64), K, m)
+    w2[:, :2] = -w2[:, :2]
+    assert np.array_equal(got, w2.astype(np.float32))
+
+
+def test_voxel_downsample_kernel_keeps_one_random_point_per_voxel():
+    from cppf2_amd import geometry, ops
+    e, d, m, K = _example_inputs()
+    pc, _ = ops.backproject(d.astype(np.float32), K, m)
+    res = 0.004
+    key = np.floor((pc - pc.min(0)) / np.float32(res)).astype(np.int64)
+    flat = (key[:, 0] << 42) | (key[:, 1] << 21) | key[:, 2]
+    nvox = len(np.unique(flat))
+    assert nvox == len(geometry.downsample(pc, res, np.random.RandomState(0)))      # same voxelisation as the host helper
+    a = ops.downsample(pc, res, seed=5)
+    assert len(a) == nvox and np.all(np.diff(a) > 0)                                # ascending, unique
+    assert len(np.unique(flat[a])) == nvox                                          # exactly one per occupied voxel
+    assert np.array_equal(a, ops.downsample(pc, res, seed=5))                       # reproducible
+    b = ops.downsample(pc, res, seed=6)
+    assert len(b) == nvox and not np.array_equal(a, b)                              # the draw depends on the seed
+    # uniform within the voxel: over many seeds, the rank of the kept point inside its voxel is ~uniform
+    order = np.argsort(flat, kind="stable")
+    sf = flat[order]
+    starts = np.flatnonzero(np.r_[True, sf[1:] != sf[:-1]])
+    cnt = np.diff(np.r_[starts, len(sf)])
+    big = np.flatnonzero(cnt >= 4)
+    rank_of = np.empty(len(pc), np.int64)
+    rank_of[order] = np.arange(len(pc)) - np.repeat(starts, cnt)
+    cnt_of = np.empty(len(pc), np.int64)
+    cnt_of[order] = np.repeat(cnt, cnt)
+    u = []
+    for s in range(8):
+        k = ops.downsample(pc, res, seed=100 + s)
+        k = k[cnt_of[k] >= 4]
+        u.append((rank_of[k] + 0.5) / cnt_of[k])
+    u = np.concatenate(u)
+    assert len(big) > 100 and abs(u.mean() - 0.5) < 0.02 and abs((u < 0.25).mean() - 0.25) < 0.03
+    # degenerate inputs
+    assert len(ops.downsample(np.zeros((0, 3), np.float32), res)) == 0
+    assert list(ops.downsample(np.ones((7, 3), np.float32), res)) in [[i] for i in range(7)]
