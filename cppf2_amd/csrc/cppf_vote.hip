@@ -209,6 +209,72 @@ __device__ __forceinline__ ArcSet slab_arcs(float cx, float invA, float phi, flo
   return o;
 }
 
+// ---- wavefront scans on the DPP cross-lane path (no LDS round trip): Hillis-Steele inside each row of 16 lanes
+// (row_shr 1,2,4,8), then the row totals ripple with row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3).
+#define VC_DPP(x, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (x), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+  x += VC_DPP(x, 0x111, 0xf);
+  x += VC_DPP(x, 0x112, 0xf);
+  x += VC_DPP(x, 0x114, 0xf);
+  x += VC_DPP(x, 0x118, 0xf);
+  x += VC_DPP(x, 0x142, 0xa);
+  x += VC_DPP(x, 0x143, 0xc);
+  return x;
+}
+__device__ __forceinline__ int wave_incl_scan_max(int x) {   // values >= 0
+  x = max(x, VC_DPP(x, 0x111, 0xf));
+  x = max(x, VC_DPP(x, 0x112, 0xf));
+  x = max(x, VC_DPP(x, 0x114, 0xf));
+  x = max(x, VC_DPP(x, 0x118, 0xf));
+  x = max(x, VC_DPP(x, 0x142, 0xa));
+  x = max(x, VC_DPP(x, 0x143, 0xc));
+  return x;
+}
+
+typedef float vc_f2 __attribute__((ext_vector_type(2)));
+
+struct GridFast {
+  float c0x, res, rinv, hm;     // hm = 0.5 - rounding margin
+  vc_f2 c0yz;
+  int gx, gy, gz;
+};
+
+// Flat cell of one vote on the fast path, or a negative value; `sure` is cleared when the caller has to redo the vote
+// with vote_cell_exact below.  Same decision procedure as cell_fast above (multiply by the rounded reciprocal;
+// whenever a coordinate lands within the rounding margin of a cell boundary -- or is NaN / huge -- the exact IEEE
+// divisions decide), arranged branch-free for the packed-fp32 pipe: y and z travel as one register pair.  x is
+// clamped to [0, gx] instead of tested: x-layer 0 and layer gx fall outside every slab's valid window (lo_eff in the
+// kernel), which is where the reference's `> 0` / `< grid_res` tests put them.
+__device__ __forceinline__ int vote_cell_packed(float cx, vc_f2 cyz, float xx, vc_f2 xyz, float yx, vc_f2 yyz,
+                                                float cs, float sn, const GridFast& gc, bool& sure) {
+  const float ox = cs * xx + sn * yx;
+  const vc_f2 oyz = cs * xyz + sn * yyz;
+  const float nx = (cx + ox) - gc.c0x;
+  const vc_f2 nyz = (cyz + oyz) - gc.c0yz;
+  const float tx = fmaf(nx, gc.rinv, 0.5f);
+  const float ty = fmaf(nyz.x, gc.rinv, 0.5f), tz = fmaf(nyz.y, gc.rinv, 0.5f);
+  const float e = fmaxf(fmaxf(fabsf(__builtin_amdgcn_fractf(tx) - 0.5f), fabsf(__builtin_amdgcn_fractf(ty) - 0.5f)),
+                        fabsf(__builtin_amdgcn_fractf(tz) - 0.5f));
+  sure = e <= gc.hm;
+  // floor + convert in one instruction each; x clamped with one median; 24-bit multiply-adds (see `narrow`)
+  int ix, iy, iz, lin;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(tx));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(ty));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(tz));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(ix) : "v"(ix), "s"(gc.gx));
+  const bool ok = ((unsigned)(iy - 1) < (unsigned)(gc.gy - 1)) & ((unsigned)(iz - 1) < (unsigned)(gc.gz - 1));
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(ix), "s"(gc.gy), "v"(iy));
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(lin), "s"(gc.gz), "v"(iz));
+  return ok ? lin : -1;
+}
+
+// the same vote with the reference's arithmetic (train_dino.py:195-203)
+__device__ __noinline__ int vote_cell_exact(float cx, vc_f2 cyz, float xx, vc_f2 xyz, float yx, vc_f2 yyz, float cs,
+                                            float sn, const GridFast& gc) {
+  return vote_cell(cx, cyz.x, cyz.y, xx, xyz.x, xyz.y, yx, yyz.x, yyz.y, cs, sn, gc.c0x, gc.c0yz.x, gc.c0yz.y, gc.res,
+                   gc.gx, gc.gy, gc.gz);
+}
+
 __device__ __forceinline__ float bcast_f(float x, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
 }
@@ -221,6 +287,10 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
     SlabBest* __restrict__ slab_best, int s_max, int P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
   float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
+  // per-wavefront strip of 64 owner marks (ARCS only), behind the largest table the arcs path accepts
+  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
+                         (threadIdx.x >> 6) * 64;
+  int tag = 0;
   // grid = (scene, P, slab rank): the slab rank is the slowest dimension of the dispatch order
   const int pc = blockIdx.y, rank = blockIdx.z;
   // workgroup id % 8 selects the XCD: rotating the scene by the slab rank spreads a scene's slabs (and the uneven
@@ -239,8 +309,13 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
   if (ARCS) {
     for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
+    s_mark[threadIdx.x & 63] = 0;
   }
   __syncthreads();
+#ifdef VC_DIAG
+  const long long t_a = wall_clock64();
+  int nwin = 0;
+#endif
 
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
   const int per = (nt + P - 1) / P;
@@ -253,69 +328,116 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   gc.gx = gx; gc.gy = gy; gc.gz = gz;
   const int gyz = gy * gz;
   const int xl = lo / gyz, xh = (lo + n - 1) / gyz;            // x-layers this slab touches
+  GridFast gf;
+  gf.c0x = c0x; gf.res = res; gf.rinv = gc.rinv; gf.c0yz.x = c0y; gf.c0yz.y = c0z;
+  gf.hm = 0.5f - fmaxf(gc.mx, fmaxf(gc.my, gc.mz));
+  gf.gx = gx; gf.gy = gy; gf.gz = gz;
+  // the packed cell index uses 24-bit multiplies: (gx + 1) * gy must stay below 2^23 (any grid the reference
+  // accepts, eval.py:200, is far below); wider grids take the exhaustive sweep with 32-bit arithmetic
+  const bool narrow = (int64_t)(gx + 1) * gy < (1 << 23) && gz < (1 << 23);
+  // valid cells of this slab: x-layer 0 is never a valid cell (train_dino.py:199 keeps indices > 0)
+  const int lo_eff = max(lo, gyz);
+  const unsigned n_eff = (lo + n > lo_eff) ? (unsigned)(lo + n - lo_eff) : 0u;
   const int lane = wave_lane();
-  for (int tb = ts; tb < te; tb += VC_THREADS) {
-    const int t = tb + threadIdx.x;
-    float cx = NAN, cy = 0, cz = 0, xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0, invA = 0, phi = 0;
-    uint32_t wv = 0;
-    if (t < te) {
-      const int64_t row = (int64_t)(t0 + t);
-      cx = fr[0 * total + row]; cy = fr[1 * total + row]; cz = fr[2 * total + row];
-      xx = fr[3 * total + row]; xy = fr[4 * total + row]; xz = fr[5 * total + row];
-      yx = fr[6 * total + row]; yy = fr[7 * total + row]; yz = fr[8 * total + row];
-      invA = fr[9 * total + row]; phi = fr[10 * total + row];
-      wv = __float_as_uint(fr[11 * total + row]);
-    }
-    if (ARCS) {
-      // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
-      // handful, many none), so the wavefront's 64 arcs are cut into quanta of VC_QUANTUM rotations and the
-      // quanta are dealt out evenly: lane l takes quantum q = base + l, finds its owner pair by binary search
-      // over the inclusive scan of quanta counts and pulls the owner's frame across lanes (ds_bpermute).
-      const ArcSet arcs = slab_arcs(cx, invA, phi, c0x, res, xl, xh, num_rots);
-      const int ntot = arcs.n0 + arcs.n1;
-      const int nq = (ntot + VC_QUANTUM - 1) / VC_QUANTUM;
-      int incl = nq;
+  // frames of the next block of pairs are requested before the current block is processed (register double buffer)
+  float nf[VC_FRAME_FLOATS];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
+  for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = (c == 0) ? NAN : 0.0f;
+  if (ts + (int)threadIdx.x < te) {
+#pragma unroll
+    for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = fr[c * total + (int64_t)(t0 + ts + (int)threadIdx.x)];
+  }
+  for (int tb = ts; tb < te; tb += VC_THREADS) {
+    const float cx = nf[0], cy = nf[1], cz = nf[2], xx = nf[3], xy = nf[4], xz = nf[5], yx = nf[6], yy = nf[7],
+                yz = nf[8], invA = nf[9], phi = nf[10];
+    const uint32_t wv = __float_as_uint(nf[11]);
+    {
+      const int tn = tb + VC_THREADS + (int)threadIdx.x;
+      if (tn < te) {
+#pragma unroll
+        for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = fr[c * total + (int64_t)(t0 + tn)];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = (c == 0) ? NAN : 0.0f;
       }
+    }
+    if (ARCS && narrow) {
+      // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
+      // handful, many none), so the wavefront's arcs are cut into quanta of VC_QUANTUM rotations (never straddling
+      // the two arcs of a pair) and the quanta are dealt out evenly, 64 at a time: lane l of window w takes quantum
+      // 64 w + l.  Its owner pair is found without a search: every owner drops (window tag | lane id) at the window
+      // slot of its first quantum in a 64-entry LDS strip, and a DPP max-scan of the strip spreads it over the
+      // owner's quanta (stale entries of older windows carry smaller tags, so the strip is never cleared).  The
+      // owner's frame then comes across lanes with ds_bpermute.
+      ArcSet arcs = slab_arcs(cx, invA, phi, c0x, res, xl, xh, num_rots);
+      arcs.a0 += (arcs.a0 < 0) ? num_rots : 0; arcs.a0 += (arcs.a0 < 0) ? num_rots : 0;
+      arcs.a0 -= (arcs.a0 >= num_rots) ? num_rots : 0; arcs.a0 -= (arcs.a0 >= num_rots) ? num_rots : 0;
+      arcs.a1 += (arcs.a1 < 0) ? num_rots : 0; arcs.a1 += (arcs.a1 < 0) ? num_rots : 0;
+      arcs.a1 -= (arcs.a1 >= num_rots) ? num_rots : 0; arcs.a1 -= (arcs.a1 >= num_rots) ? num_rots : 0;
+      const int nq0 = (arcs.n0 + VC_QUANTUM - 1) / VC_QUANTUM;
+      const int nq = nq0 + (arcs.n1 + VC_QUANTUM - 1) / VC_QUANTUM;
+      const int pk0 = arcs.a0 | (arcs.n0 << 10) | (nq0 << 21);       // a < 1024, n <= 1024, nq0 <= 1024
+      const int pk1 = arcs.a1 | (arcs.n1 << 10);
+      const int incl = wave_incl_scan_add(nq);
       const int excl = incl - nq;
       const int WQ = __builtin_amdgcn_readlane(incl, 63);
+      const vc_f2 cyz = {cy, cz}, xyz = {xy, xz}, yyz = {yy, yz};
       for (int qb = 0; qb < WQ; qb += 64) {
-        const int q = qb + lane;
-        int pos = 0;                                  // number of lanes whose quanta all precede q
-#pragma unroll
-        for (int st = 32; st >= 1; st >>= 1) {
-          const int val = __shfl(incl, pos + st - 1);
-          pos += (val <= q) ? st : 0;
-        }
-        const int src = min(pos, 63);
-        const int j0 = (q - __shfl(excl, src)) * VC_QUANTUM;
-        const float ocx = __shfl(cx, src), ocy = __shfl(cy, src), ocz = __shfl(cz, src);
-        const float oxx = __shfl(xx, src), oxy = __shfl(xy, src), oxz = __shfl(xz, src);
-        const float oyx = __shfl(yx, src), oyy = __shfl(yy, src), oyz = __shfl(yz, src);
-        const int oa0 = __shfl(arcs.a0, src), on0 = __shfl(arcs.n0, src), oa1 = __shfl(arcs.a1, src);
-        // NB every cross-lane read sits in wave-uniform control flow: ds_bpermute returns 0 for a source lane
-        // that is masked off, so a shuffle under `if (q < WQ)` would lose the quanta owned by idle lanes.
-        const int ont_all = __shfl(ntot, src);
+        tag += 64;
+#ifdef VC_DIAG
+        ++nwin;
+#endif
+        const int first = __popcll(__ballot(incl <= qb));            // owner of quantum qb (< 64 because qb < WQ)
+        const unsigned wslot = (unsigned)(excl - qb);
+        if (nq > 0 && wslot < 64u) s_mark[wslot] = tag | lane;
+        __builtin_amdgcn_wave_barrier();
+        int m = s_mark[lane];
+        __builtin_amdgcn_wave_barrier();
+        m = (lane == 0) ? (tag | first) : m;
+        const int src = wave_incl_scan_max(m) & 63;
+        const float ocx = __shfl(cx, src), oxx = __shfl(xx, src), oyx = __shfl(yx, src);
+        vc_f2 ocyz, oxyz, oyyz;
+        ocyz.x = __shfl(cyz.x, src); ocyz.y = __shfl(cyz.y, src);
+        oxyz.x = __shfl(xyz.x, src); oxyz.y = __shfl(xyz.y, src);
+        oyyz.x = __shfl(yyz.x, src); oyyz.y = __shfl(yyz.y, src);
+        const int opk0 = __shfl(pk0, src), opk1 = __shfl(pk1, src);
+        const int ql = qb + lane - __shfl(excl, src);                 // quantum index inside the owner
         const uint32_t owv = (uint32_t)__shfl((int)wv, src);
-        const int ont = (q < WQ) ? ont_all : 0;
+        const int onq0 = opk0 >> 21;
+        const bool second = ql >= onq0;
+        const int qa = (second ? ql - onq0 : ql) * VC_QUANTUM;
+        const int opk = second ? opk1 : opk0;
+        int rr = (opk & 1023) + qa;                                   // < 2 R
+        rr -= (rr >= num_rots) ? num_rots : 0;
+        int len = ((opk >> 10) & 2047) - qa;
+        len = (qb + lane < WQ) ? len : 0;
+        // the quantum's rotations are independent: table reads first, then all cells branch-free (so the
+        // compiler interleaves them), the rare boundary cases redone exactly, then the counters
+        float2 tg[VC_QUANTUM];
 #pragma unroll
         for (int jj = 0; jj < VC_QUANTUM; ++jj) {
-          const int j = j0 + jj;
-          if (j < ont) {
-            int rr = (j < on0) ? oa0 + j : oa1 + (j - on0);   // in (-2R, 3R): fold without an integer division
-            rr += (rr < 0) ? num_rots : 0;
-            rr += (rr < 0) ? num_rots : 0;
-            rr -= (rr >= num_rots) ? num_rots : 0;
-            rr -= (rr >= num_rots) ? num_rots : 0;
-            const float2 tg = s_trig[rr];
-            const int lin = vote_cell_fast(ocx, ocy, ocz, oxx, oxy, oxz, oyx, oyy, oyz, tg.x, tg.y, gc);
-            const unsigned rel = (unsigned)(lin - lo);
-            if (lin >= 0 && rel < (unsigned)n) atomicAdd(&slab[rel], owv);
-          }
+          tg[jj] = s_trig[rr];
+          ++rr;
+          rr = (rr == num_rots) ? 0 : rr;
         }
+        int lin[VC_QUANTUM];
+        unsigned redo = 0;
+#pragma unroll
+        for (int jj = 0; jj < VC_QUANTUM; ++jj) {
+          bool sure;
+          const int l = vote_cell_packed(ocx, ocyz, oxx, oxyz, oyx, oyyz, tg[jj].x, tg[jj].y, gf, sure);
+          lin[jj] = (jj < len) ? l : -1;
+          redo |= (jj < len && !sure) ? (1u << jj) : 0u;
+        }
+        if (__builtin_expect(redo != 0, 0)) {
+#pragma unroll
+          for (int jj = 0; jj < VC_QUANTUM; ++jj)
+            if (redo & (1u << jj))
+              lin[jj] = vote_cell_exact(ocx, ocyz, oxx, oxyz, oyx, oyyz, tg[jj].x, tg[jj].y, gf);
+        }
+#pragma unroll
+        for (int jj = 0; jj < VC_QUANTUM; ++jj)
+          if ((unsigned)(lin[jj] - lo_eff) < n_eff) atomicAdd(&slab[lin[jj] - lo], owv);
       }
     } else if (cx == cx) {
       for (int r = 0; r < num_rots; ++r) {
@@ -327,6 +449,9 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
     }
   }
   __syncthreads();
+#ifdef VC_DIAG
+  const long long t_b = wall_clock64();
+#endif
 
   const int64_t goff = grid ? (grid_off ? grid_off[b] : (int64_t)b * cells_cap) : 0;
   if (P == 1) {
@@ -346,6 +471,12 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
       for (int w = 1; w < VC_THREADS / 64; ++w) argmax_combine(bv, bi, s_v[w], s_i[w]);
       SlabBest o; o.idx = bi; o.val = bv;
       o.pad = (uint32_t)(wall_clock64() - t_start);     // workgroup duration in 100 MHz ticks (diagnostics)
+#ifdef VC_DIAG
+      if (VC_DIAG == 1) o.pad = (uint32_t)(t_a - t_start);
+      if (VC_DIAG == 2) o.pad = (uint32_t)(t_b - t_a);
+      if (VC_DIAG == 3) o.pad = (uint32_t)(wall_clock64() - t_b);
+      if (VC_DIAG == 4) o.pad = (uint32_t)nwin * 100;
+#endif
       slab_best[(int64_t)b * s_max + s] = o;
     }
   } else {
@@ -502,7 +633,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       if (P > pmax) P = pmax;
       if (P < 1) P = 1;
     }
-    const int lds_bytes = VC_SLAB_CELLS * 4 + 2 * VC_MAX_LDS_ROTS * 4;
+    const int lds_bytes = VC_SLAB_CELLS * 4 + 2 * VC_MAX_LDS_ROTS * 4 + (VC_THREADS / 64) * 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
       CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<true>,

@@ -47,3 +47,30 @@ if stage == "vote_center" and mode in (0, 1):
     print("WGs", len(durs), "dur us: mean %.0f  p50 %.0f  p90 %.0f  max %.0f  sum/256 %.0f" % (durs.mean(), np.median(durs), np.percentile(durs, 90), durs.max(), durs.sum() / 256))
     b0 = raw[0, :nsl[0], 3] / 100.0
     print("scene0 per-slab us:", np.round(b0).astype(int).tolist())
+    # list-scheduling replay of the dispatch: WG id = rank * B + bx -> XCD id % 8, 32 CUs per XCD, greedy
+    import heapq
+    smax = int(nsl.max())
+    order = []
+    for rank in range(smax):
+        for bx in range(B):
+            b = (bx + rank) % B
+            if rank < nsl[b]:
+                mid = nsl[b] >> 1; dd = (rank + 1) >> 1
+                s = mid - dd if (rank & 1) else mid + dd
+                order.append((rank * B + bx, raw[b, s, 3] / 100.0))
+            else:
+                order.append((rank * B + bx, 0.5))
+    xcd = [[0.0] * 32 for _ in range(8)]
+    for h in xcd: heapq.heapify(h)
+    for wid, d in order:
+        h = xcd[wid % 8]
+        t = heapq.heappop(h); heapq.heappush(h, t + d)
+    print("replay makespan per XCD:", [int(max(h)) for h in xcd], " global greedy:", end=" ")
+    h = [0.0] * 256; heapq.heapify(h)
+    for wid, d in order:
+        t = heapq.heappop(h); heapq.heappush(h, t + d)
+    print(int(max(h)), " LPT:", end=" ")
+    h = [0.0] * 256; heapq.heapify(h)
+    for d in sorted([d for _, d in order], reverse=True):
+        t = heapq.heappop(h); heapq.heappush(h, t + d)
+    print(int(max(h)))
