@@ -20,7 +20,16 @@
 #define SHOT_LEN 352
 #define NR_BINS 10
 #define MAX_SECTORS 32
+#ifndef SH_LCAP
 #define SH_LCAP 1024      // neighbour-list capacity per query (falls back to a full rescan above it)
+#endif
+// The histogram is kept in SH_COPIES lane-interleaved copies: neighbouring lanes hold spatially neighbouring points,
+// which fall into the same bins, and LDS atomics on one address serialise (measured: ~50 passes per ds_add_f32 with
+// a single copy).  Odd stride: the copies start in different banks.
+#ifndef SH_COPIES
+#define SH_COPIES 1
+#endif
+#define SH_STRIDE 353
 
 __device__ __forceinline__ int find_scene_pt(const int32_t* __restrict__ off, int B, int i) {
   int lo = 0, hi = B;
@@ -117,103 +126,95 @@ __device__ __forceinline__ float sqdist3(float px, float py, float pz, float qx,
 #define RAD_135 2.3561944901923449288469825374596
 #define RAD_PI_7_8 2.7488935718910690836548129603691
 
-// Per-neighbour interpolation arithmetic type.  PCL 1.9.1 evaluates it in double and rounds every addend to float
-// when it is accumulated; the default here is float with the two angles taken from atan2 (accurate at the poles,
-// where acosf of a float cosine is not), which differs from the double evaluation by ~1e-7 per addend -- the size
-// of the float rounding PCL applies to the same addends -- and costs a third of the instructions on the GPU
-// (float64 runs at half rate and its acos/atan2 are ~5x longer).  -DSHOT_REAL=double restores the double path.
-#ifndef SHOT_REAL
-#define SHOT_REAL float
-#endif
-typedef SHOT_REAL real_t;
-
-__device__ __forceinline__ real_t r_inclination(real_t zf, real_t rho, real_t distance) {
-  if (sizeof(real_t) == 8) {
-    double c = (double)zf / (double)distance;
-    c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
-    return (real_t)acos(c);
-  }
-  return (real_t)atan2f((float)rho, (float)zf);      // in [0, pi], well conditioned everywhere
-}
-__device__ __forceinline__ real_t r_atan2(real_t y, real_t x) {
-  return sizeof(real_t) == 8 ? (real_t)atan2((double)y, (double)x) : (real_t)atan2f((float)y, (float)x);
-}
-__device__ __forceinline__ real_t r_sqrt(real_t x) {
-  return sizeof(real_t) == 8 ? (real_t)sqrt((double)x) : (real_t)__builtin_sqrtf((float)x);
+// atan2 for the two interpolation angles: octant reduction + degree-8 polynomial in t^2 (near-minimax fit of
+// atan(t)/t on [0, 1], max abs error 1.3e-7 rad evaluated in float = the rounding of the result itself), one v_rcp.
+// Inputs are never both zero here (magnitudes below 1e-30 were flushed and the caller tests the pair).
+__device__ __forceinline__ float shot_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float s = t * t;
+  float p = 0.0028340641874819994f;
+  p = fmaf(p, s, -0.016005029901862144f);
+  p = fmaf(p, s, 0.042587608098983765f);
+  p = fmaf(p, s, -0.07495445758104324f);
+  p = fmaf(p, s, 0.10636754333972931f);
+  p = fmaf(p, s, -0.14202570915222168f);
+  p = fmaf(p, s, 0.19992484152317047f);
+  p = fmaf(p, s, -0.3333306610584259f);
+  p = fmaf(p, s, 1.0f);
+  float r = p * t;
+  r = (ay > ax) ? 1.5707963267948966f - r : r;
+  r = (x < 0.0f) ? 3.141592653589793f - r : r;
+  return copysignf(r, y);
 }
 
+// One neighbour's quadrilinear contribution (pcl::SHOTEstimation::interpolateSingleChannel, PCL 1.9.1
+// features/impl/shot.hpp), float arithmetic, written without divergent arms: every interpolation axis (cosine bin,
+// radial shell, elevation, azimuth) yields one weight 1 - |d| for the home bin and one predicated atomic |d| for the
+// neighbouring bin; divisions by the constant bin widths are multiplications by their reciprocals and the two square
+// roots are the 1-ulp hardware ones.  The decisions (sector, shell, hemisphere, bin) are the reference's.
 __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, float qx, float qy, float qz, float d2,
-                                                float nqx, float nqy, float nqz, const float* rf, real_t radius,
-                                                float* shot) {
-  const real_t ONE = 1, HALF = (real_t)0.5;
+                                                float nqx, float nqy, float nqz, const float* rf, float radius,
+                                                uint32_t* shot, float fx_scale) {
   if (!isfinite(nqx) || !isfinite(nqy) || !isfinite(nqz)) return;
-  real_t cosd = (real_t)((nqx * rf[6] + nqy * rf[7]) + nqz * rf[8]);
-  if (cosd > ONE) cosd = ONE;
-  if (cosd < -ONE) cosd = -ONE;
-  real_t bin_distance = ((ONE + cosd) * NR_BINS) / 2;
-  const real_t distance = r_sqrt((real_t)d2);
-  if (fabs(distance) < (real_t)1e-15) return;
+  float cosd = (nqx * rf[6] + nqy * rf[7]) + nqz * rf[8];
+  cosd = fminf(fmaxf(cosd, -1.0f), 1.0f);
+  float bd = (1.0f + cosd) * (0.5f * NR_BINS);
+  const float distance = __builtin_amdgcn_sqrtf(d2);
+  if (distance < 1e-15f) return;
   const float dx = qx - px, dy = qy - py, dz = qz - pz;
-  real_t xf = (real_t)((dx * rf[0] + dy * rf[1]) + dz * rf[2]);
-  real_t yf = (real_t)((dx * rf[3] + dy * rf[4]) + dz * rf[5]);
-  real_t zf = (real_t)((dx * rf[6] + dy * rf[7]) + dz * rf[8]);
-  if (fabs(yf) < (real_t)1e-30) yf = 0;
-  if (fabs(xf) < (real_t)1e-30) xf = 0;
-  if (fabs(zf) < (real_t)1e-30) zf = 0;
-  const real_t r12 = radius / 2, r14 = radius / 4, r34 = radius * 3 / 4;
-  const int bit4 = ((yf > 0) || ((yf == 0) && (xf < 0))) ? 1 : 0;
-  const int bit3 = ((xf > 0) || ((xf == 0) && (yf > 0))) ? !bit4 : bit4;
-  int desc_index = ((bit4 << 3) + (bit3 << 2)) << 1;
-  if ((xf * yf > 0) || (xf == 0))
-    desc_index += (fabs(xf) >= fabs(yf)) ? 0 : 4;
-  else
-    desc_index += (fabs(xf) > fabs(yf)) ? 4 : 0;
-  desc_index += zf > 0 ? 1 : 0;
-  desc_index += (distance > r12) ? 2 : 0;
-  const int step_index = (int)floor(bin_distance + HALF);
-  const int volume_index = desc_index * (NR_BINS + 1);
-  bin_distance -= step_index;
-  real_t w = ONE - fabs(bin_distance);
-  if (bin_distance > 0)
-    atomicAdd(&shot[volume_index + ((step_index + 1) % NR_BINS)], (float)bin_distance);
-  else
-    atomicAdd(&shot[volume_index + ((step_index - 1 + NR_BINS) % NR_BINS)], -(float)bin_distance);
-  if (distance > r12) {
-    const real_t rd = (distance - r34) / r12;
-    if (distance > r34) w += 1 - rd;
-    else { w += 1 + rd; atomicAdd(&shot[(desc_index - 2) * (NR_BINS + 1) + step_index], -(float)rd); }
-  } else {
-    const real_t rd = (distance - r14) / r12;
-    if (distance < r14) w += 1 + rd;
-    else { w += 1 - rd; atomicAdd(&shot[(desc_index + 2) * (NR_BINS + 1) + step_index], (float)rd); }
+  float xf = (dx * rf[0] + dy * rf[1]) + dz * rf[2];
+  float yf = (dx * rf[3] + dy * rf[4]) + dz * rf[5];
+  float zf = (dx * rf[6] + dy * rf[7]) + dz * rf[8];
+  yf = (fabsf(yf) < 1e-30f) ? 0.0f : yf;
+  xf = (fabsf(xf) < 1e-30f) ? 0.0f : xf;
+  zf = (fabsf(zf) < 1e-30f) ? 0.0f : zf;
+  const float r12 = radius * 0.5f, r14 = radius * 0.25f, r34 = radius * 0.75f, inv_r12 = 2.0f / radius;
+  const bool outer = distance > r12;
+  const int bit4 = ((yf > 0.0f) || ((yf == 0.0f) && (xf < 0.0f))) ? 1 : 0;
+  const int bit3 = ((xf > 0.0f) || ((xf == 0.0f) && (yf > 0.0f))) ? (bit4 ^ 1) : bit4;
+  int desc = (bit4 << 4) + (bit3 << 3);
+  const float fx = fabsf(xf), fy = fabsf(yf);
+  if ((xf * yf > 0.0f) || (xf == 0.0f)) desc += (fx >= fy) ? 0 : 4;
+  else desc += (fx > fy) ? 4 : 0;
+  desc += (zf > 0.0f) ? 1 : 0;
+  desc += outer ? 2 : 0;
+  const float stepf = floorf(bd + 0.5f);
+  const int step = (int)stepf;
+  const int home = desc * (NR_BINS + 1) + step;
+  bd -= stepf;
+  float w = 1.0f - fabsf(bd);
+  {  // cosine bins wrap inside the volume
+    int nb = step + ((bd > 0.0f) ? 1 : NR_BINS - 1);
+    nb -= (nb >= NR_BINS) ? NR_BINS : 0;
+    atomicAdd(&shot[desc * (NR_BINS + 1) + nb], (uint32_t)__float2uint_rn((fabsf(bd)) * fx_scale));
   }
-  const real_t inc = r_inclination(zf, r_sqrt(xf * xf + yf * yf), distance);
-  const real_t R45 = (real_t)RAD_45, R90 = (real_t)RAD_90, R135 = (real_t)RAD_135;
-  if (inc > R90 || (fabs(inc - R90) < (real_t)1e-30 && zf <= 0)) {
-    const real_t id = (inc - R135) / R90;
-    if (inc > R135) w += 1 - id;
-    else { w += 1 + id; atomicAdd(&shot[(desc_index + 1) * (NR_BINS + 1) + step_index], -(float)id); }
-  } else {
-    const real_t id = (inc - R45) / R90;
-    if (inc < R45) w += 1 + id;
-    else { w += 1 - id; atomicAdd(&shot[(desc_index - 1) * (NR_BINS + 1) + step_index], (float)id); }
+  {  // radial shells: the neighbour exists only towards the shell boundary at radius / 2
+    const float rd = (distance - (outer ? r34 : r14)) * inv_r12;
+    w += 1.0f - fabsf(rd);
+    const bool has = outer ? !(distance > r34) : !(distance < r14);
+    if (has) atomicAdd(&shot[home + (outer ? -2 : 2) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(rd)) * fx_scale));
   }
-  if (yf != 0 || xf != 0) {
-    const real_t az = r_atan2(yf, xf);
-    const int sel = desc_index >> 2;
-    real_t ad = (az - (-(real_t)RAD_PI_7_8 + R45 * sel)) / R45;
-    ad = ad < -HALF ? -HALF : (ad > HALF ? HALF : ad);
-    if (ad > 0) {
-      w += 1 - ad;
-      atomicAdd(&shot[((desc_index + 4) % MAX_SECTORS) * (NR_BINS + 1) + step_index], (float)ad);
-    } else {
-      w += 1 + ad;
-      atomicAdd(&shot[((desc_index - 4 + MAX_SECTORS) % MAX_SECTORS) * (NR_BINS + 1) + step_index], -(float)ad);
-    }
+  {  // elevation: two hemispheres, neighbour only towards the equator
+    const float inc = shot_atan2(__builtin_amdgcn_sqrtf(xf * xf + yf * yf), zf);      // [0, pi], exact at the poles
+    const float R45 = (float)RAD_45, R90 = (float)RAD_90, R135 = (float)RAD_135;
+    const bool lower = inc > R90 || (inc == R90 && zf <= 0.0f);
+    const float id = (inc - (lower ? R135 : R45)) * (float)(1.0 / RAD_90);
+    w += 1.0f - fabsf(id);
+    const bool has = lower ? !(inc > R135) : !(inc < R45);
+    if (has) atomicAdd(&shot[home + (lower ? 1 : -1) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(id)) * fx_scale));
   }
-  atomicAdd(&shot[volume_index + step_index], (float)w);
+  if (yf != 0.0f || xf != 0.0f) {  // azimuth sectors wrap around
+    const float az = shot_atan2(yf, xf);
+    float ad = (az - (-(float)RAD_PI_7_8 + (float)RAD_45 * (float)(desc >> 2))) * (float)(1.0 / RAD_45);
+    ad = fminf(fmaxf(ad, -0.5f), 0.5f);
+    w += 1.0f - fabsf(ad);
+    const int sec = (desc + ((ad > 0.0f) ? 4 : MAX_SECTORS - 4)) & (MAX_SECTORS - 1);
+    atomicAdd(&shot[sec * (NR_BINS + 1) + step], (uint32_t)__float2uint_rn((fabsf(ad)) * fx_scale));
+  }
+  atomicAdd(&shot[home], (uint32_t)__float2uint_rn((w) * fx_scale));
 }
-
 
 #define CELL_CAP 16384     // cells per scene held in LDS by shot_cells (64 KiB of counters)
 #define NSUM 19            // 9 normal sums + count, 6 LRF sums + weight sum + valid count (+1 pad)
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(1024) void shot_cells_kernel(const float* __restric
                                                           CellHdr* __restrict__ hdrs,
                                                           int32_t* __restrict__ cell_start /* [B][CELL_CAP+1] */,
                                                           int32_t* __restrict__ sorted_idx,
-                                                          float* __restrict__ sorted_pts,
+                                                          float4* __restrict__ sorted_pts,
                                                           int32_t* __restrict__ scene_of) {
   __shared__ uint32_t s_cnt[CELL_CAP];
   __shared__ float s_red[16][6];
@@ -334,8 +335,7 @@ __global__ __launch_bounds__(1024) void shot_cells_kernel(const float* __restric
     const uint32_t pos = atomicAdd(&s_cnt[(cz * h.d[1] + cy) * h.d[0] + cx], 1u);
     scene_of[p0 + i] = b;
     sorted_idx[p0 + pos] = i;
-    float* o = sorted_pts + 3 * (int64_t)(p0 + pos);
-    o[0] = x; o[1] = y; o[2] = z;
+    sorted_pts[(int64_t)p0 + pos] = make_float4(x, y, z, __int_as_float(i));   // .w = original index
   }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
-                                                      const float* __restrict__ sorted_pts,
+                                                      const float4* __restrict__ sorted_pts,
                                                       const int32_t* __restrict__ scene_of, float rn, float rs,
                                                       double* __restrict__ sums /* [Ntot][NSUM] */) {
   __shared__ double s_part[NSUM][64];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
   const int p0 = pt_off[b];
   const CellHdr h = hdrs[b];
   const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
-  const float* sp = sorted_pts + 3 * (int64_t)p0;
+  const float4* sp = sorted_pts + (int64_t)p0;
   const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
   const float rn2 = rn * rn, rs2 = rs * rs;
   Runs runs;
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     for (int j = runs.beg[k] + lane; j < runs.end[k]; j += 64) {
-      const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
+      const float4 qv = sp[j];
+      const float qx = qv.x, qy = qv.y, qz = qv.z;
       const float d2 = sqdist3(px, py, pz, qx, qy, qz);
       const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
       if (d2 < rn2) {
@@ -467,6 +468,19 @@ __global__ __launch_bounds__(256) void shot_eig_kernel(int64_t total, const floa
   }
 }
 
+// normals permuted into the cell-sorted order, so that the histogram pass reads a neighbour's position and normal
+// with the same index (no dependent index load in its inner loop)
+__global__ __launch_bounds__(256) void shot_sort_normals_kernel(int64_t total, const float* __restrict__ nrm,
+                                                                const int32_t* __restrict__ pt_off,
+                                                                const int32_t* __restrict__ scene_of,
+                                                                const int32_t* __restrict__ sorted_idx,
+                                                                float4* __restrict__ sorted_nrm) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const int64_t src = (int64_t)pt_off[scene_of[g]] + sorted_idx[g];
+  sorted_nrm[g] = make_float4(nrm[3 * src], nrm[3 * src + 1], nrm[3 * src + 2], 0.0f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // shot_hist: sign disambiguation + interpolated histogram
 // ---------------------------------------------------------------------------------------------
@@ -475,12 +489,14 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const CellHdr* __restrict__ hdrs,
                                                        const int32_t* __restrict__ cell_start,
                                                        const int32_t* __restrict__ sorted_idx,
-                                                       const float* __restrict__ sorted_pts,
+                                                       const float4* __restrict__ sorted_pts,
                                                        const int32_t* __restrict__ scene_of,
-                                                       const float* __restrict__ nrm, const LrfPre* __restrict__ pre,
-                                                       float radius, float* __restrict__ out_shot,
+                                                       const float4* __restrict__ sorted_nrm,
+                                                       const LrfPre* __restrict__ pre, float radius,
+                                                       float* __restrict__ out_shot,
                                                        float* __restrict__ out_rf) {
-  __shared__ float s_hist[SHOT_LEN];
+  __shared__ uint32_t s_hist[SH_COPIES * SH_STRIDE];
+  uint32_t* hist = s_hist + (threadIdx.x & (SH_COPIES - 1)) * SH_STRIDE;
   __shared__ int s_list[SH_LCAP];       // positions in the cell-sorted order
   __shared__ float s_rf[9];
   const int lane = threadIdx.x;
@@ -489,9 +505,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   const int p0 = pt_off[b];
   const CellHdr h = hdrs[b];
   const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
-  const float* sp = sorted_pts + 3 * (int64_t)p0;
-  const int32_t* sid = sorted_idx + p0;
-  const float* sn = nrm + 3 * (int64_t)p0;
+  const float4* sp = sorted_pts + (int64_t)p0;       // (x, y, z, original index)
+  const float4* sn = sorted_nrm + (int64_t)p0;       // cell-sorted order, like sp
   const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
   const float r2 = radius * radius;
   float* o = out_shot + (int64_t)SHOT_LEN * qi;
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
       const int j = jb + lane;
       bool in = false;
-      if (j < runs.end[k]) in = sqdist3(px, py, pz, sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]) < r2;
+      if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
       const unsigned long long mask = __ballot(in);
       if (in) {
         const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
@@ -541,8 +556,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     _Pragma("unroll") for (int k = 0; k < 9; ++k)                                            \
       for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {                               \
         const int j = min(jb + lane, runs.end[k] - 1);                                       \
-        const bool act = (jb + lane < runs.end[k]) &&                                        \
-                         (sqdist3(px, py, pz, sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]) < r2); \
+        const float4 qv_ = sp[j];                                                            \
+        const bool act = (jb + lane < runs.end[k]) && (sqdist3(px, py, pz, qv_.x, qv_.y, qv_.z) < r2); \
         __VA_ARGS__                                                                               \
       }                                                                                      \
   }
@@ -550,7 +565,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   FOR_EACH_NEIGHBOUR({
     bool p1 = false, p3 = false;
     if (act) {
-      const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
+      const float4 qv = sp[j];
+      const float qx = qv.x, qy = qv.y, qz = qv.z;
       if (!(qx == px && qy == py && qz == pz)) {
         const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
         p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
@@ -567,26 +583,29 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     FOR_EACH_NEIGHBOUR({
       bool h1 = false, h3 = false;
       if (act) {
-        const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
+        const float4 qv = sp[j];
+        const float qx = qv.x, qy = qv.y, qz = qv.z;
         if (!(qx == px && qy == py && qz == pz)) {
           const float d2 = sqdist3(px, py, pz, qx, qy, qz);
-          const int oj = sid[j];
+          const int oj = __float_as_int(qv.w);
           int rank = 0;
           if (listed) {
             for (int c2 = 0; c2 < m; ++c2) {
               const int j2 = s_list[c2];
-              const float ux = sp[3 * j2], uy = sp[3 * j2 + 1], uz = sp[3 * j2 + 2];
+              const float4 uv = sp[j2];
+              const float ux = uv.x, uy = uv.y, uz = uv.z;
               const float e2 = sqdist3(px, py, pz, ux, uy, uz);
               const bool nb2 = !(ux == px && uy == py && uz == pz);
-              rank += (nb2 && (e2 < d2 || (e2 == d2 && sid[j2] < oj))) ? 1 : 0;
+              rank += (nb2 && (e2 < d2 || (e2 == d2 && __float_as_int(uv.w) < oj))) ? 1 : 0;
             }
           } else {
             for (int k2 = 0; k2 < 9; ++k2)
               for (int j2 = runs.beg[k2]; j2 < runs.end[k2]; ++j2) {
-                const float ux = sp[3 * j2], uy = sp[3 * j2 + 1], uz = sp[3 * j2 + 2];
+                const float4 uv = sp[j2];
+                const float ux = uv.x, uy = uv.y, uz = uv.z;
                 const float e2 = sqdist3(px, py, pz, ux, uy, uz);
                 const bool nb2 = (e2 < r2) && !(ux == px && uy == py && uz == pz);
-                rank += (nb2 && (e2 < d2 || (e2 == d2 && sid[j2] < oj))) ? 1 : 0;
+                rank += (nb2 && (e2 < d2 || (e2 == d2 && __float_as_int(uv.w) < oj))) ? 1 : 0;
               }
           }
           if (rank >= med - 2 && rank <= med + 2) {
@@ -621,23 +640,55 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
 #pragma unroll
     for (int c = 0; c < 9; ++c) s_rf[c] = rf[c];
   }
-  for (int c = lane; c < SHOT_LEN; c += 64) s_hist[c] = 0.0f;
+  for (int c = lane; c < SH_COPIES * SH_STRIDE; c += 64) s_hist[c] = 0u;
+  // Bins are summed in fixed point: a bin receives at most 4 per neighbour, so 2^(29 - ceil(log2(m + 1))) units per 1.0
+  // cannot overflow 32 bits.  Integer LDS atomics run at full rate (float ones were measured ~50 cycles per
+  // wavefront instruction), the sum does not depend on the order of the neighbours, and one unit (<= 2^-22 for the
+  // usual m < 128) is below the float rounding of the bins it replaces.
+  const float fx_scale = (float)(1u << (29 - (32 - __clz(m))));
   __syncthreads();
-  FOR_EACH_NEIGHBOUR({
-    if (act) {
-      const float qx = sp[3 * j], qy = sp[3 * j + 1], qz = sp[3 * j + 2];
-      const float d2 = sqdist3(px, py, pz, qx, qy, qz);
-      const int oj = sid[j];
-      shot_accumulate(px, py, pz, qx, qy, qz, d2, sn[3 * oj], sn[3 * oj + 1], sn[3 * oj + 2], s_rf, (real_t)radius, s_hist);
+  if (listed) {
+    // the next 64 neighbours' positions and normals are requested before the current 64 are accumulated
+    bool act = lane < m;
+    float4 qp, qn;
+    {
+      const int j = act ? s_list[lane] : 0;
+      qp = sp[j]; qn = sn[j];
     }
-  })
+    for (int base = 0; base < m; base += 64) {
+      const float qx = qp.x, qy = qp.y, qz = qp.z, nx = qn.x, ny = qn.y, nz = qn.z;
+      const bool cur = act;
+      const int cn = base + 64 + lane;
+      act = cn < m;
+      if (base + 64 < m) {
+        const int j = act ? s_list[cn] : 0;
+        qp = sp[j]; qn = sn[j];
+      }
+      if (cur) shot_accumulate(px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), nx, ny, nz, s_rf, radius, hist, fx_scale);
+    }
+  } else {
+    FOR_EACH_NEIGHBOUR({
+      if (act) {
+        const float4 qv = sp[j], nv = sn[j];
+        shot_accumulate(px, py, pz, qv.x, qv.y, qv.z, sqdist3(px, py, pz, qv.x, qv.y, qv.z), nv.x, nv.y, nv.z, s_rf, radius,
+                        hist, fx_scale);
+      }
+    })
+  }
 #undef FOR_EACH_NEIGHBOUR
   __syncthreads();
   double acc = 0.0;
-  for (int c = lane; c < SHOT_LEN; c += 64) acc += (double)s_hist[c] * (double)s_hist[c];
+  for (int c = lane; c < SHOT_LEN; c += 64) {
+    uint32_t u = s_hist[c];
+#pragma unroll
+    for (int k = 1; k < SH_COPIES; ++k) u += s_hist[k * SH_STRIDE + c];
+    const float v = (float)u / fx_scale;               // power-of-two scale: exact
+    s_hist[c] = __float_as_uint(v);                    // each bin is folded by the lane that normalises it below
+    acc += (double)v * (double)v;
+  }
   acc = sqrt(wave_sum(acc));
   const float facc = (float)acc;
-  for (int c = lane; c < SHOT_LEN; c += 64) __builtin_nontemporal_store(s_hist[c] / facc, &o[c]);
+  for (int c = lane; c < SHOT_LEN; c += 64) __builtin_nontemporal_store(__uint_as_float(s_hist[c]) / facc, &o[c]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,8 +697,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
 static inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct ShotWs {
-  CellHdr* hdr; int32_t* cell_start; int32_t* sorted_idx; float* sorted_pts; double* sums; LrfPre* pre;
-  int32_t* scene_of;
+  CellHdr* hdr; int32_t* cell_start; int32_t* sorted_idx; float4* sorted_pts; double* sums; LrfPre* pre;
+  int32_t* scene_of; float4* sorted_nrm;
 };
 
 static ShotWs carve(void* ws, int B, int64_t n) {
@@ -656,18 +707,19 @@ static ShotWs carve(void* ws, int B, int64_t n) {
   w.hdr = (CellHdr*)p; p += up256((int64_t)B * sizeof(CellHdr));
   w.cell_start = (int32_t*)p; p += up256((int64_t)B * (CELL_CAP + 1) * 4);
   w.sorted_idx = (int32_t*)p; p += up256(n * 4);
-  w.sorted_pts = (float*)p; p += up256(n * 12);
+  w.sorted_pts = (float4*)p; p += up256(n * 16);
   w.sums = (double*)p; p += up256(n * NSUM * 8);
   w.pre = (LrfPre*)p; p += up256(n * (int64_t)sizeof(LrfPre));
-  w.scene_of = (int32_t*)p;
+  w.scene_of = (int32_t*)p; p += up256(n * 4);
+  w.sorted_nrm = (float4*)p;
   return w;
 }
 
 extern "C" int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points) {
   if (B <= 0 || total_points <= 0) return 0;
   return up256((int64_t)B * sizeof(CellHdr)) + up256((int64_t)B * (CELL_CAP + 1) * 4) + up256(total_points * 4) +
-         up256(total_points * 12) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre)) +
-         up256(total_points * 4);
+         up256(total_points * 16) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre)) +
+         up256(total_points * 4) + up256(total_points * 16);
 }
 
 static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, float normal_r, float shot_r,
@@ -687,9 +739,11 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
                      out_normal, want_s ? w.pre : (LrfPre*)nullptr);
   CPPF_LAUNCH_CHECK();
   if (want_s) {
+    hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
+                       normals_in ? normals_in : out_normal, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
+    CPPF_LAUNCH_CHECK();
     hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                       w.sorted_idx, w.sorted_pts, w.scene_of, normals_in ? normals_in : out_normal, w.pre, shot_r, out_shot,
-                       out_rf);
+                       w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, out_shot, out_rf);
     CPPF_LAUNCH_CHECK();
   }
   return CPPF_OK;
@@ -758,8 +812,12 @@ extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off
   if (total_points <= 0) return CPPF_OK;
   CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, total_points));
   const ShotWs w = carve(workspace, B, total_points);
+  hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((total_points + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, total_points, normals, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
+  CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, normals, w.pre, shot_r, out_shot, out_rf);
+                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, out_shot,
+                     out_rf);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
