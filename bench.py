@@ -145,7 +145,10 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
         "shot352": N * 12 + N * 12 + N * 56 + N * 352 * 4,
         "encode_tuples": T * 5 * 4 + N * 12 + N * 12 + N * 64 * 4 + T * 360 * 4,
         "decode_bins": T * 6 * 32 * 4 + T * 6 * 4 + T * 8 + T * (8 + 12 + 24 + 4 + 24),
-        "vote_center": T * 8 + T * 8 + N * 12 + 0 * G,       # grid stays on-chip (LDS slabs); only the peak leaves
+        # idx + tr + points, grid clear G*4, one 4-byte accumulator update per vote (V = T*R), argmax
+        # read G*4.  (This implementation keeps the accumulator in LDS slabs, so its HBM traffic -- `traffic` -- is
+        # well below this figure: the frames workspace and the per-slab re-reads of it.)
+        "vote_center": T * 8 + T * 8 + N * 12 + G * 4 + T * R * 4 + G * 4,
         "backvote_filter": T * 8 + T * 8 + N * 12 + T * (1 + 4 + 4 + 8 + 4),
         "rot_bins": 2 * (T // 10) * (4 + 8 + 4 + 8 + 12) + 2 * S * 4,
         "assemble_pose": 160,
@@ -260,6 +263,7 @@ def main():
                         frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms,
                         kernel_name=STAGE_KERNEL.get(dominant),
                         algorithmic_bytes_per_launch=dom_bytes,
+                        algorithmic_model="SURVEY.md 8d per-scene bytes x %d scenes per launch" % B,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
         ok = 0
