@@ -59,7 +59,7 @@ class Step:
     """Holds the resident inputs and runs one pass of the path."""
 
     STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
-              "decode_bins", "vote_center", "backvote_filter", "rot_bins", "assemble_pose", "gather"]
+              "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "assemble_pose", "gather"]
 
     def __init__(self, args, rank, world, dev):
         from cppf2_amd import ops, synth
@@ -121,7 +121,9 @@ class Step:
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         pipe.decode(self.pts, idx, logits, u)
         self._mark("decode_bins")
-        pipe.vote_center(self.pts, idx)
+        pipe.vote_center(self.pts, idx, phase=1)      # scene bounds + per-pair circle frames
+        self._mark("vote_frames")
+        pipe.vote_center(self.pts, idx, phase=2)      # the vote kernel (+ the 5 us final argmax)
         self._mark("vote_center")
         pipe.backvote(self.pts, idx)
         self._mark("backvote_filter")
@@ -149,6 +151,7 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
         # read G*4.  (This implementation keeps the accumulator in LDS slabs, so its HBM traffic -- `traffic` -- is
         # well below this figure: the frames workspace and the per-slab re-reads of it.)
         "vote_center": T * 8 + T * 8 + N * 12 + G * 4 + T * R * 4 + G * 4,
+        "vote_frames": T * 8 + T * 8 + N * 12 + T * 48,
         "backvote_filter": T * 8 + T * 8 + N * 12 + T * (1 + 4 + 4 + 8 + 4),
         "rot_bins": 2 * (T // 10) * (4 + 8 + 4 + 8 + 12) + 2 * S * 4,
         "assemble_pose": 160,
@@ -158,7 +161,7 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
 
 STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_cov_kernel", "shot352": "shot_hist_kernel",
                 "encode_tuples": "encode_shot_kernel<5, 16>", "decode_bins": "decode_bins_kernel<32>",
-                "vote_center": "vote_center_slab_kernel<true>", "backvote_filter": "backvote_kernel",
+                "vote_frames": "vote_frames_kernel", "vote_center": "vote_center_slab_kernel<true>", "backvote_filter": "backvote_kernel",
                 "rot_bins": "rot_bins_lut_kernel", "assemble_pose": "assemble_pose_kernel"}
 
 

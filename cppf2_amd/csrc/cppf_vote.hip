@@ -268,15 +268,32 @@ __device__ __forceinline__ int vote_cell_packed(float cx, vc_f2 cyz, float xx, v
   return ok ? lin : -1;
 }
 
-// the same vote with the reference's arithmetic (train_dino.py:195-203)
-__device__ __noinline__ int vote_cell_exact(float cx, vc_f2 cyz, float xx, vc_f2 xyz, float yx, vc_f2 yyz, float cs,
-                                            float sn, const GridFast& gc) {
-  return vote_cell(cx, cyz.x, cyz.y, xx, xyz.x, xyz.y, yx, yyz.x, yyz.y, cs, sn, gc.c0x, gc.c0yz.x, gc.c0yz.y, gc.res,
-                   gc.gx, gc.gy, gc.gz);
+// the same vote with the reference's arithmetic (train_dino.py:195-203); out of line (rare) and with every argument by
+// value: a reference to the grid constants would force them into scratch memory for the whole kernel
+__device__ __noinline__ int vote_cell_exact(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                            float yy, float yz, float cs, float sn, float c0x, float c0y, float c0z,
+                                            float res, int gx, int gy, int gz) {
+  return vote_cell(cx, cy, cz, xx, xy, xz, yx, yy, yz, cs, sn, c0x, c0y, c0z, res, gx, gy, gz);
 }
 
-__device__ __forceinline__ float bcast_f(float x, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+struct FrameRegs {
+  float cx, cy, cz, xx, xy, xz, yx, yy, yz, invA, phi;
+  uint32_t wv;
+};
+
+// one pair's frame from the SoA workspace (a NaN centre = "no votes" for rows past the end)
+__device__ __forceinline__ FrameRegs load_frame(const float* __restrict__ fr, int64_t total, int64_t row, bool in) {
+  FrameRegs f;
+  f.cx = NAN; f.cy = 0.0f; f.cz = 0.0f; f.xx = 0.0f; f.xy = 0.0f; f.xz = 0.0f; f.yx = 0.0f; f.yy = 0.0f; f.yz = 0.0f;
+  f.invA = 0.0f; f.phi = 0.0f; f.wv = 0u;
+  if (in) {
+    f.cx = fr[0 * total + row]; f.cy = fr[1 * total + row]; f.cz = fr[2 * total + row];
+    f.xx = fr[3 * total + row]; f.xy = fr[4 * total + row]; f.xz = fr[5 * total + row];
+    f.yx = fr[6 * total + row]; f.yy = fr[7 * total + row]; f.yz = fr[8 * total + row];
+    f.invA = fr[9 * total + row]; f.phi = fr[10 * total + row];
+    f.wv = __float_as_uint(fr[11 * total + row]);
+  }
+  return f;
 }
 
 template <bool ARCS>
@@ -340,26 +357,14 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   const unsigned n_eff = (lo + n > lo_eff) ? (unsigned)(lo + n - lo_eff) : 0u;
   const int lane = wave_lane();
   // frames of the next block of pairs are requested before the current block is processed (register double buffer)
-  float nf[VC_FRAME_FLOATS];
-#pragma unroll
-  for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = (c == 0) ? NAN : 0.0f;
-  if (ts + (int)threadIdx.x < te) {
-#pragma unroll
-    for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = fr[c * total + (int64_t)(t0 + ts + (int)threadIdx.x)];
-  }
+  FrameRegs nf = load_frame(fr, total, (int64_t)t0 + ts + (int)threadIdx.x, ts + (int)threadIdx.x < te);
   for (int tb = ts; tb < te; tb += VC_THREADS) {
-    const float cx = nf[0], cy = nf[1], cz = nf[2], xx = nf[3], xy = nf[4], xz = nf[5], yx = nf[6], yy = nf[7],
-                yz = nf[8], invA = nf[9], phi = nf[10];
-    const uint32_t wv = __float_as_uint(nf[11]);
+    const float cx = nf.cx, cy = nf.cy, cz = nf.cz, xx = nf.xx, xy = nf.xy, xz = nf.xz, yx = nf.yx, yy = nf.yy,
+                yz = nf.yz, invA = nf.invA, phi = nf.phi;
+    const uint32_t wv = nf.wv;
     {
       const int tn = tb + VC_THREADS + (int)threadIdx.x;
-      if (tn < te) {
-#pragma unroll
-        for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = fr[c * total + (int64_t)(t0 + tn)];
-      } else {
-#pragma unroll
-        for (int c = 0; c < VC_FRAME_FLOATS; ++c) nf[c] = (c == 0) ? NAN : 0.0f;
-      }
+      nf = load_frame(fr, total, (int64_t)t0 + tn, tn < te);
     }
     if (ARCS && narrow) {
       // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
@@ -433,7 +438,8 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
 #pragma unroll
           for (int jj = 0; jj < VC_QUANTUM; ++jj)
             if (redo & (1u << jj))
-              lin[jj] = vote_cell_exact(ocx, ocyz, oxx, oxyz, oyx, oyyz, tg[jj].x, tg[jj].y, gf);
+              lin[jj] = vote_cell_exact(ocx, ocyz.x, ocyz.y, oxx, oxyz.x, oxyz.y, oyx, oyyz.x, oyyz.y, tg[jj].x, tg[jj].y, c0x,
+                                        c0y, c0z, res, gx, gy, gz);
         }
 #pragma unroll
         for (int jj = 0; jj < VC_QUANTUM; ++jj)
@@ -617,6 +623,10 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
   uint32_t* ws_grid = (uint32_t*)wsp;
   float* frames = (float*)(wsp + align_up((int64_t)B * cells_cap * 4, 256));
   const int s_max = (int)((cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
+  // two-call form (lets a caller put events around the vote kernel alone): CPPF_VC_FRAMES_ONLY fills the per-pair
+  // frames in the workspace and returns; CPPF_VC_FRAMES_READY skips that step
+  const bool frames_only = (mode & CPPF_VC_FRAMES_ONLY) != 0, frames_ready = (mode & CPPF_VC_FRAMES_READY) != 0;
+  mode &= 0xff;
   if (mode == 0) mode = (s_max <= 64) ? 1 : 2;
   int exhaustive = 0;
   if (mode == 3) { mode = 1; exhaustive = 1; }
@@ -652,9 +662,12 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
       CPPF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
-                       tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
-    CPPF_LAUNCH_CHECK();
+    if (!frames_ready) {
+      hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
+                         tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
+      CPPF_LAUNCH_CHECK();
+    }
+    if (frames_only) return CPPF_OK;
     if (arcs)
       hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
                          total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,

@@ -97,15 +97,21 @@ class VotingPipeline:
                                        self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
                                        ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")
 
-    def vote_center(self, pts, idx, grid=None, grid_off=None, vote_wt=None):
+    def vote_center(self, pts, idx, grid=None, grid_off=None, vote_wt=None, phase=0):
+        """phase 0: bounds + frames + votes + argmax in one go.  phase 1: bounds + per-pair frames only;
+        phase 2: votes + argmax on the frames left by phase 1 (CPPF_VC_FRAMES_ONLY / _READY, LDS-slab mode)."""
         st = ops._stream()
-        _lib.check(_L.cppf_scene_bounds(self.B, ops._p(pts), ops._p(self.pt_off), C.c_float(self.res),
-                                        ops._p(self.grids), st), "cppf_scene_bounds")
+        mode = self.vote_mode
+        if phase:
+            mode = 1 | (0x200 if phase == 1 else 0x100)
+        if phase != 2:
+            _lib.check(_L.cppf_scene_bounds(self.B, ops._p(pts), ops._p(self.pt_off), C.c_float(self.res),
+                                            ops._p(self.grids), st), "cppf_scene_bounds")
         _lib.check(_L.cppf_vote_center(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
                                        ops._p(self.tup_off), self.max_t, self.Ttot, ops._p(self.tr), ops._p(vote_wt),
                                        C.c_double(self.res),
                                        self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.grids), ops._p(grid),
-                                       ops._p(grid_off), self.cells_cap, self.vote_mode, ops._p(self.ws),
+                                       ops._p(grid_off), self.cells_cap, mode, ops._p(self.ws),
                                        self.ws_vote_bytes, ops._p(self.argmax), ops._p(self.peak), ops._p(self.world),
                                        st), "cppf_vote_center")
 

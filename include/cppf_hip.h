@@ -150,11 +150,16 @@ int cppf_generate_target_pairs(int B, const float* pairs, const int32_t* tup_off
  *   cells_cap: upper bound on ncell of any scene in the batch (sizes the launch; scenes above it get
  *     flags bit2 and no votes).  mode: 0 = auto, 1 = LDS-slab accumulation (per-slab rotation arcs),
  *     2 = global atomics, 3 = LDS-slab with the exhaustive rotation sweep (A/B reference).
+ *     Mode 1 may be OR-ed with CPPF_VC_FRAMES_ONLY (compute the per-pair circle frames into the workspace and
+ *     return) or CPPF_VC_FRAMES_READY (the workspace already holds them): the two-call form of the same work, for
+ *     callers that time or overlap the vote kernel separately.
  *   vote_wt: NULL = every vote counts 1 (the reference).  Otherwise per-pair weights in [0, 4]; a vote adds
  *     round(w*256) to its cell (integer accumulation, deterministic) -- the uncertainty-weighted accumulator of
  *     BASELINE config 5, an extension the reference does not have; w == 1 yields 256 x the reference grid.
  *   workspace: cppf_vote_center_workspace_bytes(B, cells_cap, total_tuples) bytes.
  *   out_argmax int64[B], out_peak uint32[B] (0xFFFFFFFF for a scene above cells_cap), out_world float64[B,3]. */
+#define CPPF_VC_FRAMES_ONLY 0x200
+#define CPPF_VC_FRAMES_READY 0x100
 int cppf_scene_bounds(int B, const float* pts, const int32_t* pt_off, float res, CppfSceneGrid* out, void* stream);
 int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples);
 int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,

@@ -89,3 +89,26 @@ def test_shot_different_radii():
     ok = ~np.isnan(os_).any(1)
     assert np.allclose(hn.reshape(-1, 3), on, atol=2e-6, equal_nan=True)
     assert np.abs(hs.reshape(-1, 352)[ok] - os_[ok]).max() < 2e-5
+
+
+def test_vote_center_two_call_form_equals_single_call():
+    """CPPF_VC_FRAMES_ONLY + CPPF_VC_FRAMES_READY (the form bench.py times the vote kernel with) == one call."""
+    from cppf2_amd import ops, synth
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    B, N, T = 3, 1500, 6000
+    scs = [synth.make_scene(4, b, N) for b in range(B)]
+    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scs])).to(dev)
+    idx = ops.sample_tuples(N, T, 5, 4, tuple(range(B)))
+    lg = torch.cat([torch.from_numpy(synth.teacher_logits(s["pc_canon"], idx[b * T:(b + 1) * T].cpu().numpy(), 32))
+                    for b, s in enumerate(scs)]).to(dev)
+    u = ops.philox_uniform(T, 6, 4, 1, tuple(range(B)))
+    pipe = VotingPipeline([N] * B, [T] * B, num_rots=60)
+    pipe.decode(pts, idx, lg, u)
+    pipe.vote_center(pts, idx)
+    want = (pipe.argmax.clone(), pipe.peak.clone(), pipe.world.clone())
+    pipe.argmax.zero_(); pipe.peak.zero_(); pipe.world.zero_()
+    pipe.vote_center(pts, idx, phase=1)
+    pipe.vote_center(pts, idx, phase=2)
+    assert torch.equal(pipe.argmax, want[0]) and torch.equal(pipe.peak, want[1]) and torch.equal(pipe.world, want[2])
+    assert int(pipe.peak.min()) > 0
