@@ -144,6 +144,13 @@ class VotingPipeline:
                                          ops._p(self.kept_tuple), ops._p(self.kept_count), ops._p(self.results),
                                          ops._stream()), "cppf_assemble_pose")
 
+    def refine(self, pts, idx, y_only, steps=100, lr=1e-2):
+        """Online alignment refinement of the assembled poses, in place (eval.py:319-355; `opt=True`)."""
+        _lib.check(_L.cppf_refine_pose(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                       ops._p(self.tup_off), ops._p(self.scaled), ops._p(self.kept_tuple),
+                                       ops._p(self.kept_count), int(bool(y_only)), int(steps), C.c_float(lr),
+                                       ops._p(self.results), ops._stream()), "cppf_refine_pose")
+
     def vote(self, pts, idx, logits, uniforms, pred_scales=None, grid=None, grid_off=None):
         """Everything after the MLP: eval.py:225-313.  All arguments are device tensors in the batch layout.
         Returns the device tensor of B result records (uint8 [B,160]); use results_to_numpy() to read them."""

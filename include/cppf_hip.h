@@ -229,6 +229,17 @@ int cppf_assemble_pose(int B, const float* sphere, const int32_t* up_idx, const 
                        const int32_t* kept_tuple, const int32_t* kept_count,
                        CppfSceneResult* out, void* stream);
 
+/* ---- step behind the path: online alignment refinement, replaces eval.py:319-355 (100 Adam steps on
+ * the translation and a quaternion delta, lietorch SO3; mean L1 between the kept pairs' points in the object frame and
+ * the predicted pair coordinates, y component only for up-symmetric categories).  scaled float32[T,2,3]
+ * (pred_pairs_scaled of cppf_decode_bins); kept_* from cppf_backvote_filter; results: the records of
+ * cppf_assemble_pose, whose t and R are replaced in place (flags bit3 set).  lr = 1e-2, steps = 100 in the reference.
+ * PARITY UNPINNED (lietorch absent): pinned only by oracle/cppf_oracle.py:refine_pose. */
+int cppf_refine_pose(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                     const int32_t* tup_off, const float* scaled, const int32_t* kept_tuple,
+                     const int32_t* kept_count, int y_only, int steps, float lr, CppfSceneResult* results,
+                     void* stream);
+
 /* ---- steps in front of the path ---------------------------------------------------------------
  * Back-projection of a masked depth map: replaces backproject() (utils/util.py:2586-2607) + the sign flip and
  * float32 cast at eval.py:185-189.  depth float32[H,W] in metres, mask uint8[H,W]; h_kinv = inverse intrinsics

@@ -494,3 +494,78 @@ def run_scene(pc, point_idxs_all, pred_cls, pred_scales, uniforms, cfg_up, cfg_r
         # torch.median returns the lower median (eval.py:309)
         out["pred_scale"] = np.sort(ps, axis=0)[(ps.shape[0] - 1) // 2]
     return out
+
+
+# ----------------------------------------------------------------------------
+# online alignment refinement, eval.py:319-355  
+#
+# PARITY UNPINNED: the reference evaluates this block with lietorch 0.2 (SO3.InitFromVec(q).matrix() and its custom
+# backward), which is not in /root/reference and not installed here, so no golden vector can be produced.  The
+# restatement follows lietorch's published algorithm (lietorch/include/so3.h, groups.py): the rotation of a point
+# by the stored quaternion q = (x, y, z, w) is  p + w * 2 (v x p) + v x (2 (v x p))  with v = (x, y, z) and NO
+# normalisation of q; matrix() rotates the three basis vectors; the backward of that action hands the group element
+# the tangent-space gradient  sum_j (M e_j) x dL/d(M e_j), stored in the first three components of q's gradient
+# (the fourth is zero), which eval.py:341 scales by pi/180 before torch.optim.Adam (defaults) adds it to q.
+# ----------------------------------------------------------------------------
+def so3_matrix(q):
+    """lietorch SO3(q).matrix()[:3, :3] for an un-normalised quaternion q = (x, y, z, w), float32."""
+    q = np.asarray(q, dtype=F32)
+    v, w = q[:3], q[3]
+    M = np.empty((3, 3), dtype=F32)
+    for j in range(3):
+        e = np.zeros(3, dtype=F32)
+        e[j] = 1
+        uv = np.cross(v, e).astype(F32)
+        uv = (uv + uv).astype(F32)
+        M[:, j] = (e + w * uv + np.cross(v, uv).astype(F32)).astype(F32)
+    return M
+
+
+def refine_pose(pc, idx2, pred_pairs_scaled, T_est, R_est, y_only, steps=100, lr=1e-2, return_trace=False):
+    """eval.py:321-350.  pc f32[N,3]; idx2 int[Tf,2] (kept tuples' first two points); pred_pairs_scaled f32[Tf,2,3];
+    returns (T_est f32[3], R_est f32[3,3]) after `steps` Adam updates of the translation and the quaternion."""
+    pc = np.asarray(pc, dtype=F32)
+    idx2 = np.asarray(idx2).astype(np.int64)
+    tgt = np.asarray(pred_pairs_scaled, dtype=F32).reshape(-1, 2, 3)
+    t = np.asarray(T_est, dtype=np.float64).astype(F32)            # torch.from_numpy(T_est).cuda().float()
+    R0 = np.asarray(R_est, dtype=np.float64).astype(F32)
+    q = np.array([0, 0, 0, 1], dtype=F32)
+    b1, b2, eps = F32(0.9), F32(0.999), F32(1e-8)
+    m_t, v_t = np.zeros(3, F32), np.zeros(3, F32)
+    m_q, v_q = np.zeros(4, F32), np.zeros(4, F32)
+    P = pc[idx2]                                                   # [Tf,2,3]
+    n_el = tgt.shape[0] * 2 * (1 if y_only else 3)
+    trace = []
+    for step in range(1, steps + 1):
+        M = so3_matrix(q)
+        rot = (M @ R0).astype(F32)
+        d = (P - t).astype(F32)
+        c = (d @ rot).astype(F32)                                  # pc_canon[point_idxs]
+        r = (c - tgt).astype(F32)
+        g = np.sign(r).astype(F32) / F32(n_el)                     # d mean|r| / d c
+        if y_only:
+            g[..., 0] = 0
+            g[..., 2] = 0
+            loss = float(np.abs(r[..., 1]).mean())
+        else:
+            loss = float(np.abs(r).mean())
+        trace.append(loss)
+        g2, d2 = g.reshape(-1, 3), d.reshape(-1, 3)
+        g_t = (-(g2 @ rot.T).sum(0)).astype(F32)                   # c = (p - t) rot
+        g_rot = (d2.T @ g2).astype(F32)
+        g_M = (g_rot @ R0.T).astype(F32)                           # rot = M R0
+        g_xi = np.zeros(3, F32)
+        for j in range(3):
+            g_xi += np.cross(M[:, j], g_M[:, j]).astype(F32)
+        g_q = np.concatenate([g_xi, np.zeros(1, F32)]).astype(F32) / F32(180) * F32(np.pi)
+        bc1 = F32(1) - b1 ** F32(step)
+        bc2 = F32(1) - b2 ** F32(step)
+        for p_, g_, m_, v_ in ((t, g_t, m_t, v_t), (q, g_q, m_q, v_q)):
+            m_[:] = b1 * m_ + (F32(1) - b1) * g_
+            v_[:] = b2 * v_ + (F32(1) - b2) * g_ * g_
+            denom = np.sqrt(v_) / np.sqrt(bc2) + eps
+            p_[:] = p_ - (F32(lr) / bc1) * m_ / denom
+    R_new = (so3_matrix(q) @ R0).astype(F32)
+    if return_trace:
+        return t, R_new, trace
+    return t, R_new
