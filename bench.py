@@ -212,11 +212,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI; CPPF_BENCH_BACKEND=gloo is a dry-run switch for boxes with fewer GPUs than ranks
+        backend = os.environ.get("CPPF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     step = Step(args, rank, world, dev)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),
     "cppf_refine_pose": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p]),
+    "cppf_interpolate_features": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _p, _i, _f, _i, _p, _i, _p]),
     "cppf_backproject": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
     "cppf_voxel_downsample_workspace_bytes": (_i64, [_i64]),
     "cppf_voxel_downsample": (_i, [_p, _i, _f, _u64, _p, _p, _p, _i64, _p]),

@@ -185,3 +185,73 @@ extern "C" int cppf_voxel_downsample(const float* pts, int n, float res, uint64_
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// DINO-branch feature plumbing: interpolate_features (dataset.py:40-59) = F.grid_sample(bilinear,
+// zeros padding, align_corners=False) of the patch-token map at the keypoints' pixel centres + F.normalize over the
+// channels.  One wavefront per keypoint, lanes over channels; the map is addressed through element strides, so the
+// ViT's native patch-major layout [h*w, C] (coalesced) and the reference's NCHW view both work without a copy.
+// ---------------------------------------------------------------------------------------------
+#define IF_WAVES 4
+
+template <typename OUT>
+__global__ __launch_bounds__(IF_WAVES * 64) void interpolate_features_kernel(
+    const float* __restrict__ desc, int C, int h, int w, int64_t sc, int64_t sy, int64_t sx,
+    const float* __restrict__ pts, int n, float strides, int normalize, OUT* __restrict__ out) {
+  extern __shared__ float s_val[];                 // [IF_WAVES][C]
+  const int lane = wave_lane(), wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * IF_WAVES + wv;
+  if (i >= n) return;
+  float* val = s_val + (size_t)wv * C;
+  const float px = pts[2 * i], py = pts[2 * i + 1];
+  const float gx = ((px + 0.5f) / (float)w / strides) * 2.0f - 1.0f;           // dataset.py:46-47
+  const float gy = ((py + 0.5f) / (float)h / strides) * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)w - 1.0f) / 2.0f;                      // grid_sampler_unnormalize, align_corners=False
+  const float iy = ((gy + 1.0f) * (float)h - 1.0f) / 2.0f;
+  const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+  const float wt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
+  const float cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+  int64_t base[4];
+  bool ok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ok[q] = cx[q] >= 0.0f && cx[q] <= (float)(w - 1) && cy[q] >= 0.0f && cy[q] <= (float)(h - 1);
+    base[q] = ok[q] ? (int64_t)cy[q] * sy + (int64_t)cx[q] * sx : 0;
+  }
+  float ss = 0.0f;
+  for (int c = lane; c < C; c += 64) {
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok[q]) v += desc[base[q] + (int64_t)c * sc] * wt[q];
+    val[c] = v;
+    ss += v * v;
+  }
+  float inv = 1.0f;
+  if (normalize) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    inv = fmaxf(__builtin_sqrtf(ss), 1e-12f);                                   // F.normalize eps
+  }
+  OUT* o = out + (int64_t)i * C;
+  for (int c = lane; c < C; c += 64) o[c] = (OUT)(normalize ? val[c] / inv : val[c]);
+}
+
+extern "C" int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t stride_c, int64_t stride_y,
+                                         int64_t stride_x, const float* pts, int n, float strides, int normalize,
+                                         void* out, int out_f16, void* stream) {
+  CPPF_CHECK_ARG(C > 0 && h > 0 && w > 0 && n >= 0 && strides > 0.0f);
+  CPPF_CHECK_ARG((int64_t)IF_WAVES * C * 4 <= 64 * 1024);
+  if (n == 0) return CPPF_OK;
+  CPPF_CHECK_ARG(desc && pts && out);
+  const dim3 grid((n + IF_WAVES - 1) / IF_WAVES), block(IF_WAVES * 64);
+  const size_t lds = (size_t)IF_WAVES * C * 4;
+  if (out_f16)
+    hipLaunchKernelGGL(interpolate_features_kernel<_Float16>, grid, block, lds, (hipStream_t)stream, desc, C, h, w,
+                       stride_c, stride_y, stride_x, pts, n, strides, normalize, (_Float16*)out);
+  else
+    hipLaunchKernelGGL(interpolate_features_kernel<float>, grid, block, lds, (hipStream_t)stream, desc, C, h, w,
+                       stride_c, stride_y, stride_x, pts, n, strides, normalize, (float*)out);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

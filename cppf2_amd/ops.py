@@ -455,3 +455,26 @@ def downsample(pc, res, seed=0, return_device=False):
                                         _p(ws), wsb, _stream()), "cppf_voxel_downsample")
     idx = idx[: int(cnt.item())].long()
     return idx if return_device else idx.cpu().numpy()
+
+
+def interpolate_features(descriptors, pts, strides=8, normalize=True, half=False):
+    """interpolate_features(descriptors[1,C,h,w], pts[1,n,2]) (dataset.py:40-59) on the GPU.  `descriptors` may be any
+    strided view of the token map (e.g. tokens.reshape(1,h,w,C).permute(0,3,1,2), as dataset.py:78 builds it): the
+    kernel reads it in place.  Returns [1, C, n] like the reference (a transposed view of the keypoint-major result;
+    `.squeeze(0).T` is contiguous); half=True gives float16."""
+    dev = _dev()
+    d = descriptors if isinstance(descriptors, torch.Tensor) else torch.as_tensor(np.asarray(descriptors))
+    d = d.to(device=dev, dtype=torch.float32)
+    if d.dim() == 3:
+        d = d[None]
+    if d.dim() != 4 or d.shape[0] != 1:
+        raise CppfError("interpolate_features: descriptors must be [1, C, h, w]")
+    _, Cc, h, w = d.shape
+    p = _t(pts, torch.float32, dev).reshape(-1, 2)
+    n = p.shape[0]
+    out = torch.empty((n, Cc), dtype=torch.float16 if half else torch.float32, device=dev)
+    sc, sy, sx = d.stride(1), d.stride(2), d.stride(3)
+    _lib.check(_L.cppf_interpolate_features(_p(d), Cc, h, w, sc, sy, sx, _p(p), n, C.c_float(strides),
+                                            int(bool(normalize)), _p(out), int(bool(half)), _stream()),
+               "cppf_interpolate_features")
+    return out.T[None]

@@ -255,6 +255,16 @@ int64_t cppf_voxel_downsample_workspace_bytes(int64_t n);
 int cppf_voxel_downsample(const float* pts, int n, float res, uint64_t seed, int32_t* out_idx, int32_t* out_count,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* DINO-branch feature plumbing: replaces interpolate_features (dataset.py:40-59) = grid_sample
+ * (bilinear, zeros padding, align_corners=False) of the patch-token map desc at the pixel centres of pts float32[n,2]
+ * (x, y), then L2 normalisation over the C channels.  desc is addressed as desc[c*stride_c + y*stride_y + x*stride_x]
+ * (elements): patch-major tokens [h*w, C] -> (1, w*C, C); the reference's NCHW view -> (h*w, w, 1).  strides = the
+ * reference's `strides` (pixels per token).  out: float32[n,C], or float16[n,C] when out_f16 (BASELINE config 5's
+ * fp16 feature tables).  Needs 16*C bytes of LDS: C <= 4096. */
+int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t stride_c, int64_t stride_y,
+                              int64_t stride_x, const float* pts, int n, float strides, int normalize, void* out,
+                              int out_f16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -569,3 +569,35 @@ def refine_pose(pc, idx2, pred_pairs_scaled, T_est, R_est, y_only, steps=100, lr
     if return_trace:
         return t, R_new, trace
     return t, R_new
+
+
+# ----------------------------------------------------------------------------
+# DINO-branch feature plumbing, dataset.py:40-59
+# ----------------------------------------------------------------------------
+def interpolate_features(descriptors, pts, strides=8, normalize=True):
+    """interpolate_features(descriptors[1,C,h,w], pts[n,2] (x, y) pixels) -> [n, C]: F.grid_sample(bilinear, zeros
+    padding, align_corners=False) at the pixel centres, then F.normalize over the channels (dataset.py:40-59;
+    returned keypoint-major like DINOV2.forward does, dataset.py:79-80).  float32 like torch."""
+    d = np.asarray(descriptors, dtype=F32)
+    d = d[0] if d.ndim == 4 else d
+    C, h, w = d.shape
+    p = np.asarray(pts, dtype=F32).reshape(-1, 2)
+    gx = ((p[:, 0] + F32(0.5)) / F32(w) / F32(strides)) * F32(2) - F32(1)            # dataset.py:46-47
+    gy = ((p[:, 1] + F32(0.5)) / F32(h) / F32(strides)) * F32(2) - F32(1)
+    ix = ((gx + F32(1)) * F32(w) - F32(1)) / F32(2)                                   # grid_sampler_unnormalize
+    iy = ((gy + F32(1)) * F32(h) - F32(1)) / F32(2)
+    x0, y0 = np.floor(ix), np.floor(iy)
+    x1, y1 = x0 + 1, y0 + 1
+    wts = (((x1 - ix) * (y1 - iy), x0, y0), ((ix - x0) * (y1 - iy), x1, y0),
+           ((x1 - ix) * (iy - y0), x0, y1), ((ix - x0) * (iy - y0), x1, y1))          # nw, ne, sw, se
+    out = np.zeros((p.shape[0], C), dtype=F32)
+    for wgt, xs, ys in wts:
+        ok = (xs >= 0) & (xs <= w - 1) & (ys >= 0) & (ys <= h - 1)
+        xi = np.clip(xs, 0, w - 1).astype(np.int64)
+        yi = np.clip(ys, 0, h - 1).astype(np.int64)
+        val = d[:, yi, xi].T                                                           # [n, C]
+        out += np.where(ok[:, None], val * wgt.astype(F32)[:, None], F32(0)).astype(F32)
+    if normalize:
+        nrm = np.sqrt((out.astype(F32) ** 2).sum(1, dtype=F32)).astype(F32)
+        out = out / np.maximum(nrm, F32(1e-12))[:, None]
+    return out.astype(F32)

@@ -127,3 +127,15 @@ def test_full_size_summary(full_summary):
         # Tolerance: at most 4 of 720 bins off, each by no more than two votes of the largest weight.
         d = np.abs(allc - fs[name + "_counts"])
         assert (d > 0).sum() <= 4 and d.max() <= 2.0 / ipw.min()
+
+
+def test_interpolate_features_matches_the_reference_golden():
+    """dataset.py:40-59 (grid_sample bilinear + normalize), vectors from the reference itself
+    (tests/golden/make_golden_dino.py): image corners, pixel centres, far-outside keypoints included."""
+    g = np.load(os.path.join(GOLDEN, "dino_interp.npz"))
+    for name, norm in (("normalized", True), ("raw", False)):
+        got = O.interpolate_features(g["desc"], g["pts"], int(g["stride"]), norm)
+        assert got.shape == g[name].shape
+        assert np.abs(got - g[name]).max() < 2e-6, name
+    far = O.interpolate_features(g["desc"], g["pts"][4:6], int(g["stride"]), False)
+    assert np.all(far == 0)                                   # zeros padding
