@@ -171,22 +171,35 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
     if summary and "rot_err_deg" in summary[0]:
         ok = [s["rot_err_deg"] < 5 and s["tr_err_cm"] < 5 for s in summary]
         report["acc_5deg_5cm"] = float(np.mean(ok))
+    # the reference's per-image result record (eval.py:143-147, 370-372, 399): pred_RTs [n,4,4] (rotation scaled by the
+    # scale norm), pred_scales [n,3] (normalised); identity / ones for instances no enabled branch produced
+    from cppf2_amd import metrics
+    cls_id = int(cfg.get("category", 0))
+    pred_RTs, pred_scales = np.stack([np.eye(4) for _ in range(B)]), np.ones((B, 3))
+    for item in summary:
+        pred_RTs[item["scene"]] = np.array(item["pred_RT"])
+        if item["pred_scale"] is not None:
+            pred_scales[item["scene"]] = np.array(item["pred_scale"])
+    gt = {}
+    if scenes[0]["R"] is not None:                      # synthetic scenes carry their pose: unit-scale ground truth
+        gt_RTs = np.stack([np.eye(4) for _ in range(B)])
+        for b_, sc in enumerate(scenes):
+            gt_RTs[b_, :3, :3], gt_RTs[b_, :3, 3] = sc["R"], sc["t"]
+        gt = dict(gt_class_ids=np.full((B,), cls_id), gt_RTs=gt_RTs, gt_scales=np.ones((B, 3)))
+    # all instances of the run form one record, like the instances of one image in the reference
+    record = metrics.make_result_record(np.full((B,), cls_id), pred_RTs, pred_scales, None, **gt)
+    if gt and 0 < cls_id < len(metrics.SYNSET_NAMES):
+        aps = metrics.pose_mAP([record])                # eval.py:400-410 (degree / cm part)
+        report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): float(aps[cls_id, i_, j_])
+                             for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
+    if out_pkl:
+        import pickle
+        with open(out_pkl, "wb") as f:
+            pickle.dump(record, f)
     print(json.dumps(report if debug else {k_: v for k_, v in report.items() if k_ != "results"}))
     if out:
         with open(out, "w") as f:
             json.dump(report, f)
-    if out_pkl:
-        # the reference's per-image result record (eval.py:143-147, 370-372, 399): pred_RTs [n,4,4] (rotation scaled by
-        # the scale norm), pred_scales [n,3] (normalised); identity / ones for instances no enabled branch produced
-        import pickle
-        res = dict(pred_RTs=np.stack([np.eye(4) for _ in range(B)]), pred_scales=np.ones((B, 3)),
-                   pred_class_ids=np.full((B,), int(cfg.get("category", 0))))
-        for item in summary:
-            res["pred_RTs"][item["scene"]] = np.array(item["pred_RT"])
-            if item["pred_scale"] is not None:
-                res["pred_scales"][item["scene"]] = np.array(item["pred_scale"])
-        with open(out_pkl, "wb") as f:
-            pickle.dump(res, f)
     return report
 
 

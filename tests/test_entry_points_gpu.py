@@ -78,6 +78,11 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     assert res["pred_RTs"].shape == (3, 4, 4) and res["pred_scales"].shape == (3, 3)
     assert np.allclose(res["pred_RTs"][:, 3], [0, 0, 0, 1])
     assert rep["acc_5deg_5cm"] >= 2 / 3
+    # the record is what the pose-mAP scorer (cppf2_amd.metrics.pose_mAP == the reference toolkit) consumes
+    from cppf2_amd import metrics
+    assert set(metrics.RESULT_KEYS) <= set(res) and res["gt_RTs"].shape == (3, 4, 4)
+    assert rep["pose_AP"]["15deg_15cm"] >= rep["pose_AP"]["5deg_5cm"] >= 0.0
+    assert abs(metrics.pose_mAP([res])[1, 0, 0] - rep["pose_AP"]["5deg_5cm"]) < 1e-12
     for r in rep["results"]:
         assert r["model"] in ("dino", "shot") and np.isfinite(r["loss"])
     # branch gating keeps the reference's swapped names: geo_branch gates the DINO model

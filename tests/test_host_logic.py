@@ -141,3 +141,27 @@ def test_example_data_backproject_golden(full_summary):
     pc[:, :2] = -pc[:, :2]
     keep = geometry.downsample(pc.astype(np.float32), 2e-3, np.random.RandomState(0))
     assert len(keep) == 4251
+
+
+def test_pose_map_scorer_matches_the_reference_toolkit():
+    """degree/cm pose AP == the reference's compute_degree_cm_mAP (utils/util.py:2736-2955) on 40
+    synthetic images in the on-disk record format (golden: tests/golden/make_golden_map.py)."""
+    import pickle
+    from cppf2_amd import metrics
+    with open(os.path.join(GOLDEN, "map_results.pkl"), "rb") as f:
+        g = pickle.load(f)
+    aps = metrics.pose_mAP(g["results"], g["synset_names"], (5, 10, 15), (5, 10, 15))
+    assert aps.shape == g["pose_aps"].shape == (8, 4, 4)
+    assert np.allclose(aps, g["pose_aps"], rtol=0, atol=1e-12, equal_nan=True)
+    assert 0.05 < aps[-1, 0, 0] < aps[-1, -1, -1] <= 1.0
+    # the record builder writes what the scorer (and the reference's pickles) expect
+    r0 = g["results"][0]
+    rec = metrics.make_result_record(r0["pred_class_ids"], r0["pred_RTs"], r0["pred_scales"], r0["pred_scores"],
+                                     r0["gt_class_ids"], r0["gt_RTs"], r0["gt_scales"], r0["gt_handle_visibility"])
+    assert set(metrics.RESULT_KEYS) <= set(rec) and rec["pred_RTs"].dtype == np.float64
+    one = metrics.pose_mAP([rec], g["synset_names"])
+    assert np.allclose(one, metrics.pose_mAP([r0], g["synset_names"]), equal_nan=True)
+    # perfect predictions score 1 for every class that occurs
+    perfect = [metrics.make_result_record(r["gt_class_ids"], r["gt_RTs"], r["gt_scales"], None, r["gt_class_ids"],
+                                          r["gt_RTs"], r["gt_scales"], r["gt_handle_visibility"]) for r in g["results"]]
+    assert np.allclose(metrics.pose_mAP(perfect, g["synset_names"])[1:, 0, 0], 1.0)
