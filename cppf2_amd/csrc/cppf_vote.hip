@@ -85,50 +85,11 @@ __device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx,
   return ((int)fx * gy + (int)fy) * gz + (int)fz;
 }
 
-// One coordinate without the IEEE division.  num = (c+off)-c0 exactly as the reference computes it; the
-// reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fma(num, rinv, 0.5) differs from it by at most
-// (|q|+1) * 3e-7 (rounded reciprocal + one rounding vs quotient rounding + add rounding), so whenever t is
-// farther than m = (g+2)*1e-6 from every integer, trunc(t) == trunc(t_ref) and both validity tests
-// (cell > 0, cell < g) agree.  Otherwise (t on a cell boundary, NaN, far outside) `sure` is cleared and the
-// caller decides with the exact arithmetic.
-__device__ __forceinline__ int cell_fast(float num, float rinv, float m, bool& sure) {
-  const float t = fmaf(num, rinv, 0.5f);
-  const float fl = floorf(t);
-  const float fr = t - fl;
-  sure = sure & (fr >= m) & (fr <= 1.0f - m) & (fabsf(t) < 16777216.0f);
-  return (int)fl;
-}
-
-__device__ __noinline__ int vote_cell_exact_lin(float nx, float ny, float nz, float res, int gx, int gy, int gz) {
-  const float fx = nx / res + 0.5f, fy = ny / res + 0.5f, fz = nz / res + 0.5f;
-  const bool ok = (fx >= 1.0f) & (fy >= 1.0f) & (fz >= 1.0f) & (fx < (float)gx) & (fy < (float)gy) & (fz < (float)gz);
-  if (!ok) return -1;
-  return ((int)fx * gy + (int)fy) * gz + (int)fz;
-}
-
-struct GridConst {
-  float c0x, c0y, c0z, res, rinv, mx, my, mz;
-  int gx, gy, gz;
-};
-
-__device__ __forceinline__ int vote_cell_fast(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
-                                              float yy, float yz, float cs, float sn, const GridConst& gc) {
-  const float ox = cs * xx + sn * yx;
-  const float oy = cs * xy + sn * yy;
-  const float oz = cs * xz + sn * yz;
-  const float nx = (cx + ox) - gc.c0x, ny = (cy + oy) - gc.c0y, nz = (cz + oz) - gc.c0z;
-  bool sure = true;
-  const int ix = cell_fast(nx, gc.rinv, gc.mx, sure);
-  const int iy = cell_fast(ny, gc.rinv, gc.my, sure);
-  const int iz = cell_fast(nz, gc.rinv, gc.mz, sure);
-  if (__builtin_expect(!sure, 0)) {
-    // certainly outside (by more than the rounding margin)?  then no exact arithmetic is needed either
-    return vote_cell_exact_lin(nx, ny, nz, gc.res, gc.gx, gc.gy, gc.gz);
-  }
-  const bool ok = ((unsigned)(ix - 1) < (unsigned)(gc.gx - 1)) & ((unsigned)(iy - 1) < (unsigned)(gc.gy - 1)) &
-                  ((unsigned)(iz - 1) < (unsigned)(gc.gz - 1));
-  return ok ? (ix * gc.gy + iy) * gc.gz + iz : -1;
-}
+// Cell of a vote without the IEEE division (vote_cell_packed below).  num = (c+off)-c0 exactly as the reference
+// computes it; the reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fma(num, rinv, 0.5) differs from it by at
+// most (|q|+1) * 3e-7 (rounded reciprocal + one rounding vs quotient rounding + add rounding), so whenever t is
+// farther than m = (g+2)*1e-6 from every integer, floor(t) == trunc(t_ref) and both validity tests (cell > 0,
+// cell < g) agree.  Otherwise (t on a cell boundary, NaN, far outside) the vote is redone with the exact arithmetic.
 
 // Vote weight in accumulator units: 1 per vote when no weights are given (the reference, train_dino.py:204);
 // otherwise round(w * 256), w clamped to [0, 4] (deterministic integer accumulation: the "uncertainty-weighted"
@@ -240,7 +201,7 @@ struct GridFast {
 };
 
 // Flat cell of one vote on the fast path, or a negative value; `sure` is cleared when the caller has to redo the vote
-// with vote_cell_exact below.  Same decision procedure as cell_fast above (multiply by the rounded reciprocal;
+// with vote_cell_exact below.  The decision procedure described above (multiply by the rounded reciprocal;
 // whenever a coordinate lands within the rounding margin of a cell boundary -- or is NaN / huge -- the exact IEEE
 // divisions decide), arranged branch-free for the packed-fp32 pipe: y and z travel as one register pair.  x is
 // clamped to [0, gx] instead of tested: x-layer 0 and layer gx fall outside every slab's valid window (lo_eff in the
@@ -339,15 +300,11 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   const int ts = pc * per, te = min(nt, ts + per);
   const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
   const float c0x = g.c0[0], c0y = g.c0[1], c0z = g.c0[2];
-  GridConst gc;
-  gc.c0x = c0x; gc.c0y = c0y; gc.c0z = c0z; gc.res = res; gc.rinv = 1.0f / res;
-  gc.mx = (float)(gx + 2) * 1e-6f; gc.my = (float)(gy + 2) * 1e-6f; gc.mz = (float)(gz + 2) * 1e-6f;
-  gc.gx = gx; gc.gy = gy; gc.gz = gz;
   const int gyz = gy * gz;
   const int xl = lo / gyz, xh = (lo + n - 1) / gyz;            // x-layers this slab touches
   GridFast gf;
-  gf.c0x = c0x; gf.res = res; gf.rinv = gc.rinv; gf.c0yz.x = c0y; gf.c0yz.y = c0z;
-  gf.hm = 0.5f - fmaxf(gc.mx, fmaxf(gc.my, gc.mz));
+  gf.c0x = c0x; gf.res = res; gf.rinv = 1.0f / res; gf.c0yz.x = c0y; gf.c0yz.y = c0z;
+  gf.hm = 0.5f - (float)(max(gx, max(gy, gz)) + 2) * 1e-6f;
   gf.gx = gx; gf.gy = gy; gf.gz = gz;
   // the packed cell index uses 24-bit multiplies: (gx + 1) * gy must stay below 2^23 (any grid the reference
   // accepts, eval.py:200, is far below); wider grids take the exhaustive sweep with 32-bit arithmetic
