@@ -161,7 +161,7 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
 
 STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_cov_kernel", "shot352": "shot_hist_kernel",
                 "encode_tuples": "encode_shot_kernel<5, 16>", "decode_bins": "decode_bins_kernel<32>",
-                "vote_frames": "vote_frames_kernel", "vote_center": "vote_center_slab_kernel<true>", "backvote_filter": "backvote_kernel",
+                "vote_frames": "vote_frames_kernel", "vote_center": "vote_center_persist_kernel", "backvote_filter": "backvote_kernel",
                 "rot_bins": "rot_bins_lut_kernel", "assemble_pose": "assemble_pose_kernel"}
 
 

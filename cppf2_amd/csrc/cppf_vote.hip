@@ -257,38 +257,19 @@ __device__ __forceinline__ FrameRegs load_frame(const float* __restrict__ fr, in
   return f;
 }
 
+// One work item of the slab scheme: scene b, slab s (n cells from flat cell lo), part pc of Pl of the scene's pair
+// list.  Called by the one-item-per-workgroup kernel (small batches) and by the persistent kernel (work list).
 template <bool ARCS>
-__global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_kernel(
-    const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
-    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
+__device__ __forceinline__ void vote_slab_item(
+    uint32_t* slab, const float2* s_trig, volatile int* s_mark, int& tag, int b, int s, int pc, int Pl,
+    const CppfSceneGrid& g, int G, const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off,
+    float res, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
     SlabBest* __restrict__ slab_best, int s_max, int P) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
-  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
-  // per-wavefront strip of 64 owner marks (ARCS only), behind the largest table the arcs path accepts
-  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
-                         (threadIdx.x >> 6) * 64;
-  int tag = 0;
-  // grid = (scene, P, slab rank): the slab rank is the slowest dimension of the dispatch order
-  const int pc = blockIdx.y, rank = blockIdx.z;
-  // workgroup id % 8 selects the XCD: rotating the scene by the slab rank spreads a scene's slabs (and the uneven
-  // scene sizes) over all XCDs instead of pinning 8 whole scenes to each (measured 5 % faster)
-  const int b = (blockIdx.x + rank) % gridDim.x;
   const long long t_start = wall_clock64();
-  const CppfSceneGrid g = grids[b];
-  const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
-  const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
-  if (rank >= nslab) return;
-  // centre-out permutation of 0..nslab-1: mid, mid-1, mid+1, mid-2, ... (heavy central slabs dispatched first)
-  const int mid = nslab >> 1, dd = (rank + 1) >> 1;
-  const int s = (rank & 1) ? mid - dd : mid + dd;
   const int lo = s * VC_SLAB_CELLS;
   const int n = min(VC_SLAB_CELLS, G - lo);
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
-  if (ARCS) {
-    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
-    s_mark[threadIdx.x & 63] = 0;
-  }
   __syncthreads();
 #ifdef VC_DIAG
   const long long t_a = wall_clock64();
@@ -296,7 +277,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
 #endif
 
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
-  const int per = (nt + P - 1) / P;
+  const int per = (nt + Pl - 1) / Pl;
   const int ts = pc * per, te = min(nt, ts + per);
   const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
   const float c0x = g.c0[0], c0y = g.c0[1], c0z = g.c0[2];
@@ -450,6 +431,117 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   }
 }
 
+
+// (scene, part, slab rank) -> one item per workgroup: small batches (pair lists split P ways, merged with global
+// atomics) and the exhaustive A/B mode
+template <bool ARCS>
+__global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_kernel(
+    const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
+    uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
+    SlabBest* __restrict__ slab_best, int s_max, int P) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
+  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
+  // per-wavefront strip of 64 owner marks (ARCS only), behind the largest table the arcs path accepts
+  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
+                         (threadIdx.x >> 6) * 64;
+  int tag = 0;
+  const int pc = blockIdx.y, rank = blockIdx.z;
+  const int b = (blockIdx.x + rank) % gridDim.x;
+  const CppfSceneGrid g = grids[b];
+  const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
+  const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+  if (rank >= nslab) return;
+  // centre-out permutation of 0..nslab-1: mid, mid-1, mid+1, mid-2, ... (heavy central slabs dispatched first)
+  const int mid = nslab >> 1, dd = (rank + 1) >> 1;
+  const int s = (rank & 1) ? mid - dd : mid + dd;
+  if (ARCS) {
+    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
+    s_mark[threadIdx.x & 63] = 0;
+  }
+  vote_slab_item<ARCS>(slab, s_trig, s_mark, tag, b, s, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
+                       grid, grid_off, cells_cap, slab_best, s_max, P);
+}
+
+// Work list of the persistent kernel: one entry (scene | slab << 16) per existing slab, in the order they should start
+// -- slab rank (centre-out, heavy slabs first) outermost, scenes rotated by the rank.  One workgroup, block scans.
+// (Halving the pair lists of the heavy slabs over two workgroups that merge through memory was built and measured:
+// perfectly balanced CUs, but the extra zero / reduce / merge passes cost what the balance gained.)
+__global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid* __restrict__ grids, int B,
+                                                             int64_t cells_cap, int s_max,
+                                                             uint32_t* __restrict__ list, int* __restrict__ ctl) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base, s_maxn;
+  if (threadIdx.x == 0) { s_base = 0; s_maxn = 0; }
+  __syncthreads();
+  // slabs of the largest scene bound the ranks that exist at all
+  int mx = 0;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
+    mx = max(mx, (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
+  }
+  if (mx > 0) atomicMax(&s_maxn, mx);
+  __syncthreads();
+  const int64_t cand = (int64_t)B * min(s_maxn, s_max);             // (rank, scene slot) candidates, rank-major
+  for (int64_t base = 0; base < cand; base += 1024) {
+    const int64_t c = base + threadIdx.x;
+    int cnt = 0, b = 0, s = 0;
+    if (c < cand) {
+      const int rank = (int)(c / B), x = (int)(c % B);
+      b = (x + rank) % B;
+      const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
+      const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+      if (rank < nslab) {
+        cnt = 1;
+        const int mid = nslab >> 1, dd = (rank + 1) >> 1;
+        s = (rank & 1) ? mid - dd : mid + dd;
+      }
+    }
+    const int incl = wave_incl_scan_add(cnt);
+    if (wave_lane() == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += s_wave[w];
+    off += incl - cnt;
+    if (cnt) list[off] = (uint32_t)b | ((uint32_t)s << 16);
+    __syncthreads();
+    if (threadIdx.x == 1023) s_base = off + cnt;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = s_base; }       // next item, item count
+}
+
+// Persistent form for throughput-sized batches: one workgroup per CU pulls (scene, slab) items from the work
+// list -- no empty workgroups (the (scene, rank) launch has ~5 per real one, each needing a CU's whole LDS just to
+// exit), list scheduling in the intended order regardless of the dispatcher, the table staged once per CU.
+__global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_kernel(
+    const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
+    uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
+    SlabBest* __restrict__ slab_best, int s_max, const uint32_t* __restrict__ list, int* __restrict__ ctl) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
+  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);
+  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
+                         (threadIdx.x >> 6) * 64;
+  __shared__ int s_item;
+  int tag = 0;
+  for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
+  s_mark[threadIdx.x & 63] = 0;
+  const int count = ctl[1];
+  for (;;) {
+    __syncthreads();                                   // previous item's epilogue is done with the slab and s_item
+    if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= count) break;
+    const uint32_t e = list[item];
+    const int b = (int)(e & 0xffffu), s = (int)(e >> 16);
+    const CppfSceneGrid g = grids[b];
+    vote_slab_item<true>(slab, s_trig, s_mark, tag, b, s, 0, 1, g, g.ncell, fr, total, tup_off, res, num_rots, cos_tab,
+                         sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1);
+  }
+}
+
 __global__ __launch_bounds__(256) void vote_center_global_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
     const int32_t* __restrict__ tup_off, const float* __restrict__ tr, const float* __restrict__ vote_wt, float res,
@@ -559,7 +651,7 @@ static inline int vc_parts(int64_t cells_cap) {
 extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples) {
   if (B <= 0 || cells_cap <= 0 || total_tuples < 0) return 0;
   return align_up((int64_t)B * vc_parts(cells_cap) * (int64_t)sizeof(SlabBest), 256) +
-         align_up((int64_t)B * cells_cap * 4, 256) + align_up(total_tuples * VC_FRAME_FLOATS * 4, 256);
+         align_up((int64_t)B * vc_parts(cells_cap) * 4 + 256, 256) + align_up((int64_t)B * cells_cap * 4, 256) + align_up(total_tuples * VC_FRAME_FLOATS * 4, 256);
 }
 
 extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
@@ -577,12 +669,16 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
   const int s_max_parts = vc_parts(cells_cap);
   SlabBest* best = (SlabBest*)workspace;
   char* wsp = (char*)workspace + align_up((int64_t)B * s_max_parts * sizeof(SlabBest), 256);
+  int* ws_ctl = (int*)wsp;                        // persistent kernel: next item, item count, then the work list
+  uint32_t* ws_list = (uint32_t*)(wsp + 256);
+  wsp += align_up((int64_t)B * s_max_parts * 4 + 256, 256);
   uint32_t* ws_grid = (uint32_t*)wsp;
   float* frames = (float*)(wsp + align_up((int64_t)B * cells_cap * 4, 256));
   const int s_max = (int)((cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
   // two-call form (lets a caller put events around the vote kernel alone): CPPF_VC_FRAMES_ONLY fills the per-pair
   // frames in the workspace and returns; CPPF_VC_FRAMES_READY skips that step
   const bool frames_only = (mode & CPPF_VC_FRAMES_ONLY) != 0, frames_ready = (mode & CPPF_VC_FRAMES_READY) != 0;
+  const int mode_bits = mode;                     // bit 11 (0x800): one-item-per-workgroup launch even for big batches
   mode &= 0xff;
   if (mode == 0) mode = (s_max <= 64) ? 1 : 2;
   int exhaustive = 0;
@@ -619,13 +715,31 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
       CPPF_LAUNCH_CHECK();
     }
+    // throughput-sized batches (more (scene, slab) items than CUs) run the persistent work-list form
+    const bool persist = arcs && P == 1 && wgs >= 256 && B <= 0xffff && s_max <= 0xffff && (mode_bits & 0x800) == 0;
     if (!frames_ready) {
       hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
                          tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
+      if (persist)      // the work list belongs to the preparation half of the two-call form
+        hipLaunchKernelGGL(vote_worklist_kernel, dim3(1), dim3(1024), 0, st, grids, B, cells_cap, s_max, ws_list, ws_ctl);
       CPPF_LAUNCH_CHECK();
     }
     if (frames_only) return CPPF_OK;
-    if (arcs)
+    if (persist) {
+      static int num_cus = 0;
+      if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        CPPF_HIP(hipGetDevice(&dev));
+        CPPF_HIP(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_persist_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      }
+      hipLaunchKernelGGL(vote_center_persist_kernel, dim3(num_cus), dim3(VC_THREADS), lds_bytes, st, frames,
+                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap, best,
+                         s_max_parts, ws_list, ws_ctl);
+    } else if (arcs)
       hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
                          total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
                          best, s_max_parts, P);

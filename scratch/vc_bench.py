@@ -37,7 +37,7 @@ e1.record(); torch.cuda.synchronize()
 res = pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8)
 print(stage, "mode", mode, "B", B, "ms/launch %.3f" % (e0.elapsed_time(e1) / reps), "mean cells", res[:, 6].mean(), "argmax0", int(pipe.argmax[0]))
 
-if stage == "vote_center" and mode in (0, 1):
+if stage == "vote_center" and (mode & 0xff) in (0, 1):
     import ctypes
     smp = max((pipe.cells_cap + 36864 - 1) // 36864, 32)
     raw = pipe.ws[:B * smp * 16].cpu().numpy().view(np.uint32).reshape(B, smp, 4)
