@@ -116,10 +116,9 @@ class Step:
         x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
         self._mark("encode_tuples")
         logits, scales = self.model.heads(x)
-        logits = logits.add_(self.prior)
         self._mark("tuple_mlp_torch")
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
-        pipe.decode(self.pts, idx, logits, u)
+        pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
         self._mark("decode_bins")
         pipe.vote_center(self.pts, idx, phase=1)      # scene bounds + per-pair circle frames
         self._mark("vote_frames")
@@ -146,7 +145,7 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
         "shot_frames": N * 12 * 2 + N * 12 + N * 19 * 8 * 2 + N * 56,   # points in+sorted, normals out, sums w+r, frames
         "shot352": N * 12 + N * 12 + N * 56 + N * 352 * 4,
         "encode_tuples": T * 5 * 4 + N * 12 + N * 12 + N * 64 * 4 + T * 360 * 4,
-        "decode_bins": T * 6 * 32 * 4 + T * 6 * 4 + T * 8 + T * (8 + 12 + 24 + 4 + 24),
+        "decode_bins": 2 * T * 6 * 32 * 4 + T * 6 * 4 + T * 8 + T * (8 + 12 + 24 + 4 + 24),   # logits + prior read
         # idx + tr + points, grid clear G*4, one 4-byte accumulator update per vote (V = T*R), argmax
         # read G*4.  (This implementation keeps the accumulator in LDS slabs, so its HBM traffic -- `traffic` -- is
         # well below this figure: the frames workspace and the per-slab re-reads of it.)

@@ -387,8 +387,8 @@ extern "C" int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* 
 // three passes over the (L1-resident) logit line instead of a runtime-indexed array (which would spill).
 template <int NB>
 __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
-    int B, const float* __restrict__ logits, int nb_rt, const float* __restrict__ uniforms,
-    const float* __restrict__ pts, const int32_t* __restrict__ idx, int k, const int32_t* __restrict__ pt_off,
+    int B, const float* __restrict__ logits, const float* __restrict__ prior, int nb_rt,
+    const float* __restrict__ uniforms, const float* __restrict__ pts, const int32_t* __restrict__ idx, int k, const int32_t* __restrict__ pt_off,
     const int32_t* __restrict__ tup_off, int64_t total, Axes9 axes, int32_t* __restrict__ bins,
     float* __restrict__ scaled, float* __restrict__ scale_out, float* __restrict__ tr, float* __restrict__ rot) {
   __shared__ int s_bin[DEC_TUPLES * 6];
@@ -409,6 +409,14 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
           const float4 v = lg4[j];
           e[4 * j + 0] = v.x; e[4 * j + 1] = v.y; e[4 * j + 2] = v.z; e[4 * j + 3] = v.w;
         }
+        if (prior) {           // additive logit prior: one float32 add per logit, like `logits + prior` in torch
+          const float4* pr4 = reinterpret_cast<const float4*>(prior + (t * 6 + c) * nb);
+#pragma unroll
+          for (int j = 0; j < NB / 4; ++j) {
+            const float4 v = pr4[j];
+            e[4 * j + 0] += v.x; e[4 * j + 1] += v.y; e[4 * j + 2] += v.z; e[4 * j + 3] += v.w;
+          }
+        }
         float m = e[0];
 #pragma unroll
         for (int j = 1; j < NB; ++j) m = fmaxf(m, e[j]);
@@ -419,13 +427,15 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
 #pragma unroll
         for (int j = 0; j < NB; ++j) cnt += (e[j] <= target) ? 1 : 0;        // first j with cdf[j] > target
       } else {
-        float m = lg[0];
-        for (int j = 1; j < nb; ++j) m = fmaxf(m, lg[j]);
+        const float* pr = prior ? prior + (t * 6 + c) * nb : nullptr;
+        auto at = [&](int j) { return pr ? lg[j] + pr[j] : lg[j]; };
+        float m = at(0);
+        for (int j = 1; j < nb; ++j) m = fmaxf(m, at(j));
         float acc = 0.0f;
-        for (int j = 0; j < nb; ++j) acc += expf(lg[j] - m);
+        for (int j = 0; j < nb; ++j) acc += expf(at(j) - m);
         const float target = uniforms[t * 6 + c] * acc;
         float run = 0.0f;
-        for (int j = 0; j < nb; ++j) { run += expf(lg[j] - m); cnt += (run <= target) ? 1 : 0; }
+        for (int j = 0; j < nb; ++j) { run += expf(at(j) - m); cnt += (run <= target) ? 1 : 0; }
       }
       bin = cnt < nb - 1 ? cnt : nb - 1;
       if (bins) bins[t * 6 + c] = bin;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
   }
 }
 
-extern "C" int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
+extern "C" int cppf_decode_bins(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms, const float* pts,
                                 const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                                 int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,
                                 float* scale, float* tr, float* rot, void* stream) {
@@ -479,11 +489,11 @@ extern "C" int cppf_decode_bins(int B, const float* logits, int nb, const float*
   const int64_t blocks = (total_tuples + DEC_TUPLES - 1) / DEC_TUPLES;
   if (nb == 32)
     hipLaunchKernelGGL(decode_bins_kernel<32>, dim3((unsigned)blocks), dim3(DEC_TUPLES * 6), 0, (hipStream_t)stream,
-                       B, logits, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
+                       B, logits, logit_prior, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
                        tr, rot);
   else
     hipLaunchKernelGGL(decode_bins_kernel<0>, dim3((unsigned)blocks), dim3(DEC_TUPLES * 6), 0, (hipStream_t)stream,
-                       B, logits, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
+                       B, logits, logit_prior, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, ax, bins, scaled, scale,
                        tr, rot);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;

@@ -276,7 +276,7 @@ def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=N
 # ----------------------------------------------------------------------------------------------
 # a4 + a5. decode
 # ----------------------------------------------------------------------------------------------
-def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt_off=None, tup_off=None):
+def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt_off=None, tup_off=None, prior=None):
     """eval.py:225-240.  pred_cls [T,6,nb] logits, uniforms [T,6] in [0,1).  (up, right, front) are the three
     axis vectors in the positional order of generate_target_pairs' signature (the reference call site passes
     cfg.up, cfg.front, cfg.right).  Returns dict(bins, pred_pairs_scaled [T,2,3], scale, targets_tr, targets_rot)."""
@@ -296,7 +296,8 @@ def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt
     scale = torch.empty((T,), dtype=torch.float32, device=dev)
     tr = torch.empty((T, 2), dtype=torch.float32, device=dev)
     rot = torch.empty((T, 3), dtype=torch.float32, device=dev)
-    _lib.check(_L.cppf_decode_bins(B, _p(lg), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
+    pr = None if prior is None else _t(prior, torch.float32, dev).reshape(T, 6, nb)
+    _lib.check(_L.cppf_decode_bins(B, _p(lg), _p(pr), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
                                    _axes9(up, right, front), _p(bins), _p(scaled), _p(scale), _p(tr), _p(rot),
                                    _stream()), "cppf_decode_bins")
     return dict(bins=bins, pred_pairs_scaled=scaled, scale=scale, targets_tr=tr, targets_rot=rot)

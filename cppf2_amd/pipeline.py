@@ -91,8 +91,9 @@ class VotingPipeline:
         self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
 
     # -- stages ---------------------------------------------------------------------------------
-    def decode(self, pts, idx, logits, uniforms):
-        _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), logits.shape[-1], ops._p(uniforms), ops._p(pts),
+    def decode(self, pts, idx, logits, uniforms, prior=None):
+        """prior (optional, same shape as logits) is added to the logits inside the kernel (== logits + prior)."""
+        _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), ops._p(prior), logits.shape[-1], ops._p(uniforms), ops._p(pts),
                                        ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
                                        self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
                                        ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")

@@ -129,8 +129,11 @@ int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k,
  * logits: float32[T,6,nb] (nb <= 64); uniforms: float32[T,6]; h_axes: 9 doubles = the three axis vectors
  * in the positional order handed to generate_target_pairs (eval.py passes up, front, right).
  * Outputs (any may be NULL): bins int32[T,6], scaled float32[T,6] (pred_pairs_scaled), scale float32[T],
- * tr float32[T,2] (proj_len, dist2o), rot float32[T,3]. */
-int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
+ * tr float32[T,2] (proj_len, dist2o), rot float32[T,3].
+ * logit_prior (optional, same shape as logits): added to the logits before the softmax with one float32 add each
+ * (an extension: a per-bin prior without a separate pass over the 15 MB/scene logit tensor; NULL = none). */
+int cppf_decode_bins(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms,
+                     const float* pts,
                      const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                      int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled, float* scale,
                      float* tr, float* rot, void* stream);

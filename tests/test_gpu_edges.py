@@ -112,3 +112,19 @@ def test_vote_center_two_call_form_equals_single_call():
     pipe.vote_center(pts, idx, phase=2)
     assert torch.equal(pipe.argmax, want[0]) and torch.equal(pipe.peak, want[1]) and torch.equal(pipe.world, want[2])
     assert int(pipe.peak.min()) > 0
+
+
+@pytest.mark.parametrize("nb", [32, 20])
+def test_decode_logit_prior_equals_adding_it_first(nb):
+    """cppf_decode_bins(logits, logit_prior) == cppf_decode_bins(logits + logit_prior): one float32 add per logit."""
+    rng = np.random.RandomState(8)
+    N, T = 300, 2000
+    pc = torch.from_numpy(rng.rand(N, 3).astype(np.float32)).cuda()
+    idx = torch.from_numpy(rng.randint(0, N, (T, 5)).astype(np.int32)).cuda()
+    lg = torch.from_numpy(rng.randn(T, 6, nb).astype(np.float32) * 3).cuda()
+    pr = torch.from_numpy(rng.randn(T, 6, nb).astype(np.float32) * 3).cuda()
+    u = torch.from_numpy(rng.rand(T, 6).astype(np.float32)).cuda()
+    a = ops.decode_bins(lg, u, pc, idx, (0, 1, 0), (0, 0, 1), (1, 0, 0), prior=pr)
+    b = ops.decode_bins(lg + pr, u, pc, idx, (0, 1, 0), (0, 0, 1), (1, 0, 0))
+    for k_ in a:
+        assert torch.equal(a[k_], b[k_]), k_
