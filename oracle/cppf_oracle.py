@@ -601,3 +601,38 @@ def interpolate_features(descriptors, pts, strides=8, normalize=True):
         nrm = np.sqrt((out.astype(F32) ** 2).sum(1, dtype=F32)).astype(F32)
         out = out / np.maximum(nrm, F32(1e-12))[:, None]
     return out.astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# steps in front of the path, utils/util.py:2586-2607 and 39-46
+# ----------------------------------------------------------------------------
+def backproject(depth, intrinsics, instance_mask):
+    """Masked depth -> points, same convention as utils/util.py:2586-2607: returns points with x and y NEGATED
+    (every caller negates them back, eval.py:187-188) and the (row, col) index arrays of the used pixels."""
+    depth = np.asarray(depth)
+    valid = np.logical_and(instance_mask, depth > 0)
+    rows, cols = np.nonzero(valid)
+    z = depth[rows, cols]
+    pix = np.stack([cols, rows, np.ones_like(cols)], 0).astype(np.float64)
+    rays = (np.linalg.inv(intrinsics) @ pix).T
+    pts = rays * z[:, None] / rays[:, -1:]
+    pts[:, 0] = -pts[:, 0]
+    pts[:, 1] = -pts[:, 1]
+    return pts, (rows, cols)
+
+
+def downsample(pc, res, rng=None):
+    """One randomly chosen point per `res` voxel (utils/util.py:39-46 does this with open3d's
+    voxel_down_sample_and_trace + np.random.choice); voxels are anchored at the cloud's min bound.
+    Returns the indices of the kept points, ordered by voxel key."""
+    pc = np.asarray(pc)
+    rng = np.random if rng is None else rng
+    key = np.floor((pc - pc.min(0)) / res).astype(np.int64)
+    dims = key.max(0) + 1
+    flat = (key[:, 0] * dims[1] + key[:, 1]) * dims[2] + key[:, 2]
+    order = np.argsort(flat, kind="stable")
+    sf = flat[order]
+    starts = np.flatnonzero(np.r_[True, sf[1:] != sf[:-1]])
+    counts = np.diff(np.r_[starts, len(sf)])
+    pick = starts + (rng.random_sample(len(starts)) * counts).astype(np.int64)
+    return order[pick]

@@ -177,12 +177,13 @@ def _example_inputs():
 
 def test_backproject_kernel_matches_the_reference_pinned_host_path():
     """cppf_backproject == utils/util.py:2586-2607 + eval.py:185-189 on the reference's example scene.  The host
-    restatement (geometry.backproject) is pinned to the reference's float64 output by SHA in test_host_logic; the
+    restatement (oracle backproject) is pinned to the reference's float64 output by SHA in test_host_logic; the
     kernel must reproduce its float32 cast bit for bit, in np.where order."""
     import hashlib
-    from cppf2_amd import geometry, ops
+    from cppf2_amd import ops
+    from oracle import cppf_oracle as O
     e, d, m, K = _example_inputs()
-    want64, (rows, cols) = geometry.backproject(d, K, m)
+    want64, (rows, cols) = O.backproject(d, K, m)
     assert hashlib.sha256(np.ascontiguousarray(want64).tobytes()).hexdigest() == e["sha"]
     want = want64.copy()
     want[:, :2] = -want[:, :2]
@@ -196,20 +197,21 @@ def test_backproject_kernel_matches_the_reference_pinned_host_path():
     rel = np.abs(got.astype(np.float64) - want) / np.abs(want).max()
     assert rel.max() < 2.5e-7
     # and it is bit-exact against the same float64 arithmetic fed the float32 depth
-    w2, _ = geometry.backproject(d.astype(np.float32).astype(np.float64), K, m)
+    w2, _ = O.backproject(d.astype(np.float32).astype(np.float64), K, m)
     w2[:, :2] = -w2[:, :2]
     assert np.array_equal(got, w2.astype(np.float32))
 
 
 def test_voxel_downsample_kernel_keeps_one_random_point_per_voxel():
-    from cppf2_amd import geometry, ops
+    from cppf2_amd import ops
+    from oracle import cppf_oracle as O
     e, d, m, K = _example_inputs()
     pc, _ = ops.backproject(d.astype(np.float32), K, m)
     res = 0.004
     key = np.floor((pc - pc.min(0)) / np.float32(res)).astype(np.int64)
     flat = (key[:, 0] << 42) | (key[:, 1] << 21) | key[:, 2]
     nvox = len(np.unique(flat))
-    assert nvox == len(geometry.downsample(pc, res, np.random.RandomState(0)))      # same voxelisation as the host helper
+    assert nvox == len(O.downsample(pc, res, np.random.RandomState(0)))      # same voxelisation as the host helper
     a = ops.downsample(pc, res, seed=5)
     assert len(a) == nvox and np.all(np.diff(a) > 0)                                # ascending, unique
     assert len(np.unique(flat[a])) == nvox                                          # exactly one per occupied voxel

