@@ -107,9 +107,9 @@ class Step:
         self._mark("sample_tuples")
         shotmod.prepare_device(self.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, self.normal)   # eval.py:210
         self._mark("shot_frames")
-        shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot)
+        shot = shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot,
+                                       nan_to_zero=True)                                   # eval.py:215 folded in
         self._mark("shot352")
-        shot = torch.nan_to_num_(self.shot, nan=0.0)                                       # eval.py:215-216
         normal = torch.nan_to_num_(self.normal, nan=0.0)
         feat = self.model.encode_points(shot)
         self._mark("shot_encoder_torch")

@@ -49,7 +49,7 @@ SIGNATURES = {
     "cppf_shot352": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i64, _p]),
     "cppf_shot352_from_normals": (_i, [_i, _p, _p, _i64, _p, _f, _p, _p, _p, _i64, _p]),
     "cppf_shot_prepare": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _i64, _p]),
-    "cppf_shot_describe": (_i, [_i, _p, _p, _i64, _p, _f, _p, _p, _p, _i64, _p]),
+    "cppf_shot_describe": (_i, [_i, _p, _p, _i64, _p, _f, _i, _p, _p, _p, _i64, _p]),
     "cppf_estimate_normals": (_i, [_i, _p, _p, _i64, _f, _p, _p, _i64, _p]),
     "cppf_encode_tuples_shot": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
     "cppf_encode_tuples_shot_f16": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const float4* __restrict__ sorted_pts,
                                                        const int32_t* __restrict__ scene_of,
                                                        const float4* __restrict__ sorted_nrm,
-                                                       const LrfPre* __restrict__ pre, float radius,
+                                                       const LrfPre* __restrict__ pre, float radius, int nan_to_zero,
                                                        float* __restrict__ out_shot,
                                                        float* __restrict__ out_rf) {
   __shared__ uint32_t s_hist[SH_COPIES * SH_STRIDE];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   const int valid = lp.valid;
   bool ok = valid >= 5;
   if (!ok || lp.nn < 5) {
-    for (int c = lane; c < SHOT_LEN; c += 64) o[c] = NAN;
+    for (int c = lane; c < SHOT_LEN; c += 64) o[c] = nan_to_zero ? 0.0f : NAN;
     if (out_rf && lane < 9) out_rf[9 * (int64_t)qi + lane] = NAN;
     if (!ok) return;
     // LRF exists but too few points for the descriptor: frame is still reported
@@ -688,7 +688,11 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   }
   acc = sqrt(wave_sum(acc));
   const float facc = (float)acc;
-  for (int c = lane; c < SHOT_LEN; c += 64) __builtin_nontemporal_store(__uint_as_float(s_hist[c]) / facc, &o[c]);
+  for (int c = lane; c < SHOT_LEN; c += 64) {
+    float v = __uint_as_float(s_hist[c]) / facc;
+    if (nan_to_zero && !(v == v)) v = 0.0f;            // an all-zero histogram normalises to 0/0
+    __builtin_nontemporal_store(v, &o[c]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -743,7 +747,7 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
                        normals_in ? normals_in : out_normal, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
     CPPF_LAUNCH_CHECK();
     hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                       w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, out_shot, out_rf);
+                       w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, 0, out_shot, out_rf);
     CPPF_LAUNCH_CHECK();
   }
   return CPPF_OK;
@@ -805,7 +809,8 @@ extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off,
 }
 
 extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
-                                  const float* normals, float shot_r, float* out_shot, float* out_rf, void* workspace,
+                                  const float* normals, float shot_r, int nan_to_zero, float* out_shot, float* out_rf,
+                                  void* workspace,
                                   int64_t workspace_bytes, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && normals && out_shot && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
@@ -816,8 +821,8 @@ extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off
                      (hipStream_t)stream, total_points, normals, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
-                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, out_shot,
-                     out_rf);
+                     w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, nan_to_zero,
+                     out_shot, out_rf);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }

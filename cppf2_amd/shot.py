@@ -80,14 +80,15 @@ def prepare_device(pts, pt_off, normal_r, shot_r, out_normal=None):
     return out_normal
 
 
-def describe_device(pts, pt_off, normals, shot_r, out=None):
-    """Second half of compute_device (histogram kernel); must directly follow prepare_device on the same inputs."""
+def describe_device(pts, pt_off, normals, shot_r, out=None, nan_to_zero=False):
+    """Second half of compute_device (histogram kernel); must directly follow prepare_device on the same inputs.
+    nan_to_zero folds eval.py:215's np.nan_to_num(shot_feat) into the kernel's store."""
     n = pts.shape[0]
     B = pt_off.numel() - 1
     out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
     ws = _workspace(B, n, pts.device)
     _lib.check(_L.cppf_shot_describe(B, ops._p(pts), ops._p(pt_off), n, ops._p(normals), C.c_float(shot_r),
-                                     ops._p(out), None, ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_describe")
+                                     int(bool(nan_to_zero)), ops._p(out), None, ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_describe")
     return out
 
 

@@ -95,12 +95,13 @@ int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, in
 /* Two-call form of cppf_shot352 sharing one workspace: prepare = cell sort + covariances + eigen-solves (normals out,
  * local-frame axes kept in the workspace); describe = the histogram kernel alone.  describe must follow a prepare
  * on the same inputs / stream / workspace.  `normals` are the ones the descriptor reads (eval.py zeroes NaNs only
- * after shot.compute, so pass prepare's output unchanged). */
+ * after shot.compute, so pass prepare's output unchanged).  nan_to_zero != 0 makes describe write 0 where shot.compute
+ * writes NaN (invalid frames, < 5 neighbours): the np.nan_to_num of eval.py:215 folded into the store. */
 int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                       float shot_r, float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);
 int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t total_points, const float* normals,
-                       float shot_r, float* out_shot, float* out_rf, void* workspace, int64_t workspace_bytes,
-                       void* stream);
+                       float shot_r, int nan_to_zero, float* out_shot, float* out_rf, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                           float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);

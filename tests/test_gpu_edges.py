@@ -128,3 +128,19 @@ def test_decode_logit_prior_equals_adding_it_first(nb):
     b = ops.decode_bins(lg + pr, u, pc, idx, (0, 1, 0), (0, 0, 1), (1, 0, 0))
     for k_ in a:
         assert torch.equal(a[k_], b[k_]), k_
+
+
+def test_shot_describe_nan_to_zero_equals_nan_to_num():
+    """describe(nan_to_zero=True) == nan_to_num(describe()) (eval.py:215), on a cloud with isolated points (NaN rows)."""
+    rng = np.random.RandomState(5)
+    dense = rng.rand(600, 3).astype(np.float32) * 0.05
+    lonely = (rng.rand(12, 3).astype(np.float32) + 3.0) * np.arange(1, 13, dtype=np.float32)[:, None]
+    pts = torch.from_numpy(np.concatenate([dense, lonely])).cuda()
+    off = torch.tensor([0, pts.shape[0]], dtype=torch.int32, device="cuda")
+    nrm = shot.prepare_device(pts, off, 0.02, 0.02)
+    a = shot.describe_device(pts, off, nrm, 0.02)
+    assert torch.isnan(a).any()
+    shot.prepare_device(pts, off, 0.02, 0.02)
+    b = shot.describe_device(pts, off, nrm, 0.02, nan_to_zero=True)
+    assert not torch.isnan(b).any()
+    assert torch.equal(torch.nan_to_num(a, nan=0.0), b)
