@@ -35,6 +35,32 @@ def _stack(dims):
     return nn.Sequential(*[ResLayer(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
 
 
+def _fused_plan(seq):
+    """Per-layer (W1^T, b1', W0^T | None, b0', W2^T) with the pending-offset algebra of fused_stack applied once; cached
+    on the module and rebuilt when any parameter changed (version counters) or moved."""
+    stamp = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    cached = getattr(seq, "_fused_plan_cache", None)
+    if cached is not None and cached[0] == stamp:
+        return cached[1]
+    plan, c = [], None
+    with torch.no_grad():
+        for layer in seq:
+            w1, b1, w2, b2 = layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias
+            if c is not None:
+                b1 = torch.addmv(b1, w1, c)
+            if layer.fc0 is not None:
+                b0 = layer.fc0.bias + b2
+                if c is not None:
+                    b0 = torch.addmv(b0, layer.fc0.weight, c)
+                plan.append((w1.t(), b1.clone(), layer.fc0.weight.t(), b0, w2.t()))
+                c = None
+            else:
+                plan.append((w1.t(), b1.clone(), None, None, w2.t()))
+                c = b2.clone() if c is None else c + b2
+    seq._fused_plan_cache = (stamp, (plan, c))
+    return plan, c
+
+
 def fused_stack(seq, x):
     """Inference-only execution of a stack of ResLayers with the elementwise work folded into GEMM epilogues
     (same fp32 math, fewer passes over the [T, C] activations, which are 1.3 M rows at bench size):
@@ -44,22 +70,14 @@ def fused_stack(seq, x):
     Identity-skip layers accumulate h W2^T into x in place; their output bias b2 is not added to the activation
     but carried as a pending per-channel offset c (true activation = x + c) and folded into the biases of the
     next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
-    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`."""
-    c = None
-    for layer in seq:
-        w1, b1, w2, b2 = layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias
-        if c is not None:
-            b1 = torch.addmv(b1, w1, c)
-        h = torch._addmm_activation(b1, x, w1.t())
-        if layer.fc0 is not None:
-            b0 = layer.fc0.bias + b2
-            if c is not None:
-                b0 = torch.addmv(b0, layer.fc0.weight, c)
-            x = torch.addmm(b0, x, layer.fc0.weight.t())
-            c = None
-        else:
-            c = b2 if c is None else c + b2
-        x = x.addmm_(h, w2.t())
+    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`.
+    The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
+    plan, c = _fused_plan(seq)
+    for w1t, b1, w0t, b0, w2t in plan:
+        h = torch._addmm_activation(b1, x, w1t)
+        if w0t is not None:
+            x = torch.addmm(b0, x, w0t)
+        x = x.addmm_(h, w2t)
     if c is not None:
         x = x.add_(c)
     return x

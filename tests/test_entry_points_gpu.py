@@ -34,6 +34,16 @@ def test_shot_model_forward_matches_reference_golden():
     # fp32 GEMMs on the GPU vs the reference's CPU GEMMs: 1e-4 absolute on O(1) logits
     assert np.allclose(cls.cpu().numpy(), g["pred_cls"], atol=1e-4)
     assert np.allclose(sc.cpu().numpy(), g["pred_scales"], atol=1e-4)
+    # the folded biases of the inference path are cached per weight version: an in-place update must invalidate them
+    from cppf2_amd.models import fused_stack
+    x = torch.randn(257, 256, device="cuda")
+    with torch.no_grad():
+        before = fused_stack(m.scale_encoder, x.clone())
+        m.scale_encoder[0].fc2.bias.add_(0.5)
+        m.scale_encoder[1].fc1.weight.mul_(1.1)
+        after = fused_stack(m.scale_encoder, x.clone())
+        want = m.scale_encoder(x)
+    assert not torch.allclose(before, after) and torch.allclose(after, want, atol=1e-4)
 
 
 def test_dino_model_forward_matches_reference_golden():
