@@ -1,0 +1,42 @@
+"""Writes profiles/r1_summary.md from the committed rocprofv3 kernel stats, PMC traffic passes and bench line."""
+import csv, json, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(R, "profiles")
+stats = list(csv.DictReader(open(os.path.join(P, "r1_kernel_stats.csv"))))
+pmc = json.load(open(os.path.join(P, "r1_pmc_traffic.json")))
+bench = json.load(open(os.path.join(P, "r1_bench_n1.json")))
+steps = 7                                   # bench.py --steps 5 --warmup 2 under rocprofv3
+rows, gemm_ns, elt_ns = [], 0.0, 0.0
+for r in stats:
+    n = r["Name"]
+    if n.startswith("Cijk") or "rocblas" in n:
+        gemm_ns += float(r["TotalDurationNs"]); continue
+    if "at::native" in n or "elementwise" in n or "rocclr" in n:
+        elt_ns += float(r["TotalDurationNs"]); continue
+    key = n.split("(")[0].replace("void ", "")
+    t = pmc.get(key, {})
+    hbm = (2 * t.get("FETCH_SIZE_KB_per_launch", 0) + t.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 if t else None
+    rows.append((key, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, hbm))
+rows.sort(key=lambda x: -x[1] * x[2])
+with open(os.path.join(P, "r1_summary.md"), "w") as f:
+    f.write("# Round-1 profile summary (one MI355X, `python bench.py --steps 5 --warmup 2`)\n\n")
+    f.write("Sources: `r1_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `r1_pmc_traffic.json` = "
+            "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (KB per launch; HBM bytes = "
+            "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `r1_bench_n1.json` = the bench line of the same build. "
+            "Regenerate with `scratch/refresh_profiles.sh` + `scratch/profile_table.py`.\n\n")
+    f.write("Bench: %.0f scenes/s, %.2f ms/step (64 scenes); dominant HIP kernel `%s` %.3f ms per launch, "
+            "roofline %.0f GB/s of %d (frac %.3f), PMC traffic %.0f MB per launch.\n\n"
+            % (bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_name"], bench["roofline"]["launch_ms"],
+               bench["roofline"]["achieved"], bench["roofline"]["peak"], bench["roofline"]["frac"],
+               (bench["roofline"]["traffic"] or 0) / 1e6))
+    f.write("| HIP kernel | launches / step | avg us / launch | ms / step | HBM MB / launch (PMC) | HBM GB/s (PMC) |\n|---|---|---|---|---|---|\n")
+    tot = 0.0
+    for k, c, us, hbm in rows:
+        tot += c * us / 1e3
+        f.write("| `%s` | %.0f | %.1f | %.3f | %s | %s |\n" % (k, c, us, c * us / 1e3, "%.1f" % (hbm / 1e6) if hbm else "-",
+                                                            "%.0f" % (hbm / 1e9 / (us / 1e6)) if hbm else "-"))
+    f.write("| **all HIP kernels** | | | **%.3f** | | |\n" % tot)
+    f.write("| hipBLASLt / rocBLAS GEMMs (tuple MLP + point encoder, PyTorch) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
+    f.write("| PyTorch elementwise / copies | | | %.3f | | |\n" % (elt_ns / steps / 1e6))
+    f.write("\nPer-stage HIP-event times of the bench (ms per step): `%s`\n" % json.dumps(bench["roofline"]["per_stage_ms"]))
+print(open(os.path.join(P, "r1_summary.md")).read())

@@ -9,3 +9,4 @@ cp gpurun_out/pmc_traffic.json profiles/r1_pmc_traffic.json 2>/dev/null
 python3 bench.py > gpurun_out/bench_cur.json 2> gpurun_out/bench_cur.err
 tail -1 gpurun_out/bench_cur.json | cut -c1-400
 head -25 gpurun_out/prof_cur/r1_kernel_stats.csv | cut -c1-150
+python3 scratch/profile_table.py > /dev/null
