@@ -30,6 +30,8 @@
 #define SH_COPIES 1
 #endif
 #define SH_STRIDE 353
+// Neighbour lists handed from shot_cov to shot_hist through the workspace (entries per query; longer lists are rebuilt)
+#define NBR_CAP 512
 
 __device__ __forceinline__ int find_scene_pt(const int32_t* __restrict__ off, int B, int i) {
   int lo = 0, hi = B;
@@ -363,14 +365,42 @@ __device__ __forceinline__ void query_runs(const CellHdr& h, const int32_t* __re
 // ---------------------------------------------------------------------------------------------
 // shot_cov: float64 sums for the normal covariance (radius rn) and the LRF covariance (radius rs)
 // ---------------------------------------------------------------------------------------------
+// One pass over a neighbour (shared by the compacted-list and the direct-scan forms of shot_cov)
+__device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float py, float pz, float rn2, float rs2,
+                                               float rs, double a[NSUM]) {
+  const float qx = qv.x, qy = qv.y, qz = qv.z;
+  const float d2 = sqdist3(px, py, pz, qx, qy, qz);
+  const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
+  if (d2 < rn2) {
+    a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
+    a[6] += x; a[7] += y; a[8] += z; a[9] += 1.0;
+  }
+  if (d2 < rs2) {
+    a[18] += 1.0;                                             // all in-radius points (incl. self)
+    if (!(qx == px && qy == py && qz == pz)) {
+      const double w = (double)rs - (double)__builtin_sqrtf(d2);
+      a[10] += w * (x * x); a[11] += w * (x * y); a[12] += w * (x * z);
+      a[13] += w * (y * y); a[14] += w * (y * z); a[15] += w * (z * z);
+      a[16] += w; a[17] += 1.0;
+    }
+  }
+}
+
+// The candidates of the 9 runs are first compacted to the ones inside the larger radius (about a third of them), so
+// the float64 sums run over dense wavefronts; the compacted list (positions in the cell-sorted order, scan order) is
+// also left in the workspace for shot_hist, which needs the same neighbours.
 __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __restrict__ pts,
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
                                                       const float4* __restrict__ sorted_pts,
                                                       const int32_t* __restrict__ scene_of, float rn, float rs,
-                                                      double* __restrict__ sums /* [Ntot][NSUM] */) {
+                                                      double* __restrict__ sums /* [Ntot][NSUM] */,
+                                                      int32_t* __restrict__ nbr_list /* [Ntot][NBR_CAP] */,
+                                                      int32_t* __restrict__ nbr_cnt /* [Ntot] */) {
   __shared__ double s_part[NSUM][64];
+  int* s_list = reinterpret_cast<int*>(&s_part[0][0]);          // SH_LCAP ints, dead before the partial sums land
+  static_assert(SH_LCAP * sizeof(int) <= sizeof(double) * NSUM * 64, "list must fit under the partial sums");
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const int b = scene_of[qi];
@@ -379,34 +409,44 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
   const int32_t* cs = cell_start + (int64_t)b * (CELL_CAP + 1);
   const float4* sp = sorted_pts + (int64_t)p0;
   const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
-  const float rn2 = rn * rn, rs2 = rs * rs;
+  const float rn2 = rn * rn, rs2 = rs * rs, rm2 = fmaxf(rn2, rs2);
   Runs runs;
   query_runs(h, cs, px, py, pz, runs);
   double a[NSUM];
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
+  int m = 0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
-    for (int j = runs.beg[k] + lane; j < runs.end[k]; j += 64) {
-      const float4 qv = sp[j];
-      const float qx = qv.x, qy = qv.y, qz = qv.z;
-      const float d2 = sqdist3(px, py, pz, qx, qy, qz);
-      const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-      if (d2 < rn2) {
-        a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
-        a[6] += x; a[7] += y; a[8] += z; a[9] += 1.0;
+    for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
+      const int j = jb + lane;
+      bool in = false;
+      if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2; }
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < SH_LCAP) s_list[pos] = j;
       }
-      if (d2 < rs2) {
-        a[18] += 1.0;                                             // all in-radius points (incl. self)
-        if (!(qx == px && qy == py && qz == pz)) {
-          const double w = (double)rs - (double)__builtin_sqrtf(d2);
-          a[10] += w * (x * x); a[11] += w * (x * y); a[12] += w * (x * z);
-          a[13] += w * (y * y); a[14] += w * (y * z); a[15] += w * (z * z);
-          a[16] += w; a[17] += 1.0;
-        }
-      }
+      m += __popcll(mask);
     }
   }
+  __syncthreads();
+  if (m <= SH_LCAP) {
+    for (int c = lane; c < m; c += 64) {
+      const int j = s_list[c];
+      if (nbr_list && c < NBR_CAP) nbr_list[(int64_t)qi * NBR_CAP + c] = j;
+      cov_accumulate(sp[j], px, py, pz, rn2, rs2, rs, a);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      for (int j = runs.beg[k] + lane; j < runs.end[k]; j += 64) cov_accumulate(sp[j], px, py, pz, rn2, rs2, rs, a);
+  }
+  if (nbr_cnt && lane == 0) {
+    nbr_cnt[qi] = m;
+    if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
+  }
+  __syncthreads();                                               // the list is dead: its storage becomes s_part
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) s_part[c][lane] = a[c];
   __syncthreads();
@@ -493,6 +533,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const int32_t* __restrict__ scene_of,
                                                        const float4* __restrict__ sorted_nrm,
                                                        const LrfPre* __restrict__ pre, float radius, int nan_to_zero,
+                                                       const int32_t* __restrict__ nbr_list,
+                                                       const int32_t* __restrict__ nbr_cnt,
                                                        float* __restrict__ out_shot,
                                                        float* __restrict__ out_rf) {
   __shared__ uint32_t s_hist[SH_COPIES * SH_STRIDE];
@@ -519,22 +561,45 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     if (!ok) return;
     // LRF exists but too few points for the descriptor: frame is still reported
   }
-  // neighbour list (positions in cell order), all points with d2 < r2 incl. self
+  // neighbour list (positions in cell order), all points with d2 < r2 incl. self: taken from shot_cov's compacted list
+  // when that was built with this radius (copied) or a larger one (filtered), otherwise rebuilt from the 9 runs
   Runs runs;
-  query_runs(h, cs, px, py, pz, runs);
-  int m = 0;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
-      const int j = jb + lane;
-      bool in = false;
-      if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
-      const unsigned long long mask = __ballot(in);
-      if (in) {
-        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < SH_LCAP) s_list[pos] = j;
+  for (int k = 0; k < 9; ++k) { runs.beg[k] = 0; runs.end[k] = 0; }
+  int m = 0;
+  const int shared_cnt = nbr_cnt ? nbr_cnt[qi] : -1;
+  const float list_r = nbr_cnt ? reinterpret_cast<const float*>(nbr_cnt)[-1] : -1.0f;
+  if (shared_cnt >= 0 && shared_cnt <= NBR_CAP && list_r * list_r >= r2) {
+    const int32_t* nl = nbr_list + (int64_t)qi * NBR_CAP;
+    if (list_r * list_r == r2) {
+      for (int c = lane; c < shared_cnt; c += 64) s_list[c] = nl[c];
+      m = shared_cnt;
+    } else {
+      for (int base = 0; base < shared_cnt; base += 64) {
+        const int c = base + lane;
+        int j = 0;
+        bool in = false;
+        if (c < shared_cnt) { j = nl[c]; const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
+        const unsigned long long mask = __ballot(in);
+        if (in) s_list[m + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+        m += __popcll(mask);
       }
-      m += __popcll(mask);
+    }
+  } else {
+    query_runs(h, cs, px, py, pz, runs);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
+        const int j = jb + lane;
+        bool in = false;
+        if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
+        const unsigned long long mask = __ballot(in);
+        if (in) {
+          const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+          if (pos < SH_LCAP) s_list[pos] = j;
+        }
+        m += __popcll(mask);
+      }
     }
   }
   __syncthreads();
@@ -702,7 +767,7 @@ static inline int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct ShotWs {
   CellHdr* hdr; int32_t* cell_start; int32_t* sorted_idx; float4* sorted_pts; double* sums; LrfPre* pre;
-  int32_t* scene_of; float4* sorted_nrm;
+  int32_t* scene_of; float4* sorted_nrm; int32_t* nbr_cnt; int32_t* nbr_list;
 };
 
 static ShotWs carve(void* ws, int B, int64_t n) {
@@ -715,7 +780,9 @@ static ShotWs carve(void* ws, int B, int64_t n) {
   w.sums = (double*)p; p += up256(n * NSUM * 8);
   w.pre = (LrfPre*)p; p += up256(n * (int64_t)sizeof(LrfPre));
   w.scene_of = (int32_t*)p; p += up256(n * 4);
-  w.sorted_nrm = (float4*)p;
+  w.sorted_nrm = (float4*)p; p += up256(n * 16);
+  w.nbr_cnt = (int32_t*)(p + 256); p += up256(n * 4 + 256);        // one slot before the counts: the lists' radius
+  w.nbr_list = (int32_t*)p;
   return w;
 }
 
@@ -723,7 +790,8 @@ extern "C" int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points) {
   if (B <= 0 || total_points <= 0) return 0;
   return up256((int64_t)B * sizeof(CellHdr)) + up256((int64_t)B * (CELL_CAP + 1) * 4) + up256(total_points * 4) +
          up256(total_points * 16) + up256(total_points * NSUM * 8) + up256(total_points * (int64_t)sizeof(LrfPre)) +
-         up256(total_points * 4) + up256(total_points * 16);
+         up256(total_points * 4) + up256(total_points * 16) + up256(total_points * 4 + 256) +
+         up256(total_points * (int64_t)NBR_CAP * 4);
 }
 
 static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, float normal_r, float shot_r,
@@ -737,7 +805,8 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
                      w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, w.scene_of, rn, rs, w.sums);
+                     w.sorted_pts, w.scene_of, rn, rs, w.sums, want_s ? w.nbr_list : (int32_t*)nullptr,
+                     want_s ? w.nbr_cnt : (int32_t*)nullptr);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums,
                      out_normal, want_s ? w.pre : (LrfPre*)nullptr);
@@ -747,7 +816,8 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
                        normals_in ? normals_in : out_normal, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
     CPPF_LAUNCH_CHECK();
     hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                       w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, 0, out_shot, out_rf);
+                       w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, 0, w.nbr_list, w.nbr_cnt,
+                       out_shot, out_rf);
     CPPF_LAUNCH_CHECK();
   }
   return CPPF_OK;
@@ -800,7 +870,7 @@ extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off,
                      w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums);
+                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
                      w.pre);
@@ -822,7 +892,7 @@ extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
                      w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, nan_to_zero,
-                     out_shot, out_rf);
+                     w.nbr_list, w.nbr_cnt, out_shot, out_rf);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
