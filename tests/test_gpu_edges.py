@@ -144,3 +144,28 @@ def test_shot_describe_nan_to_zero_equals_nan_to_num():
     b = shot.describe_device(pts, off, nrm, 0.02, nan_to_zero=True)
     assert not torch.isnan(b).any()
     assert torch.equal(torch.nan_to_num(a, nan=0.0), b)
+
+
+@pytest.mark.parametrize("n, rn, rs", [(2600, 0.02, 0.02),      # 512 < neighbours <= 1024: the shared list overflows, hist rebuilds its own
+                                       (6000, 0.02, 0.02),      # > 1024: LDS list overflows too, both kernels rescan the runs
+                                       (1500, 0.03, 0.012)])    # normal radius > descriptor radius: hist filters cov's list
+def test_shot_neighbour_list_paths(n, rn, rs):
+    rng = np.random.RandomState(n)
+    v = rng.randn(n, 3)
+    pc = (v / np.linalg.norm(v, axis=1, keepdims=True) * (rng.rand(n, 1) ** (1 / 3)) * 0.03 + 0.5).astype(np.float32)
+    hs, hn = shot.compute(pc, rn, rs)
+    os_, on, _ = S.compute(pc, rn, rs)
+    hs, hn = hs.reshape(-1, 352), hn.reshape(-1, 3)
+    assert np.array_equal(np.isnan(os_), np.isnan(hs))
+    ok = ~np.isnan(os_).any(1)
+    assert ok.sum() > n // 2
+    d2 = ((pc[:, None, :] - pc[None, :200, :]) ** 2).sum(-1)
+    cnt = (d2 < rs * rs).sum(0)
+    if n == 2600:
+        assert 512 < cnt.max() <= 1024
+    if n == 6000:
+        assert cnt.max() > 1024
+    # dense volumetric balls have near-degenerate covariances: a few frames flip between equally valid axes
+    err = np.abs(hs[ok] - os_[ok]).max(1)
+    assert np.mean(err < 2e-5) > 0.98, float(np.mean(err < 2e-5))
+    assert np.allclose(hn[ok], on[ok], atol=5e-6) or np.mean(np.abs(hn[ok] - on[ok]).max(1) < 5e-6) > 0.98
