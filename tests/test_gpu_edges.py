@@ -169,3 +169,35 @@ def test_shot_neighbour_list_paths(n, rn, rs):
     err = np.abs(hs[ok] - os_[ok]).max(1)
     assert np.mean(err < 2e-5) > 0.98, float(np.mean(err < 2e-5))
     assert np.allclose(hn[ok], on[ok], atol=5e-6) or np.mean(np.abs(hn[ok] - on[ok]).max(1) < 5e-6) > 0.98
+
+
+def test_vote_center_persistent_equals_per_workgroup_and_global_paths():
+    """Ragged batch large enough for the persistent work-list kernel (B * slabs(cells_cap) >= 256): same grid, argmax
+    and centre as the one-item-per-workgroup launch (mode bit 0x800) and the global-atomic path (mode 2)."""
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    Ns, Ts = [900, 2048, 300, 1500, 4096, 700, 1200], [4000, 9000, 1500, 6000, 12000, 2500, 5000]
+    B = len(Ns)
+    scs = [synth.make_scene(9, b, n) for b, n in enumerate(Ns)]
+    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scs])).to(dev)
+    idx = torch.cat([ops.sample_tuples(n, t, 5, 9, (b,)) for b, (n, t) in enumerate(zip(Ns, Ts))])
+    lg = torch.cat([torch.from_numpy(synth.teacher_logits(s["pc_canon"], idx[sum(Ts[:b]):sum(Ts[:b + 1])].cpu().numpy(), 32))
+                    for b, s in enumerate(scs)]).to(dev)
+    u = torch.cat([ops.philox_uniform(t, 6, 9, 1, (b,)) for b, t in enumerate(Ts)])
+    outs = []
+    for mode in (0, 0x800, 2):
+        pipe = VotingPipeline(Ns, Ts, num_rots=90, vote_mode=mode)
+        pipe.decode(pts, idx, lg, u)
+        grid = torch.zeros(B * pipe.cells_cap, dtype=torch.int32, device=dev)
+        goff = torch.arange(B, dtype=torch.int64, device=dev) * pipe.cells_cap
+        pipe.vote_center(pts, idx, grid=grid, grid_off=goff)
+        ncell = pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8)[:, 6]
+        g = grid.cpu().numpy().reshape(B, -1)
+        outs.append((pipe.argmax.cpu().numpy().copy(), pipe.peak.cpu().numpy().copy(), pipe.world.cpu().numpy().copy(),
+                     [g[b, :ncell[b]].copy() for b in range(B)]))
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][0], other[0]) and np.array_equal(outs[0][1], other[1])
+        assert np.array_equal(outs[0][2], other[2])
+        for a, b_ in zip(outs[0][3], other[3]):
+            assert np.array_equal(a, b_)
+    assert outs[0][1].min() > 10
