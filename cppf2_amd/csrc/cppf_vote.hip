@@ -265,7 +265,7 @@ __device__ __forceinline__ void vote_slab_item(
     const CppfSceneGrid& g, int G, const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off,
     float res, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
-    SlabBest* __restrict__ slab_best, int s_max, int P) {
+    SlabBest* __restrict__ slab_best, int s_max, int P, uint32_t* __restrict__ part, int* __restrict__ tickets) {
   const long long t_start = wall_clock64();
   const int lo = s * VC_SLAB_CELLS;
   const int n = min(VC_SLAB_CELLS, G - lo);
@@ -397,6 +397,28 @@ __device__ __forceinline__ void vote_slab_item(
   const long long t_b = wall_clock64();
 #endif
 
+  if (part != nullptr && Pl > 1) {
+    // Persistent kernel with the pair list of an item split Pl ways (small batches: fewer slabs than CUs): every part adds
+    // its non-zero cells to the zeroed merge area with device atomics and takes a ticket; the part holding the last
+    // ticket reads the merged slab back and carries on to the arg-max.  No part waits for another one.
+    __shared__ int s_ticket;
+    uint32_t* pp = part + (int64_t)b * cells_cap + lo;
+    for (int i = threadIdx.x; i < n; i += VC_THREADS) {
+      const uint32_t c = slab[i];
+      if (c) atomicAdd(&pp[i], c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_ticket = atomicAdd(&tickets[(int64_t)b * s_max + s], 1);
+      __threadfence();
+    }
+    __syncthreads();
+    if (s_ticket != Pl - 1) return;
+    for (int i = threadIdx.x; i < n; i += VC_THREADS)
+      slab[i] = __hip_atomic_load(&pp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
   const int64_t goff = grid ? (grid_off ? grid_off[b] : (int64_t)b * cells_cap) : 0;
   if (P == 1) {
     uint32_t bv = 0;
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
     s_mark[threadIdx.x & 63] = 0;
   }
   vote_slab_item<ARCS>(slab, s_trig, s_mark, tag, b, s, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
-                       grid, grid_off, cells_cap, slab_best, s_max, P);
+                       grid, grid_off, cells_cap, slab_best, s_max, P, nullptr, nullptr);
 }
 
 // Work list of the persistent kernel: one entry (scene | slab << 16) per existing slab, in the order they should start
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
 // (Halving the pair lists of the heavy slabs over two workgroups that merge through memory was built and measured:
 // perfectly balanced CUs, but the extra zero / reduce / merge passes cost what the balance gained.)
 __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid* __restrict__ grids, int B,
-                                                             int64_t cells_cap, int s_max,
+                                                             int64_t cells_cap, int s_max, int max_parts, int target,
                                                              uint32_t* __restrict__ list, int* __restrict__ ctl) {
   __shared__ int s_wave[16];
   __shared__ int s_base, s_maxn;
@@ -508,7 +530,13 @@ __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid
     if (threadIdx.x == 1023) s_base = off + cnt;
     __syncthreads();
   }
-  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = s_base; }       // next item, item count
+  if (threadIdx.x == 0) {
+    // fewer slabs than `target` work items (about two per CU): split every slab's pair list into P parts
+    const int items = s_base;
+    int P = 1;
+    if (max_parts > 1 && items > 0 && items < target) P = min(max_parts, (target + items - 1) / items);
+    ctl[0] = 0; ctl[1] = items * P; ctl[2] = P;               // next work item, work item count, parts per slab
+  }
 }
 
 // Persistent form for throughput-sized batches: one workgroup per CU pulls (scene, slab) items from the work
@@ -518,7 +546,8 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
     const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
-    SlabBest* __restrict__ slab_best, int s_max, const uint32_t* __restrict__ list, int* __restrict__ ctl) {
+    SlabBest* __restrict__ slab_best, int s_max, const uint32_t* __restrict__ list, int* __restrict__ ctl,
+    uint32_t* __restrict__ part, int* __restrict__ tickets) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
   float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);
   volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
@@ -527,18 +556,18 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
   int tag = 0;
   for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
   s_mark[threadIdx.x & 63] = 0;
-  const int count = ctl[1];
+  const int count = ctl[1], parts = ctl[2];
   for (;;) {
     __syncthreads();                                   // previous item's epilogue is done with the slab and s_item
     if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
     __syncthreads();
     const int item = s_item;
     if (item >= count) break;
-    const uint32_t e = list[item];
+    const uint32_t e = list[item / parts];                // the parts of a slab are consecutive work items
     const int b = (int)(e & 0xffffu), s = (int)(e >> 16);
     const CppfSceneGrid g = grids[b];
-    vote_slab_item<true>(slab, s_trig, s_mark, tag, b, s, 0, 1, g, g.ncell, fr, total, tup_off, res, num_rots, cos_tab,
-                         sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1);
+    vote_slab_item<true>(slab, s_trig, s_mark, tag, b, s, item % parts, parts, g, g.ncell, fr, total, tup_off, res,
+                         num_rots, cos_tab, sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1, part, tickets);
   }
 }
 
@@ -651,7 +680,8 @@ static inline int vc_parts(int64_t cells_cap) {
 extern "C" int64_t cppf_vote_center_workspace_bytes(int B, int64_t cells_cap, int64_t total_tuples) {
   if (B <= 0 || cells_cap <= 0 || total_tuples < 0) return 0;
   return align_up((int64_t)B * vc_parts(cells_cap) * (int64_t)sizeof(SlabBest), 256) +
-         align_up((int64_t)B * vc_parts(cells_cap) * 4 + 256, 256) + align_up((int64_t)B * cells_cap * 4, 256) + align_up(total_tuples * VC_FRAME_FLOATS * 4, 256);
+         align_up((int64_t)B * vc_parts(cells_cap) * 4 + 256, 256) + align_up((int64_t)B * vc_parts(cells_cap) * 4, 256) +
+         align_up((int64_t)B * cells_cap * 4, 256) + align_up(total_tuples * VC_FRAME_FLOATS * 4, 256);
 }
 
 extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
@@ -669,9 +699,11 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
   const int s_max_parts = vc_parts(cells_cap);
   SlabBest* best = (SlabBest*)workspace;
   char* wsp = (char*)workspace + align_up((int64_t)B * s_max_parts * sizeof(SlabBest), 256);
-  int* ws_ctl = (int*)wsp;                        // persistent kernel: next item, item count, then the work list
+  int* ws_ctl = (int*)wsp;                        // persistent kernel: next item, item count, parts; then the work list
   uint32_t* ws_list = (uint32_t*)(wsp + 256);
   wsp += align_up((int64_t)B * s_max_parts * 4 + 256, 256);
+  int* ws_tickets = (int*)wsp;                    // one arrival counter per (scene, slab) of the pair-split merge
+  wsp += align_up((int64_t)B * s_max_parts * 4, 256);
   uint32_t* ws_grid = (uint32_t*)wsp;
   float* frames = (float*)(wsp + align_up((int64_t)B * cells_cap * 4, 256));
   const int s_max = (int)((cells_cap + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
@@ -707,24 +739,17 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
     }
     // arcs need >1 slab to pay off and the table in LDS; mode 3 forces the exhaustive sweep (A/B reference)
     const bool arcs = (exhaustive == 0) && s_max > 1 && num_rots <= VC_MAX_LDS_ROTS && num_rots >= 8;
+    // the persistent work-list kernel serves every batch size of the arcs path; the one-item-per-workgroup launch
+    // remains for the exhaustive A/B mode and on request (mode bit 0x800)
+    const bool persist = arcs && B <= 0xffff && s_max <= 0xffff && (mode_bits & 0x800) == 0;
     uint32_t* g_use = grid;
     const int64_t* goff_use = grid_off;
-    if (P > 1) {
+    if (P > 1 && !persist) {
       if (!g_use) { g_use = ws_grid; goff_use = nullptr; }
       // slabs are merged with atomics -> the target must start from zero
       hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, g_use, goff_use, cells_cap, grids);
       CPPF_LAUNCH_CHECK();
     }
-    // throughput-sized batches (more (scene, slab) items than CUs) run the persistent work-list form
-    const bool persist = arcs && P == 1 && wgs >= 256 && B <= 0xffff && s_max <= 0xffff && (mode_bits & 0x800) == 0;
-    if (!frames_ready) {
-      hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
-                         tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
-      if (persist)      // the work list belongs to the preparation half of the two-call form
-        hipLaunchKernelGGL(vote_worklist_kernel, dim3(1), dim3(1024), 0, st, grids, B, cells_cap, s_max, ws_list, ws_ctl);
-      CPPF_LAUNCH_CHECK();
-    }
-    if (frames_only) return CPPF_OK;
     if (persist) {
       static int num_cus = 0;
       if (num_cus == 0) {
@@ -736,10 +761,41 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
         CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_persist_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       }
+      // Small batches may have fewer slabs than CUs; how many is only known on the device (scene bounds), so the work
+      // list kernel picks the number of parts per slab.  The host only decides whether a split is possible at all:
+      // it costs a zeroed merge area and ticket counters per call, which a 64-scene batch never needs.
+      const int pmax_t = (max_t + VC_THREADS - 1) / VC_THREADS;
+      const int max_parts = (B <= 48) ? (pmax_t < 64 ? (pmax_t < 1 ? 1 : pmax_t) : 64) : 1;
+      if (!frames_ready) {
+        hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
+                           tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
+        // the work list belongs to the preparation half of the two-call form
+        hipLaunchKernelGGL(vote_worklist_kernel, dim3(1), dim3(1024), 0, st, grids, B, cells_cap, s_max, max_parts,
+                           2 * num_cus, ws_list, ws_ctl);
+        if (max_parts > 1) {
+          hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, ws_grid, (const int64_t*)nullptr, cells_cap,
+                             grids);
+          CPPF_HIP(hipMemsetAsync(ws_tickets, 0, (size_t)B * s_max_parts * 4, st));
+        }
+        CPPF_LAUNCH_CHECK();
+      }
+      if (frames_only) return CPPF_OK;
       hipLaunchKernelGGL(vote_center_persist_kernel, dim3(num_cus), dim3(VC_THREADS), lds_bytes, st, frames,
-                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap, best,
-                         s_max_parts, ws_list, ws_ctl);
-    } else if (arcs)
+                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, grid, grid_off, cells_cap, best,
+                         s_max_parts, ws_list, ws_ctl, max_parts > 1 ? ws_grid : (uint32_t*)nullptr, ws_tickets);
+      CPPF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap, res,
+                         out_argmax, out_peak, out_world);
+      CPPF_LAUNCH_CHECK();
+      return CPPF_OK;
+    }
+    if (!frames_ready) {
+      hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
+                         tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
+      CPPF_LAUNCH_CHECK();
+    }
+    if (frames_only) return CPPF_OK;
+    if (arcs)
       hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
                          total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
                          best, s_max_parts, P);
