@@ -10,7 +10,7 @@
 //   1. vote_frames_kernel: once per pair, the circle frame (centre c, in-plane axes x, y, all the IEEE
 //      sqrt/div work of train_dino.py:176-192) goes to a structure-of-arrays workspace, together with the
 //      amplitude/phase of the circle's x-coordinate.
-//   2. vote_center_slab_kernel: workgroup (scene, slab) streams the frames (coalesced), and for every pair
+//   2. vote_slab_item: a workgroup takes one (scene, slab) item, streams the frames (coalesced), and for every pair
 //      derives the rotation indices that can reach the slab's x-layers (two arcs of the circle, from the
 //      amplitude/phase) -- so the work per scene stays ~one pass over the votes no matter how many slabs the
 //      grid needs.  Votes are counted with LDS atomics; arcs are very uneven in length, so a wavefront cuts its
@@ -20,10 +20,12 @@
 //      of a cell boundary), which keeps the grid bit-identical to the reference's float32 pipeline.
 //      The slab is streamed out with plain coalesced stores (or not at all when the caller only wants the
 //      peak) and its first maximum is reduced in place: no global atomics, no memset, no grid re-read.
-//      Workgroups are ordered centre-out over the slabs (heavy slabs first) so the tail of the launch is
-//      filled with the light ones.
-// For small batches the pair list of a slab is additionally split over P workgroups that merge their slabs
-// into the zeroed global grid with one atomic per non-zero cell.
+//   3. Scheduling: vote_worklist_kernel lists the slabs that exist (scene bounds live on the device), centre-out so
+//      the heavy central slabs start first, and vote_center_persist_kernel runs one workgroup per CU that pulls items
+//      from the list.  When there are fewer slabs than CUs (small batches) the list kernel splits every slab's pair
+//      list into parts; the parts merge through a zeroed area with device atomics and a ticket per slab.
+// vote_center_slab_kernel (one item per workgroup, (scene, part, rank) launch) remains for the exhaustive A/B mode and
+// on request (mode bit 0x800); there the parts of a small batch merge into the zeroed global grid.
 // Mode 2 (global atomics, one thread per pair, exhaustive sweep) is the independent A/B reference; mode 3 is
 // the slab kernel with the exhaustive rotation sweep and exact divisions.
 // =============================================================================================
