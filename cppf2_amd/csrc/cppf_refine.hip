@@ -8,10 +8,14 @@
 // d loss / d rot), a fixed-order block reduction, and the 7-parameter Adam update that every thread repeats
 // identically.  Semantics of the lietorch pieces (un-normalised quaternion action, tangent-space gradient) are
 // restated in oracle/cppf_oracle.py:refine_pose -- PARITY UNPINNED, lietorch is not available to generate goldens.
+// An iteration costs one barrier: wavefront sums on the DPP path, the 4 wavefront partials double-buffered in LDS by
+// iteration parity and added up (in a fixed order) by every thread for itself.
 #include "cppf_common.h"
 
-#define RF_THREADS 1024
-#define RF_CACHE 4            // points held in registers per thread (4096 per scene = 2048 kept pairs); more are re-read
+#ifndef RF_THREADS
+#define RF_THREADS 256        // 4 wavefronts: an iteration is latency (reduction + barrier), not throughput
+#endif
+#define RF_CACHE (4096 / RF_THREADS)   // points held in registers per thread (4096 per scene = 2048 kept pairs); more are re-read
 
 struct Mat3 {
   float m[9];                 // row-major
@@ -58,6 +62,19 @@ __device__ __forceinline__ RefPoint load_ref_point(const float* __restrict__ p, 
   return r;
 }
 
+// inclusive wavefront sum on the DPP path (row_shr 1,2,4,8; row_bcast15; row_bcast31): lane 63 holds the total
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+#define RF_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+  x += RF_DPP(x, 0x111, 0xf);
+  x += RF_DPP(x, 0x112, 0xf);
+  x += RF_DPP(x, 0x114, 0xf);
+  x += RF_DPP(x, 0x118, 0xf);
+  x += RF_DPP(x, 0x142, 0xa);
+  x += RF_DPP(x, 0x143, 0xc);
+#undef RF_DPP
+  return x;
+}
+
 __device__ __forceinline__ float sgn(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 
 __device__ __forceinline__ void ref_accumulate(const RefPoint& r, const float t[3], const Mat3& rot, bool y_only,
@@ -83,8 +100,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_pose_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
     const int32_t* __restrict__ tup_off, const float* __restrict__ scaled, const int32_t* __restrict__ kept_tuple,
     const int32_t* __restrict__ kept_count, int y_only, int steps, float lr, CppfSceneResult* __restrict__ results) {
-  __shared__ float s_part[RF_THREADS / 64][12];
-  __shared__ float s_sum[12];
+  __shared__ float s_part[2][RF_THREADS / 64][12];
   const int b = blockIdx.x;
   const int nk = kept_count[b];
   CppfSceneResult& res = results[b];
@@ -121,23 +137,23 @@ __global__ __launch_bounds__(RF_THREADS) void refine_pose_kernel(
       if ((int)threadIdx.x + c * RF_THREADS < ne) ref_accumulate(cache[c], t, rot, y_only != 0, inv_n, a);
     for (int e = threadIdx.x + RF_CACHE * RF_THREADS; e < ne; e += RF_THREADS)
       ref_accumulate(load_ref_point(p, idx, k, scaled, kept, t0, e), t, rot, y_only != 0, inv_n, a);
-    // fixed-order block sum of the 12 partials
+    // fixed-order block sum of the 12 partials: DPP row reductions inside the wavefront, then 4 wavefront partials
+#pragma unroll
+    for (int c = 0; c < 12; ++c) a[c] = wave_sum_dpp(a[c]);
+    float (*sp)[12] = s_part[step & 1];
+    if (wave_lane() == 63) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) sp[threadIdx.x >> 6][c] = a[c];
+    }
+    __syncthreads();
+    float s_sum[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
+      float t_ = sp[0][c];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) a[c] += __shfl_xor(a[c], off);
+      for (int w = 1; w < RF_THREADS / 64; ++w) t_ += sp[w][c];
+      s_sum[c] = t_;
     }
-    if (wave_lane() == 0) {
-#pragma unroll
-      for (int c = 0; c < 12; ++c) s_part[threadIdx.x >> 6][c] = a[c];
-    }
-    __syncthreads();
-    if (threadIdx.x < 12) {
-      float s = 0.0f;
-      for (int w = 0; w < RF_THREADS / 64; ++w) s += s_part[w][threadIdx.x];
-      s_sum[threadIdx.x] = s;
-    }
-    __syncthreads();
     float g[7];
     g[0] = -s_sum[0]; g[1] = -s_sum[1]; g[2] = -s_sum[2];
     Mat3 gr, gM;
@@ -171,7 +187,6 @@ __global__ __launch_bounds__(RF_THREADS) void refine_pose_kernel(
       const float upd = step_size * m[c] / denom;
       if (c < 3) t[c] -= upd; else q[c - 3] -= upd;
     }
-    __syncthreads();                                             // s_sum is rewritten next iteration
   }
   if (threadIdx.x == 0) {
     const Mat3 Rn = matmul3(so3_matrix(q[0], q[1], q[2], q[3]), R0);
