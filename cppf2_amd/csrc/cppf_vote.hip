@@ -842,7 +842,9 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
 // =============================================================================================
 // a7. back-vote filter + importance weights (eval.py:251-275).  One workgroup per scene.
 // =============================================================================================
+#ifndef BV_THREADS
 #define BV_THREADS 1024
+#endif
 
 // block-wide exclusive scan of one flag per thread; returns this thread's offset, *total = block sum
 __device__ __forceinline__ int block_scan_flag(bool flag, int* s_wave, int* total) {
@@ -935,6 +937,30 @@ __device__ __forceinline__ float key_float(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// 1. back-projected vote parameters of the real pairs w.r.t. the voted centre (eval.py:252-257): throughput work, so it
+// runs as its own grid over the pairs instead of on the one CU that owns the scene's order statistics
+__global__ __launch_bounds__(256) void backvote_errs_kernel(const float* __restrict__ pts,
+                                                            const int32_t* __restrict__ pt_off,
+                                                            const int32_t* __restrict__ idx, int k,
+                                                            const int32_t* __restrict__ tup_off,
+                                                            const float* __restrict__ tr,
+                                                            const double* __restrict__ centers, Axes9 axes,
+                                                            float* __restrict__ errs) {
+  const int b = blockIdx.y;
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const double cx = centers[3 * b], cy = centers[3 * b + 1], cz = centers[3 * b + 2];
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < nt; t += gridDim.x * 256) {
+    const int64_t row = (int64_t)(t0 + t);
+    const float* a = p + 3 * (int64_t)idx[row * k];
+    const float* bb = p + 3 * (int64_t)idx[row * k + 1];
+    float tb[2];
+    target_pair(a[0], a[1], a[2], bb[0], bb[1], bb[2], cx, cy, cz, axes.a, tb, nullptr);
+    const float d0 = tr[row * 2] - tb[0], d1 = tr[row * 2 + 1] - tb[1];
+    errs[row] = __builtin_sqrtf(d0 * d0 + d1 * d1);
+  }
+}
+
 __global__ __launch_bounds__(BV_THREADS) void backvote_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
     const int32_t* __restrict__ tup_off, const float* __restrict__ tr, const double* __restrict__ centers,
@@ -955,18 +981,7 @@ __global__ __launch_bounds__(BV_THREADS) void backvote_kernel(
     if (threadIdx.x == 0) { kept_count[b] = 0; if (thr_out) thr_out[b] = NAN; }
     return;
   }
-  const double cx = centers[3 * b], cy = centers[3 * b + 1], cz = centers[3 * b + 2];
-  // 1. back-projected vote parameters of the real pairs w.r.t. the voted centre (eval.py:252-257)
-  for (int t = threadIdx.x; t < nt; t += BV_THREADS) {
-    const int64_t row = (int64_t)(t0 + t);
-    const float* a = p + 3 * (int64_t)idx[row * k];
-    const float* bb = p + 3 * (int64_t)idx[row * k + 1];
-    float tb[2];
-    target_pair(a[0], a[1], a[2], bb[0], bb[1], bb[2], cx, cy, cz, axes.a, tb, nullptr);
-    const float d0 = tr[row * 2] - tb[0], d1 = tr[row * 2 + 1] - tb[1];
-    e[t] = __builtin_sqrtf(d0 * d0 + d1 * d1);
-  }
-  __syncthreads();
+  // 1. (backvote_errs_kernel, spread over the chip) left the back-projection errors in errs[]
   // 2. np.percentile(back_errs, ratio*100), method 'linear' (eval.py:258): order statistics kq and kq+1
   int kq = kidx[b];
   if (kq > nt - 1) kq = nt - 1;
@@ -1074,6 +1089,9 @@ extern "C" int cppf_backvote_filter(int B, const float* pts, const int32_t* pt_o
   Axes9 ax;
   for (int i = 0; i < 9; ++i) ax.a[i] = h_axes[i];
   CPPF_HIP(hipMemsetAsync(workspace, 0, (size_t)workspace_bytes, (hipStream_t)stream));
+  hipLaunchKernelGGL(backvote_errs_kernel, dim3(B >= 32 ? 16 : 64, B), dim3(256), 0, (hipStream_t)stream, pts, pt_off,
+                     idx, k, tup_off, tr, centers, ax, back_errs);
+  CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(backvote_kernel, dim3(B), dim3(BV_THREADS), 0, (hipStream_t)stream, pts, pt_off, idx, k, tup_off,
                      tr, centers, ax, kidx, gammas, imp_wt_margin, num_rots, mask, kept_tuple, kept_count, kept_wt,
                      kept_row0, back_errs, thr, (int32_t*)workspace);
