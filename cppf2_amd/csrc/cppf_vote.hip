@@ -731,14 +731,23 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       if (P < 1) P = 1;
     }
     const int lds_bytes = VC_SLAB_CELLS * 4 + 2 * VC_MAX_LDS_ROTS * 4 + (VC_THREADS / 64) * 64 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // per device, on first use: the kernels' dynamic-LDS limit and the CU count (read-only afterwards)
+    static int cu_count[64] = {0};
+    int dev = 0;
+    CPPF_HIP(hipGetDevice(&dev));
+    const int dslot = dev & 63;
+    if (cu_count[dslot] == 0) {
+      hipDeviceProp_t prop;
+      CPPF_HIP(hipGetDeviceProperties(&prop, dev));
       CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
       CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set = true;
+      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_persist_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      cu_count[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int num_cus = cu_count[dslot];
     // arcs need >1 slab to pay off and the table in LDS; mode 3 forces the exhaustive sweep (A/B reference)
     const bool arcs = (exhaustive == 0) && s_max > 1 && num_rots <= VC_MAX_LDS_ROTS && num_rots >= 8;
     // the persistent work-list kernel serves every batch size of the arcs path; the one-item-per-workgroup launch
@@ -753,16 +762,6 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       CPPF_LAUNCH_CHECK();
     }
     if (persist) {
-      static int num_cus = 0;
-      if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        CPPF_HIP(hipGetDevice(&dev));
-        CPPF_HIP(hipGetDeviceProperties(&prop, dev));
-        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_persist_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      }
       // Small batches may have fewer slabs than CUs; how many is only known on the device (scene bounds), so the work
       // list kernel picks the number of parts per slab.  The host only decides whether a split is possible at all:
       // it costs a zeroed merge area and ticket counters per call, which a 64-scene batch never needs.
