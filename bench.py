@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--vote-mode", type=int, default=0)
+    ap.add_argument("--eager-scale-head", action="store_true",
+                    help="run the scale head on every tuple like the reference's forward (default: only on the pairs "
+                         "that survive the back-vote filter, the only rows eval.py:272 ever reads)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -59,7 +62,7 @@ class Step:
     """Holds the resident inputs and runs one pass of the path."""
 
     STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
-              "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "assemble_pose", "gather"]
+              "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "scale_head_torch", "assemble_pose", "gather"]
 
     def __init__(self, args, rank, world, dev):
         from cppf2_amd import ops, synth
@@ -88,6 +91,7 @@ class Step:
         self.shot = torch.empty((B * N, 352), dtype=torch.float32, device=dev)
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         self.gathered = [torch.empty((B, 160), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
         self.ev = None
 
     def _mark(self, name):
@@ -115,7 +119,7 @@ class Step:
         self._mark("shot_encoder_torch")
         x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
         self._mark("encode_tuples")
-        logits, scales = self.model.heads(x)
+        logits, feat = self.model.heads(x, lazy_scale=not a.eager_scale_head)
         self._mark("tuple_mlp_torch")
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
@@ -128,6 +132,13 @@ class Step:
         self._mark("backvote_filter")
         pipe.rot_bins(self.pts, idx)
         self._mark("rot_bins")
+        if a.eager_scale_head:
+            scales = feat                                # heads() already ran the scale head on every tuple
+        else:
+            # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples)
+            rows = pipe.kept_rows()
+            scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
+        self._mark("scale_head_torch")
         pipe.assemble(scales)
         self._mark("assemble_pose")
         if self.world > 1:
@@ -304,8 +315,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SHOT model, %d scenes/GPU x %d pts x %d tuples x %d rots, "
-                                   "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior"
-                                   % (B, N, T, R),
+                                   "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s"
+                                   % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only"),
                        "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,

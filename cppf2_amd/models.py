@@ -61,7 +61,7 @@ def _fused_plan(seq):
     return plan, c
 
 
-def fused_stack(seq, x):
+def fused_stack(seq, x, keep_input=False):
     """Inference-only execution of a stack of ResLayers with the elementwise work folded into GEMM epilogues
     (same fp32 math, fewer passes over the [T, C] activations, which are 1.3 M rows at bench size):
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
@@ -70,13 +70,17 @@ def fused_stack(seq, x):
     Identity-skip layers accumulate h W2^T into x in place; their output bias b2 is not added to the activation
     but carried as a pending per-channel offset c (true activation = x + c) and folded into the biases of the
     next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
-    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`.
+    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`
+    unless keep_input is set.
     The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
     plan, c = _fused_plan(seq)
-    for w1t, b1, w0t, b0, w2t in plan:
+    for li, (w1t, b1, w0t, b0, w2t) in enumerate(plan):
         h = torch._addmm_activation(b1, x, w1t)
         if w0t is not None:
             x = torch.addmm(b0, x, w0t)
+        elif li == 0 and keep_input:
+            x = torch.addmm(x, h, w2t)              # same GEMM, written to a new tensor: the caller's x survives
+            continue
         x = x.addmm_(h, w2t)
     if c is not None:
         x = x.add_(c)
@@ -125,9 +129,15 @@ class BeyondCPPFShot(nn.Module):
             return _EncodeShot.apply(points, idx, shot_feat, normal)
         return ops.encode_tuples_shot(points, idx, shot_feat, normal)
 
-    def heads(self, inputs):
+    def heads(self, inputs, lazy_scale=False):
+        """(preds_cls, preds_scale).  lazy_scale=True (inference) returns (preds_cls, feat) instead: the scale head's
+        output is only ever read for the pairs that survive the back-vote filter (eval.py:272, ~10 % of the tuples), so a
+        caller can run scale_head() on just those rows of `feat` later -- same rows through the same layers."""
         if not torch.is_grad_enabled() and inputs.is_cuda:
             feat = fused_stack(self.tuple_encoder, inputs)
+            if lazy_scale:
+                preds_cls = fused_stack(self.logit_encoder, feat, keep_input=True)
+                return preds_cls.reshape(feat.shape[0], 6, -1), feat
             preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
             preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
             return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
@@ -135,6 +145,12 @@ class BeyondCPPFShot(nn.Module):
         preds_scale = self.scale_encoder(feat)
         preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
         return preds_cls, preds_scale
+
+    def scale_head(self, feat_rows):
+        """scale_encoder on a subset of tuple features (rows of the `feat` heads(lazy_scale=True) returned)."""
+        if not torch.is_grad_enabled() and feat_rows.is_cuda:
+            return fused_stack(self.scale_encoder, feat_rows)
+        return self.scale_encoder(feat_rows)
 
     def encode_points(self, shot_feat):
         """shot_encoder over the per-point descriptors (train_shot.py:118)."""

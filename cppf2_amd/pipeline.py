@@ -147,6 +147,25 @@ class VotingPipeline:
                                             self.ws_rot_bytes, ops._stream()), "cppf_rot_bins")
         cur.wait_stream(self._side)
 
+    def kept_rows(self):
+        """Global tuple rows of the pairs that survived the back-vote filter, int64 [B * max_kept], without a host sync:
+        scene b's list is padded to max_kept entries by repeating its first row (harmless for gather / scatter)."""
+        B, mk = self.B, self.max_kept
+        base = self.tup_off[:-1].long()
+        j = torch.arange(mk, device=self.dev)
+        src = (base[:, None] + j[None, :]).clamp_(max=self.Ttot - 1)                 # where scene b keeps entry j
+        local = self.kept_tuple[src.reshape(-1)].reshape(B, mk).long()
+        valid = j[None, :] < self.kept_count[:, None]
+        rows = base[:, None] + torch.where(valid, local, torch.zeros_like(local))
+        return rows.reshape(-1)
+
+    def scatter_kept(self, rows, values, out=None):
+        """[T, C] buffer holding `values` at `rows` (what assemble() reads for the kept pairs); other rows are untouched."""
+        if out is None:
+            out = torch.zeros((self.Ttot, values.shape[1]), dtype=values.dtype, device=self.dev)
+        out[rows] = values
+        return out
+
     def assemble(self, pred_scales=None):
         _lib.check(_L.cppf_assemble_pose(self.B, ops._p(self.sphere), ops._p(self.top_idx[0]), ops._p(self.top_cnt[0]),
                                          ops._p(self.top_idx[1]), ops._p(self.top_cnt[1]), self.up_axis,

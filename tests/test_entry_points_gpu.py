@@ -276,3 +276,47 @@ def test_interpolate_features_kernel_matches_the_reference_golden():
     want = O.interpolate_features(tok.permute(2, 0, 1).cpu().numpy(), kp.cpu().numpy(), 14, True)
     assert np.abs(big.cpu().numpy() - want).max() < 2e-6
     assert ops.interpolate_features(desc, pts[None][:, :0], strides=stride).shape == (1, desc.shape[1], 0)
+
+
+def test_lazy_scale_head_equals_the_full_forward():
+    """heads(lazy_scale=True) + scale_head(feat[kept rows]) gives assemble_pose the same scales as the reference's
+    full forward (the scale head is read only at pairs_mask rows, eval.py:272); kept_rows() needs no host sync."""
+    from cppf2_amd import ops, synth
+    from cppf2_amd.models import BeyondCPPFShot
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    model = BeyondCPPFShot(Cfg()).to(dev).eval()
+    Ns, Ts = [700, 1200, 512], [3000, 5000, 2000]
+    B = len(Ns)
+    scs = [synth.make_scene(12, b, n) for b, n in enumerate(Ns)]
+    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scs])).to(dev)
+    idx = torch.cat([ops.sample_tuples(n, t, 5, 12, (b,)) for b, (n, t) in enumerate(zip(Ns, Ts))])
+    off = np.cumsum([0] + Ts)
+    prior = torch.cat([torch.from_numpy(synth.teacher_logits(s["pc_canon"], idx[off[b]:off[b + 1]].cpu().numpy(), 32))
+                       for b, s in enumerate(scs)]).to(dev)
+    u = torch.cat([ops.philox_uniform(t, 6, 12, 1, (b,)) for b, t in enumerate(Ts)])
+    x = torch.randn(sum(Ts), 360, device=dev) * 0.1
+    pipe = VotingPipeline(Ns, Ts, num_rots=60)
+    with torch.no_grad():
+        cls_e, sc_e = model.heads(x.clone())
+        cls_l, feat = model.heads(x.clone(), lazy_scale=True)
+        assert torch.allclose(cls_e, cls_l, atol=1e-5)
+        pipe.decode(pts, idx, cls_e.contiguous(), u, prior=prior)
+        pipe.vote_center(pts, idx); pipe.backvote(pts, idx); pipe.rot_bins(pts, idx)
+        pipe.assemble(sc_e.contiguous())
+        want = pipe.results_to_numpy()
+        rows = pipe.kept_rows()
+        kept = pipe.kept_count.cpu().numpy()
+        assert rows.shape[0] == B * pipe.max_kept and int(kept.min()) > 10
+        # the first kept_count[b] entries of scene b are its kept tuples, the padding repeats a row of the same scene
+        kt = pipe.kept_tuple.cpu().numpy()
+        r = rows.cpu().numpy().reshape(B, -1)
+        for b in range(B):
+            assert np.array_equal(r[b, :kept[b]], off[b] + kt[off[b]:off[b] + kept[b]])
+            assert np.all((r[b] >= off[b]) & (r[b] < off[b + 1]))
+        scales = pipe.scatter_kept(rows, model.scale_head(feat[rows]))
+        pipe.assemble(scales)
+        got = pipe.results_to_numpy()
+    assert np.allclose(got["scale"], want["scale"], atol=1e-6) and np.array_equal(got["R"], want["R"])
+    assert np.array_equal(got["kept"], want["kept"])
