@@ -8,7 +8,9 @@
 One *step* = one pass of the whole path over a batch of synthetic scenes resident in HBM:
   sampler (HIP) -> normals + SHOT352 (HIP) -> shot_encoder (torch fp32) -> tuple encode (HIP) -> tuple MLP
   (torch fp32) -> bin decode + vote parameters (HIP) -> centre vote + argmax (HIP) -> back-vote filter (HIP)
-  -> rotation votes x2 (HIP) -> pose assembly (HIP) -> one RCCL all_gather of the 160-byte scene records (N > 1).
+  -> rotation votes x2 (HIP) -> scale head on the kept pairs (torch fp32) -> pose assembly (HIP) -> one RCCL
+  all_gather of the 160-byte scene records (N > 1).  (--eager-scale-head runs the scale head inside the tuple MLP on
+  every tuple, the order of the reference's forward; its output is read only for the kept pairs, eval.py:272.)
 Workload = BASELINE.json configs[1]: SHOT model, 4096 points x 20 000 tuples per scene, 180 rotations, 720 sphere
 bins, res 2 mm ('bottle' axes), scenes = seeded synthetic bottle-like clouds (cppf2_amd.synth); weights are
 random-init (no checkpoints ship with the reference) plus a fixed teacher logit prior so that votes cluster the
