@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--tuples", type=int, default=20000)
     ap.add_argument("--rots", type=int, default=180)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--vote-mode", type=int, default=0)
     ap.add_argument("--eager-scale-head", action="store_true",
                     help="run the scale head on every tuple like the reference's forward (default: only on the pairs "
