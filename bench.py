@@ -94,6 +94,7 @@ class Step:
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         self.gathered = [torch.empty((B, 160), dtype=torch.uint8, device=dev) for _ in range(world)]
         self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
+        self.side = torch.cuda.Stream(device=dev)
         self.ev = None
 
     def _mark(self, name):
@@ -132,14 +133,20 @@ class Step:
         self._mark("vote_center")
         pipe.backvote(self.pts, idx)
         self._mark("backvote_filter")
-        pipe.rot_bins(self.pts, idx)
-        self._mark("rot_bins")
         if a.eager_scale_head:
             scales = feat                                # heads() already ran the scale head on every tuple
         else:
-            # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples)
-            rows = pipe.kept_rows()
-            scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
+            # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples),
+            # on a side stream -- it needs the back-vote filter only, like the rotation votes it runs beside
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                rows = pipe.kept_rows()
+                scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
+        pipe.rot_bins(self.pts, idx)
+        self._mark("rot_bins")
+        if not a.eager_scale_head:
+            torch.cuda.current_stream().wait_stream(self.side)
         self._mark("scale_head_torch")
         pipe.assemble(scales)
         self._mark("assemble_pose")
