@@ -11,7 +11,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CppfError(RuntimeError):
