@@ -39,3 +39,11 @@ for s in range(ns):
     tot_c += cnt.sum(); tot_q += q.sum(); tot_w += w
     print("slab", s, "layers", xl, xh, "cand", int(cnt.sum()), "quanta", int(q.sum()), "windows", w, "fill %.2f" % (cnt.sum() / max(1, w * 64 * Q)))
 print("total cand", int(tot_c), "of", T * R, "quanta", int(tot_q), "windows", tot_w, "lane-slot fill %.2f" % (tot_c / (tot_w * 64 * Q)))
+
+# fraction of the x-arc candidates that also land inside the grid in y and z (how much a second arc constraint could cut)
+vy = c[:, 1:2] + x[:, 1:2] * np.cos(th) + y[:, 1:2] * np.sin(th)
+vz = c[:, 2:3] + x[:, 2:3] * np.cos(th) + y[:, 2:3] * np.sin(th)
+iy = np.floor((vy - c0[1]) / res + 0.5); iz = np.floor((vz - c0[2]) / res + 0.5)
+inx = (ix >= 1) & (ix < g[0]); iny = (iy >= 1) & (iy < g[1]); inz = (iz >= 1) & (iz < g[2])
+print("rotations with x in grid: %.3f of all; of those, y in grid %.3f, z in grid %.3f, both %.3f"
+      % (inx.mean(), (inx & iny).sum() / inx.sum(), (inx & inz).sum() / inx.sum(), (inx & iny & inz).sum() / inx.sum()))
