@@ -54,6 +54,7 @@ SIGNATURES = {
     "cppf_encode_tuples_shot": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
     "cppf_encode_tuples_shot_f16": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
     "cppf_encode_tuples_coord": (_i, [_i, _p, _p, _i, _p, _p, _i64, _p, _i, _p]),
+    "cppf_encode_tuples_dino": (_i, [_i, _p, _i, _i, _p, _p, _p, _p, _i64, _p, _i, _i, _p]),
     "cppf_decode_bins": (_i, [_i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "cppf_generate_target_pairs": (_i, [_i, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "cppf_scene_bounds": (_i, [_i, _p, _p, _f, _p, _p]),

@@ -374,6 +374,48 @@ extern "C" int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* 
   return CPPF_OK;
 }
 
+// a3' (DINO model), descriptor part of prepare_tuple_inputs (train_dino.py:95-96):
+//   desc_pair_transform(cat_i desc_transform(desc[idx_i])) = bias + sum_i W_i . d[idx_i]   (W = [W_0 | ... | W_{k-1}])
+// so the Linear over the concatenation is a sum of k per-point products.  The caller forms the k products once per
+// POINT (tables[n][i][:] = W_i d[n], k small GEMMs over N rows instead of one over T rows with K = k*D), and this kernel
+// gathers and adds k rows per tuple: no [T, k*D] temporary, T/N times fewer FLOPs.  thread = (tuple, 4 channels).
+__global__ __launch_bounds__(256) void encode_dino_kernel(int B, const float* __restrict__ tables, int k, int D,
+                                                          const float* __restrict__ bias,
+                                                          const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ pt_off,
+                                                          const int32_t* __restrict__ tup_off, int64_t total,
+                                                          float* __restrict__ out, int out_stride, int out_col) {
+  const int dv = D >> 2;
+  const int64_t n = total * dv;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / dv;
+    const int c = (int)(v - t * dv) << 2;
+    const int b = find_scene(tup_off, B, t);
+    const int64_t p0 = pt_off[b];
+    float4 a = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < k; ++i) {
+      const float4 r = *reinterpret_cast<const float4*>(tables + ((p0 + idx[t * k + i]) * k + i) * D + c);
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    float* o = out + t * out_stride + out_col + c;               // rows need not be 16-byte aligned (30 + 256 floats)
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+  }
+}
+
+extern "C" int cppf_encode_tuples_dino(int B, const float* tables, int k, int D, const float* bias, const int32_t* idx,
+                                       const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, float* out,
+                                       int out_stride, int out_col, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && tables && idx && pt_off && tup_off && out);
+  CPPF_CHECK_ARG(k >= 1 && k <= 8 && D > 0 && D % 4 == 0 && out_col >= 0 && out_stride >= out_col + D);
+  if (total_tuples <= 0) return CPPF_OK;
+  const int64_t blocks = (total_tuples * (D / 4) + 255) / 256;
+  const int grid = (int)(blocks < 256 * 64 ? blocks : 256 * 64);
+  hipLaunchKernelGGL(encode_dino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, tables, k, D, bias, idx,
+                     pt_off, tup_off, total_tuples, out, out_stride, out_col);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // a4 + a5. bin decode fused with generate_target_pairs.
 // Workgroup = 192 threads = 32 tuples x 6 coordinates: phase 1, one thread per (tuple, coord) reads its

@@ -184,15 +184,20 @@ class BeyondCPPFDino(nn.Module):
         idx = point_idxs_all.to(torch.int32)
         T, k = idx.shape
         per_point = self.desc_transform(point_descs)                                   # [N,256]
-        gathered = per_point[idx.long().reshape(-1)].reshape(T, k * per_point.shape[1])  # cat_i desc_transform(desc[idx_i])
+        d = per_point.shape[1]
+        if not torch.is_grad_enabled() and per_point.is_cuda:
+            # Linear over the concatenation = sum of k per-point products: k GEMMs over N rows + a gather-add kernel
+            # instead of a [T, k*256] gather and a K = k*256 GEMM over T rows (T/N = 5x the FLOPs, 6.5 GB at bench size)
+            w = self.desc_pair_transform.weight                                        # [256, k*256]
+            tables = torch.stack([per_point @ w[:, i * d:(i + 1) * d].t() for i in range(k)], 1).contiguous()
+            out = torch.empty((T, self.ncoord + d), dtype=torch.float32, device=per_point.device)
+            ops.encode_tuples_coord(points, idx, out=out)
+            ops.encode_tuples_dino(tables, self.desc_pair_transform.bias, idx, out, self.ncoord)
+            return out
+        gathered = per_point[idx.long().reshape(-1)].reshape(T, k * d)                 # cat_i desc_transform(desc[idx_i])
         desc_part = self.desc_pair_transform(gathered)
-        if torch.is_grad_enabled() and desc_part.requires_grad:
-            coord = ops.encode_tuples_coord(points, idx)
-            return torch.cat([coord, desc_part], -1)
-        out = torch.empty((T, self.ncoord + desc_part.shape[1]), dtype=torch.float32, device=desc_part.device)
-        ops.encode_tuples_coord(points, idx, out=out)
-        out[:, self.ncoord:] = desc_part
-        return out
+        coord = ops.encode_tuples_coord(points, idx)
+        return torch.cat([coord, desc_part], -1)
 
     def forward(self, points, point_descs, point_idxs_all):
         inputs = self.prepare_tuple_inputs(points, point_descs, point_idxs_all)

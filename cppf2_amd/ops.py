@@ -276,6 +276,25 @@ def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=N
 # ----------------------------------------------------------------------------------------------
 # a4 + a5. decode
 # ----------------------------------------------------------------------------------------------
+def encode_tuples_dino(tables, bias, point_idxs_all, out, out_col, pt_off=None, tup_off=None):
+    """Descriptor part of the DINO model's prepare_tuple_inputs (train_dino.py:95-96) as a gather-add of per-point
+    products: out[:, out_col:out_col+D] = bias + sum_i tables[idx[:, i], i, :] (tables [N, k, D], see cppf_hip.h)."""
+    dev = _dev()
+    tb = _t(tables, torch.float32, dev)
+    n, k, D = tb.shape
+    idx = _t(point_idxs_all, torch.int32, dev)
+    T = idx.shape[0]
+    if pt_off is None:
+        pt_off, tup_off = _offsets([n], dev), _offsets([T], dev)
+    B = pt_off.numel() - 1
+    bs = None if bias is None else _t(bias, torch.float32, dev)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != T:
+        raise CppfError("encode_tuples_dino: out must be a contiguous float32 [T, C] tensor")
+    _lib.check(_L.cppf_encode_tuples_dino(B, _p(tb), k, D, _p(bs), _p(idx), _p(pt_off), _p(tup_off), T, _p(out),
+                                          out.shape[1], int(out_col), _stream()), "cppf_encode_tuples_dino")
+    return out
+
+
 def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt_off=None, tup_off=None, prior=None):
     """eval.py:225-240.  pred_cls [T,6,nb] logits, uniforms [T,6] in [0,1).  (up, right, front) are the three
     axis vectors in the positional order of generate_target_pairs' signature (the reference call site passes

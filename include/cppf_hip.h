@@ -124,6 +124,14 @@ int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k,
                              const int32_t* tup_off, int64_t total_tuples, float* out, int out_stride,
                              void* stream);
 
+/* a3' descriptor part (DINO model): replaces desc_pair_transform(cat_i desc_transform(desc[idx_i])) (train_dino.py:95-96)
+ * by a gather-add of per-point products: tables float32[total_points, k, D] with tables[n][i] = W_i . d[n] (W_i = the i-th
+ * column block of desc_pair_transform.weight, d = desc_transform(desc)), bias float32[D] or NULL;
+ * out[t, out_col + c] = bias[c] + sum_i tables[pt_off[b] + idx[t,i]][i][c].  D % 4 == 0; out row stride in floats. */
+int cppf_encode_tuples_dino(int B, const float* tables, int k, int D, const float* bias, const int32_t* idx,
+                            const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, float* out,
+                            int out_stride, int out_col, void* stream);
+
 /* ---- a4+a5. bin decode + vote parameters: replaces eval.py:225-240 (softmax, one multinomial draw per
  * (tuple, coord) by inverse CDF from `uniforms`, bin/(nb-1)-0.5, per-pair metric scale) fused with
  * generate_target_pairs(pred_pairs_scaled, a1, a2, a3) (dataset.py:118-135, centre 0).

@@ -320,3 +320,21 @@ def test_lazy_scale_head_equals_the_full_forward():
         got = pipe.results_to_numpy()
     assert np.allclose(got["scale"], want["scale"], atol=1e-6) and np.array_equal(got["R"], want["R"])
     assert np.array_equal(got["kept"], want["kept"])
+
+
+def test_encode_tuples_dino_gather_add_equals_linear_over_concatenation():
+    """cppf_encode_tuples_dino == desc_pair_transform(cat_i d[idx_i]) (train_dino.py:95-96), batched and ragged."""
+    from cppf2_amd import ops
+    rng = np.random.RandomState(4)
+    Ns, Ts, k, D = [300, 513], [1000, 777], 5, 64
+    d = torch.from_numpy(rng.randn(sum(Ns), D).astype(np.float32)).cuda()
+    lin = torch.nn.Linear(k * D, D).cuda()
+    idx = torch.cat([torch.from_numpy(rng.randint(0, n, (t, k)).astype(np.int32)) for n, t in zip(Ns, Ts)]).cuda()
+    pt_off, tup_off = ops._offsets(Ns, d.device), ops._offsets(Ts, d.device)
+    base = torch.repeat_interleave(pt_off[:-1].long(), torch.tensor(Ts, device=d.device))
+    with torch.no_grad():
+        want = lin(d[(idx.long() + base[:, None]).reshape(-1)].reshape(-1, k * D))
+        tables = torch.stack([d @ lin.weight[:, i * D:(i + 1) * D].t() for i in range(k)], 1).contiguous()
+    out = torch.full((sum(Ts), 30 + D), 7.0, device=d.device)
+    ops.encode_tuples_dino(tables, lin.bias, idx, out, 30, pt_off, tup_off)
+    assert torch.allclose(out[:, 30:], want, atol=2e-5) and bool((out[:, :30] == 7.0).all())
