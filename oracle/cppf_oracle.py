@@ -163,18 +163,28 @@ def prepare_tuple_inputs_shot(points, idx, feat, normal):
 # is the same distribution.  `margin` lets a test ignore draws whose uniform
 # falls within rounding distance of a CDF edge (exp() differs by ulps CPU/GPU).
 # ----------------------------------------------------------------------------
+def softmax_cdf(pred_cls):
+    """Un-normalised softmax terms exp(x - max) (f32), their left-to-right f32 running sum and its total.
+    e / total is torch.softmax(pred_cls, -1) of eval.py:228 (pinned by tests/golden/axes.npz: softmax_prob);
+    the inverse-CDF draw compares u * total with the running sum, i.e. u with the normalised CDF."""
+    pred_cls = np.asarray(pred_cls, dtype=F32)
+    NB = pred_cls.shape[-1]
+    m = pred_cls.max(-1, keepdims=True)
+    e = np.exp((pred_cls - m).astype(F32)).astype(F32)
+    cdf = np.empty_like(e)
+    acc = np.zeros(pred_cls.shape[:-1], dtype=F32)
+    for k in range(NB):                       # left-to-right f32 running sum
+        acc = (acc + e[..., k]).astype(F32)
+        cdf[..., k] = acc
+    return e, cdf, acc
+
+
 def decode_bins(pred_cls, uniforms, input_pairs, return_margin=False):
     """pred_cls f32[T,6,32] logits, uniforms f32[T,6] in [0,1), input_pairs f32[T,2,3].
     Returns bins int32[T,6], pred_pairs f32[T,2,3], scale f32[T], pred_pairs_scaled f32[T,2,3]."""
     pred_cls = np.asarray(pred_cls, dtype=F32)
     T, C, NB = pred_cls.shape
-    m = pred_cls.max(-1, keepdims=True)
-    e = np.exp((pred_cls - m).astype(F32)).astype(F32)
-    cdf = np.empty_like(e)
-    acc = np.zeros((T, C), dtype=F32)
-    for k in range(NB):                       # left-to-right f32 running sum
-        acc = (acc + e[..., k]).astype(F32)
-        cdf[..., k] = acc
+    e, cdf, acc = softmax_cdf(pred_cls)
     target = (np.asarray(uniforms, dtype=F32) * acc).astype(F32)      # u * total
     bins = (cdf <= target[..., None]).sum(-1).astype(np.int32)        # first k with cdf[k] > target
     bins = np.minimum(bins, NB - 1)

@@ -1,0 +1,133 @@
+"""Non-default axis conventions on the HIP path (through the C ABI).  The reference ships one: the `camera` and `mug`
+categories vote their second rotation axis about z and write it to column 2 of R (config/category/camera.yaml:5-6,
+mug.yaml:5-6: front = [1,0,0], right = [0,0,1]); the third column then is R[:,1] x R[:,2] instead of R[:,0] x R[:,1]
+(eval.py:312-313).  Vectors: tests/golden/axes.npz, produced by the reference's own functions
+(tests/golden/make_golden_axes.py).  Needs an MI355X: run with `pytest -m gpu`.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+from oracle import cppf_oracle as O            # noqa: E402  (checker only)
+from cppf2_amd import ops, synth               # noqa: E402
+from cppf2_amd.config import load_config       # noqa: E402
+from cppf2_amd.pipeline import VotingPipeline  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DEV = torch.device("cuda")
+
+
+def dev(x, dtype):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(DEV, dtype)
+
+
+@pytest.fixture(scope="module")
+def axes_g():
+    return dict(np.load(os.path.join(GOLDEN, "axes.npz")))
+
+
+@pytest.mark.parametrize("name", ["default", "camera"])
+def test_stages_on_reference_vectors(axes_g, name):
+    """generate_target_pairs -> vote_center -> back-vote -> rotation bins -> assemble_pose, stage by stage on the
+    reference's own intermediate tensors, for the default and the camera/mug axes."""
+    g = axes_g
+    up, right, front = (g[name + "_axes"][i].tolist() for i in range(3))
+    pc, idx, trig = g["pc"], g["idx"], (g["cos"], g["sin"])
+    tr, rot = ops.generate_target_pairs(g["scaled"], up, front, right)                 # eval.py:237-240 argument order
+    assert np.array_equal(tr, g[name + "_targets_tr"])
+    assert np.allclose(rot, g[name + "_targets_rot"], rtol=0, atol=2.4e-7, equal_nan=True)   # device acos: 1 f32 ulp
+    N, T, R = pc.shape[0], idx.shape[0], 36
+    pipe = VotingPipeline([N], [T], k=5, res=2e-3, num_rots=R, cfg_up=up, cfg_right=right, cfg_front=front, trig=trig)
+    assert pipe.up_axis == 1 and pipe.right_axis == (2 if name == "camera" else 0)
+    pts, di = dev(pc, torch.float32), dev(idx, torch.int32)
+    pipe.tr.copy_(dev(g[name + "_targets_tr"], torch.float32))
+    pipe.rot.copy_(dev(g[name + "_targets_rot"], torch.float32))
+    pipe.vote_center(pts, di)
+    grid = g[name + "_grid_obj"]
+    assert int(pipe.argmax.item()) == int(np.argmax(grid)) and int(pipe.peak.item()) == int(grid.max())
+    assert np.array_equal(pipe.world.cpu().numpy()[0], g[name + "_T_est"])
+    pipe.backvote(pts, di)
+    kept = int(pipe.kept_count.item())
+    assert np.array_equal(pipe.mask.cpu().numpy().astype(bool), g[name + "_pairs_mask"])
+    assert np.array_equal(pipe.errs.cpu().numpy(), g[name + "_back_errs"])
+    assert np.array_equal(pipe.kept_wt.cpu().numpy()[:kept], g[name + "_imp_pair_wt"])
+    for use_lut in (False, True):
+        pipe.rot_bins(pts, di, use_lut=use_lut)
+        for a, ax in ((0, "up"), (1, "right")):
+            want = g["%s_%s_counts" % (name, ax)]
+            d = np.abs(pipe.counts[a, 0].cpu().numpy() - want)
+            # tanf ulps flip isolated cone tests: <= 4 bins off by <= 2 votes of the largest weight
+            assert (d > 0).sum() <= 4 and d.max() <= 2.0 / g[name + "_imp_pair_wt"].min()
+            assert int(pipe.top_idx[a, 0].item()) == int(g["%s_%s_top1" % (name, ax)])
+    pipe.assemble(None)
+    r = pipe.results_to_numpy()[0]
+    # R from the reference's own NumPy statements (eval.py:295-313); the kernel's Gram-Schmidt is f32 like the
+    # reference's in-place ops, the cross product f64
+    assert np.allclose(r["R"], g[name + "_R_est"], rtol=0, atol=1e-6)
+    assert abs(np.linalg.det(r["R"]) - 1) < 1e-5
+    assert np.array_equal(r["R"][:, 1].astype(np.float32), g["%s_up_top5_dirs" % name][0])
+    assert np.allclose(r["R"][:, pipe.right_axis], g[name + "_right_orth"], atol=1e-6)
+
+
+def test_camera_and_default_axes_give_different_rotations(axes_g):
+    g = axes_g
+    assert not np.allclose(g["default_R_est"], g["camera_R_est"], atol=1e-3)
+
+
+@pytest.mark.parametrize("category", ["mug", "camera", "laptop", "bottle"])
+def test_pipeline_with_category_config_vs_oracle(category):
+    """Whole post-MLP path with the axes the category's YAML selects, ragged batch, against O.run_scene."""
+    cfg = load_config(os.path.join(ROOT, "config"), "config", ["category=" + category])
+    up, right, front = list(cfg.up), list(cfg.right), list(cfg.front)
+    if category in ("mug", "camera"):
+        assert right == [0, 0, 1] and front == [1, 0, 0]
+    rng = np.random.RandomState(17)
+    Ns, Ts, R = [700, 1024], [4000, 5000], 60
+    scenes = []
+    for s in range(2):
+        scene = synth.make_scene(21, s, Ns[s])
+        idx = synth.host_sample_tuples(21, s, Ts[s], 5, Ns[s])
+        logits = synth.teacher_logits(scene["pc_canon"], idx, 32, 0.6) + rng.randn(Ts[s], 6, 32).astype(np.float32) * 0.3
+        scenes.append((scene, idx, logits.astype(np.float32), O.philox_uniform(21, s, 1, Ts[s], 6),
+                       rng.rand(Ts[s], 3).astype(np.float32)))
+    pipe = VotingPipeline(Ns, Ts, k=5, res=cfg.res, num_rots=R, cfg_up=up, cfg_right=right, cfg_front=front,
+                          cells_cap=1 << 20)
+    pts = dev(np.concatenate([s[0]["pc"] for s in scenes]), torch.float32)
+    idx = dev(np.concatenate([s[1] for s in scenes]), torch.int32)
+    logits = dev(np.concatenate([s[2] for s in scenes]), torch.float32)
+    u = dev(np.concatenate([s[3] for s in scenes]), torch.float32)
+    sc = dev(np.concatenate([s[4] for s in scenes]), torch.float32)
+    res = pipe.results_to_numpy(pipe.vote(pts, idx, logits, u, sc))
+    trig = (pipe.cs.cpu().numpy(), pipe.sn.cpu().numpy())
+    bins_all = pipe.bins.cpu().numpy()
+    t0 = 0
+    for s, (scene, idx_s, lg, us, scl) in enumerate(scenes):
+        T = Ts[s]
+        onehot = np.full((T, 6, 32), -1e4, np.float32)          # the oracle decodes the device's bins
+        np.put_along_axis(onehot, bins_all[t0:t0 + T, :, None].astype(np.int64), 0.0, -1)
+        want = O.run_scene(scene["pc"], idx_s, onehot, scl, us, up, right, front, cfg.res, num_rots=R, trig=trig)
+        r = res[s]
+        assert r["argmax"] == want["argmax"] and np.array_equal(r["t"], want["T_est"])
+        assert np.array_equal(pipe.mask.cpu().numpy()[t0:t0 + T].astype(bool), want["pairs_mask"])
+        for a, name in ((0, "up"), (1, "right")):
+            d = np.abs(pipe.counts[a, s].cpu().numpy() - want[name + "_counts"])
+            assert (d > 0).sum() <= 4 and d.max() <= 2.0 / want["imp_pair_wt"].min()
+            assert int(r[name + "_idx"]) == want[name + "_idx"]
+        assert np.allclose(r["R"], want["R_est"], atol=1e-6)
+        assert np.array_equal(r["scale"], want["pred_scale"])
+        # against the synthetic ground truth: the up column and the column cfg.right selects
+        assert np.linalg.norm(r["t"] - scene["t"]) < 5e-3
+        iu, ir = int(np.nonzero(up)[0][0]), int(np.nonzero(right)[0][0])
+        for col in (iu, ir):
+            cosang = float(r["R"][:, col] @ scene["R"][:, col])
+            assert np.degrees(np.arccos(min(cosang, 1.0))) < 6.0, (category, col)
+        assert abs(np.linalg.det(r["R"]) - 1) < 1e-5
+        t0 += T
