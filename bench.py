@@ -8,7 +8,7 @@
 One *step* = one pass of the whole path over a batch of synthetic scenes resident in HBM:
   sampler (HIP) -> normals + SHOT352 (HIP) -> shot_encoder (torch fp32) -> tuple encode (HIP) -> tuple MLP
   (torch fp32) -> bin decode + vote parameters (HIP) -> centre vote + argmax (HIP) -> back-vote filter (HIP)
-  -> rotation votes x2 (HIP) -> scale head on the kept pairs (torch fp32) -> pose assembly (HIP) -> one RCCL
+  -> both rotation votes (HIP, one kernel) -> scale head on the kept pairs (torch fp32) -> pose assembly (HIP) -> one RCCL
   all_gather of the 160-byte scene records (N > 1).  (--eager-scale-head runs the scale head inside the tuple MLP on
   every tuple, the order of the reference's forward; its output is read only for the kept pairs, eval.py:272.)
 Workload = BASELINE.json configs[1]: SHOT model, 4096 points x 20 000 tuples per scene, 180 rotations, 720 sphere
@@ -301,7 +301,7 @@ def main():
         res = step.pipe.results_to_numpy()
         G = int(np.mean(res["ncell"]))
         hip_stages = [s for s in Step.STAGES if "torch" not in s and s != "gather"]
-        launches = {"rot_bins": 2}            # the stage launches its dominant kernel once per voted axis
+        launches = {}                         # launches of the stage's dominant kernel per step (all 1)
         dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0) / launches.get(s, 1))
         rows = []
         for s in Step.STAGES:

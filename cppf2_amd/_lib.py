@@ -11,7 +11,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CppfError(RuntimeError):
@@ -67,6 +67,8 @@ SIGNATURES = {
     "cppf_rot_bins_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "cppf_rot_bins": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
                            _p, _p, _p, _p, _i64, _p]),
+    "cppf_rot_bins2": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
+                            _p, _p, _p, _p, _i64, _p]),
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),
     "cppf_refine_pose": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p]),

@@ -1193,144 +1193,156 @@ __global__ __launch_bounds__(RB_THREADS) void rot_bins_dense_kernel(
 // cone + cell circumradius of the cell centre; <= RL_K per cell, 0.46 on average for the 720 fibonacci bins).
 // One thread per candidate axis: cell of the candidate -> one 16-byte table row -> exact cosine test of those few
 // bins only.  Works for any bin set; counts are identical to the dense kernel's (tests compare them).
-// Hits go to LDS float64 accumulators; each workgroup's two per-chunk partial sums leave with plain coalesced
-// stores and are folded in a fixed order by rot_bins_fold_kernel (no global atomics, run-to-run reproducible).
+//
+// Work decomposition follows the reference's float32 accumulation chunks (eval.py:41-45: rows [c*bmm, (c+1)*bmm) of the
+// candidate list are summed in float64, then added to the float32 counts): a workgroup owns `rows_per_block`
+// consecutive candidate rows that never straddle a chunk boundary (`sub_blocks` workgroups per chunk), so it has ONE
+// float64 accumulator set per voted axis in LDS, and it votes BOTH axes (eval.py:277-293: the up and the right vote
+// share the pair frames and differ only in the angle column) from the same per-pair frames.  The accumulators
+// leave with plain coalesced stores and rot_bins_fold_kernel adds the sub-block sums of a chunk in a fixed order:
+// no global atomics, run-to-run reproducible.
 #define RW_THREADS 256
-#define RW_PPB 32          // pairs per workgroup
 #define RL_K 8             // table slots per cell (int16 bin ids, -1 = empty)
 struct RwFrame {
-  float xx, xy, xz, yx, yy, yz, sux, suy, suz, tn;   // in-plane axes, sign(tan)*u, tan
-  int row0;
+  float xx, xy, xz, yx, yy, yz, ux, uy, uz;   // in-plane axes, pair direction
+  float tn[2];                                // tan of the predicted angle to each voted axis
+  int row0;                                   // first row of the pair in vote_rotation's compacted candidate list
   double inv_wt;
 };
 
+template <int NAX>
 __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
-    const int32_t* __restrict__ tup_off, const float* __restrict__ rot, int rot_col,
+    const int32_t* __restrict__ tup_off, const float* __restrict__ rot, int rot_col0, int rot_col1,
     const int32_t* __restrict__ kept_tuple, const int32_t* __restrict__ kept_count,
-    const double* __restrict__ kept_wt, const int32_t* __restrict__ kept_row0, int pairs_per_block, int num_rots,
-    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const float* __restrict__ sphere, int S,
-    float cos_thr, const int4* __restrict__ lut, int lut_rows, int lut_cols, int bmm_size,
-    double* __restrict__ partial /* [B][nblk][2][S] */, int32_t* __restrict__ block_chunk /* [B][nblk] */) {
+    const double* __restrict__ kept_wt, const int32_t* __restrict__ kept_row0, int rows_per_block, int sub_blocks,
+    int max_pairs, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+    const float* __restrict__ sphere, int S, float cos_thr, const int4* __restrict__ lut, int lut_rows, int lut_cols,
+    int bmm_size, double* __restrict__ partial /* [B][gridDim.x][NAX][S] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* s_sph = (float4*)smem;                                     // [S] (x, y, z, -)
-  double* s_acc = (double*)(smem + (size_t)S * 16);                  // [2][S]
-  __shared__ RwFrame s_fr[RW_PPB];
-  __shared__ int s_cb;
+  double* s_acc = (double*)(smem + (size_t)S * 16);                  // [NAX][S]
+  float2* s_trig = (float2*)(s_acc + (size_t)NAX * S);               // [num_rots] (cos, sin)
+  RwFrame* s_fr = (RwFrame*)(s_trig + num_rots);                     // [max_pairs]
+  int* s_list = (int*)(s_fr + max_pairs);                            // [max_pairs] kept-list positions of the block's pairs
+  __shared__ int s_n;
   const int b = blockIdx.y;
+  const int chunk = blockIdx.x / sub_blocks, sub = blockIdx.x - chunk * sub_blocks;
+  const int64_t lo64 = (int64_t)chunk * bmm_size + (int64_t)sub * rows_per_block;
+  const int64_t hi64 = min(lo64 + rows_per_block, (int64_t)(chunk + 1) * bmm_size);
   const int kept = kept_count[b];
-  const int j0 = blockIdx.x * pairs_per_block;
-  const int64_t blk = (int64_t)b * gridDim.x + blockIdx.x;
-  if (j0 >= kept) {
-    if (threadIdx.x == 0) block_chunk[blk] = -1;
+  const int t0 = tup_off[b];
+  double* out = partial + ((int64_t)b * gridDim.x + blockIdx.x) * NAX * S;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  // pairs with a candidate row in [lo, hi): row0 is increasing over the valid kept pairs, -1 for degenerate ones
+  if (lo64 < (int64_t)kept * num_rots) {
+    const int lo = (int)lo64, hi = (int)min(hi64, (int64_t)kept * num_rots);
+    for (int j = threadIdx.x; j < kept; j += RW_THREADS) {
+      const int row0 = kept_row0[t0 + j];
+      if (row0 >= 0 && row0 < hi && row0 + num_rots > lo) {
+        const int pos = atomicAdd(&s_n, 1);
+        if (pos < max_pairs) s_list[pos] = j;
+      }
+    }
+  }
+  __syncthreads();
+  const int npairs = min(s_n, max_pairs);
+  if (npairs == 0) {                                                  // chunk beyond this scene's rows
+    for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) out[i] = 0.0;
     return;
   }
-  const int npairs = min(pairs_per_block, kept - j0);
-  const int ncand = npairs * num_rots;
-  const int t0 = tup_off[b];
+  const int lo = (int)lo64, hi = (int)hi64;
   const float* p = pts + 3 * (int64_t)pt_off[b];
   for (int i = threadIdx.x; i < S; i += RW_THREADS)
     s_sph[i] = make_float4(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2], 0.0f);
-  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) s_acc[i] = 0.0;
-  if (threadIdx.x == 0) s_cb = 0x7fffffff;
-  __syncthreads();
-  // phase 1: one thread per pair -- frame of the pair (train_dino.py:219-232), tan of its angle, weight
-  if (threadIdx.x < npairs) {
-    const int j = j0 + threadIdx.x;
+  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) s_acc[i] = 0.0;
+  for (int i = threadIdx.x; i < num_rots; i += RW_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
+  // phase 1: one thread per pair -- frame of the pair (train_dino.py:219-232), tan of its angles, weight
+  for (int i = threadIdx.x; i < npairs; i += RW_THREADS) {
+    const int j = s_list[i];
+    const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
+    const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
     RwFrame fr;
+    const float den = fmaxf(f.nco, 1e-7f);
+    fr.xx = f.cox / den; fr.xy = f.coy / den; fr.xz = f.coz / den;
+    fr.yx = cross_term(fr.xy, f.uz, fr.xz, f.uy);
+    fr.yy = cross_term(fr.xz, f.ux, fr.xx, f.uz);
+    fr.yz = cross_term(fr.xx, f.uy, fr.xy, f.ux);
+    fr.ux = f.ux; fr.uy = f.uy; fr.uz = f.uz;
+    fr.tn[0] = tanf(rot[row * 3 + rot_col0]);
+    fr.tn[1] = (NAX > 1) ? tanf(rot[row * 3 + rot_col1]) : 0.0f;
     fr.row0 = kept_row0[t0 + j];
-    fr.inv_wt = 0.0;
-    fr.xx = fr.xy = fr.xz = fr.yx = fr.yy = fr.yz = fr.sux = fr.suy = fr.suz = fr.tn = 0.0f;
-    if (fr.row0 >= 0) {
-      const int64_t row = (int64_t)(t0 + kept_tuple[t0 + j]);
-      const PairFrame f = pair_frame(p, idx[row * k], idx[row * k + 1]);
-      const float den = fmaxf(f.nco, 1e-7f);
-      fr.xx = f.cox / den; fr.xy = f.coy / den; fr.xz = f.coz / den;
-      fr.yx = cross_term(fr.xy, f.uz, fr.xz, f.uy);
-      fr.yy = cross_term(fr.xz, f.ux, fr.xx, f.uz);
-      fr.yz = cross_term(fr.xx, f.uy, fr.xy, f.ux);
-      fr.tn = tanf(rot[row * 3 + rot_col]);
-      const float sg = (fr.tn > 0.0f) ? 1.0f : -1.0f;
-      fr.sux = sg * f.ux; fr.suy = sg * f.uy; fr.suz = sg * f.uz;
-      fr.inv_wt = 1.0 / kept_wt[t0 + j];
-      atomicMin(&s_cb, fr.row0 / bmm_size);          // chunk of the block's first row
-    }
-    s_fr[threadIdx.x] = fr;
+    fr.inv_wt = 1.0 / kept_wt[t0 + j];
+    s_fr[i] = fr;
   }
   __syncthreads();
-  const int cb = s_cb;
-  if (cb == 0x7fffffff) {
-    if (threadIdx.x == 0) block_chunk[blk] = -1;
-    return;
-  }
   const float row_scale = 0.5f * (float)lut_rows, col_scale = (float)lut_cols * 0.15915494309189535f;
-  // phase 2: one thread per candidate axis (train_dino.py:233-237)
+  // phase 2: one thread per candidate offset (pair, rotation); each voted axis' candidate (train_dino.py:233-237)
+  const int ncand = npairs * num_rots;
+  const int dq = RW_THREADS / num_rots, dr = RW_THREADS - dq * num_rots;
+  int pj = (int)threadIdx.x / num_rots, r = (int)threadIdx.x - pj * num_rots;
   for (int c = threadIdx.x; c < ncand; c += RW_THREADS) {
-    const int pj = c / num_rots, r = c - pj * num_rots;
     const RwFrame fr = s_fr[pj];
-    if (fr.row0 < 0) continue;
-    const float cs = cos_tab[r], sn = sin_tab[r];
+    const int row = fr.row0 + r;
+    const float2 t = s_trig[r];
+    pj += dq; r += dr;
+    if (r >= num_rots) { r -= num_rots; ++pj; }
+    if (row < lo || row >= hi) continue;
+    const float cs = t.x, sn = t.y;
     const float offx = cs * fr.xx + sn * fr.yx, offy = cs * fr.xy + sn * fr.yy, offz = cs * fr.xz + sn * fr.yz;
-    const float ux = fr.tn * offx + fr.sux, uy = fr.tn * offy + fr.suy, uz = fr.tn * offz + fr.suz;
-    const float nn = fmaxf(norm3_fused(ux, uy, uz), 1e-7f);
-    const float x = ux / nn, y = uy / nn, z = uz / nn;
-    if (!(y == y) || !(x == x) || !(z == z)) continue;                 // NaN candidate never passes the test
-    const int slot = (fr.row0 + r) / bmm_size - cb;
-    float phi = atan2f(z, x);
-    phi += (phi < 0.0f) ? 6.2831853071795865f : 0.0f;
-    int ci = (int)((1.0f - y) * row_scale), cj = (int)(phi * col_scale);
-    ci = min(max(ci, 0), lut_rows - 1);
-    cj = min(max(cj, 0), lut_cols - 1);
-    const int4 e = lut[ci * lut_cols + cj];
-    const int ids[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int a = 0; a < NAX; ++a) {
+      const float tn = fr.tn[a];
+      const float sg = (tn > 0.0f) ? 1.0f : -1.0f;
+      const float ux = tn * offx + sg * fr.ux, uy = tn * offy + sg * fr.uy, uz = tn * offz + sg * fr.uz;
+      const float nn = fmaxf(norm3_fused(ux, uy, uz), 1e-7f);
+      const float x = ux / nn, y = uy / nn, z = uz / nn;
+      if (!(y == y) || !(x == x) || !(z == z)) continue;               // NaN candidate never passes the test
+      float phi = atan2f(z, x);
+      phi += (phi < 0.0f) ? 6.2831853071795865f : 0.0f;
+      int ci = (int)((1.0f - y) * row_scale), cj = (int)(phi * col_scale);
+      ci = min(max(ci, 0), lut_rows - 1);
+      cj = min(max(cj, 0), lut_cols - 1);
+      const int4 e = lut[ci * lut_cols + cj];
+      const int ids[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
-      for (int lo16 = 0; lo16 < 2; ++lo16) {
-        const int s = lo16 ? (ids[h] >> 16) : (int)(short)(ids[h] & 0xffff);
-        if (s >= 0) {
-          const float4 q = s_sph[s];
-          const float d = fmaf(z, q.z, fmaf(y, q.y, x * q.x));
-          if (d > cos_thr) atomicAdd(&s_acc[slot * S + s], fr.inv_wt);
+      for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int lo16 = 0; lo16 < 2; ++lo16) {
+          const int s = lo16 ? (ids[h] >> 16) : (int)(short)(ids[h] & 0xffff);
+          if (s >= 0) {
+            const float4 q = s_sph[s];
+            const float d = fmaf(z, q.z, fmaf(y, q.y, x * q.x));
+            if (d > cos_thr) atomicAdd(&s_acc[a * S + s], fr.inv_wt);
+          }
         }
       }
     }
   }
   __syncthreads();
-  double* out = partial + blk * 2 * S;
-  for (int i = threadIdx.x; i < 2 * S; i += RW_THREADS) out[i] = s_acc[i];
-  if (threadIdx.x == 0) block_chunk[blk] = cb;
+  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) out[i] = s_acc[i];
 }
 
-// per-chunk float64 sum = sum over the workgroups that touched the chunk, in workgroup order (their chunk ids are
-// non-decreasing), folded into float32 counts chunk by chunk (eval.py:45), then first maximum
-__global__ __launch_bounds__(1024) void rot_bins_fold_kernel(const double* __restrict__ partial,
-                                                             const int32_t* __restrict__ block_chunk, int nblk, int S,
-                                                             float* __restrict__ counts, int32_t* __restrict__ top_idx,
-                                                             float* __restrict__ top_count) {
-  const int b = blockIdx.x;
-  const double* part = partial + (int64_t)b * nblk * 2 * S;
-  const int32_t* bc = block_chunk + (int64_t)b * nblk;
+// float32 counts of one (scene, axis): per chunk, the float64 sum of its sub-block partials in sub-block order, one
+// float32 rounding per chunk (eval.py:45), then first maximum
+__global__ __launch_bounds__(256) void rot_bins_fold_kernel(const double* __restrict__ partial, int nblk,
+                                                            int sub_blocks, int nax, int S, int B,
+                                                            float* __restrict__ counts, int32_t* __restrict__ top_idx,
+                                                            float* __restrict__ top_count) {
+  const int b = blockIdx.x, a = blockIdx.y;
+  const double* part = partial + ((int64_t)b * nblk * nax + a) * S;
+  const int64_t bstride = (int64_t)nax * S;
   float best = -INFINITY;
   int besti = 0x7fffffff;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     float c = 0.0f;
-    double a_cur = 0.0, a_next = 0.0;
-    int cur = -1;
-    for (int i = 0; i < nblk; ++i) {
-      const int cb = bc[i];                       // wave-uniform
-      if (cb < 0) continue;
-      const double v0 = part[((int64_t)i * 2 + 0) * S + s], v1 = part[((int64_t)i * 2 + 1) * S + s];
-      if (cur < 0) cur = cb;
-      while (cur < cb) {                           // close chunk `cur`: one float32 rounding per chunk
-        c = (float)((double)c + a_cur);
-        a_cur = a_next; a_next = 0.0; ++cur;
-      }
-      a_cur += v0; a_next += v1;
+    for (int i0 = 0; i0 < nblk; i0 += sub_blocks) {
+      double acc = 0.0;
+      for (int i = i0; i < i0 + sub_blocks; ++i) acc += part[i * bstride + s];
+      c = (float)((double)c + acc);
     }
-    c = (float)((double)c + a_cur);
-    c = (float)((double)c + a_next);
-    counts[(int64_t)b * S + s] = c;
+    counts[((int64_t)a * B + b) * S + s] = c;
     if (c > best || (c == best && s < besti)) { best = c; besti = s; }
   }
 #pragma unroll
@@ -1339,16 +1351,16 @@ __global__ __launch_bounds__(1024) void rot_bins_fold_kernel(const double* __res
     const int oi = __shfl_xor(besti, off);
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
-  __shared__ float s_b[16];
-  __shared__ int s_i[16];
+  __shared__ float s_b[4];
+  __shared__ int s_i[4];
   if (wave_lane() == 0) { s_b[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
       if (s_b[w] > best || (s_b[w] == best && s_i[w] < besti)) { best = s_b[w]; besti = s_i[w]; }
     if (besti == 0x7fffffff) besti = 0;
-    if (top_idx) top_idx[b] = besti;
-    if (top_count) top_count[b] = best;
+    if (top_idx) top_idx[(int64_t)a * B + b] = besti;
+    if (top_count) top_count[(int64_t)a * B + b] = best;
   }
 }
 
@@ -1390,53 +1402,39 @@ static inline int rb_max_chunks(int max_kept, int num_rots, int bmm_size) {
   return (int)((rows + bmm_size - 1) / bmm_size) + 1;
 }
 
-static inline int rw_ppb(int num_rots, int bmm_size) {
-  int ppb = RW_PPB;
-  if ((int64_t)ppb * num_rots > bmm_size) ppb = bmm_size / num_rots;
-  return ppb < 1 ? 1 : ppb;
+// Decomposition of the lookup-table path: chunks of bmm_size rows, each cut into `sub` workgroups of `rpb` rows
+// (about 160 pairs' worth for throughput-sized batches, 32 for small ones so that a single scene still fills the chip).
+struct RwPlan {
+  int nchunks, sub, rpb, nblk, max_pairs;
+};
+
+static inline RwPlan rw_plan(int B, int max_kept, int num_rots, int bmm_size) {
+  RwPlan pl;
+  const int64_t rows = (int64_t)(max_kept > 0 ? max_kept : 1) * num_rots;
+  pl.nchunks = (int)((rows + bmm_size - 1) / bmm_size);
+  const int64_t target = (int64_t)(B >= 16 ? 160 : 32) * num_rots;
+  pl.sub = (target >= bmm_size) ? 1 : (int)((bmm_size + target - 1) / target);
+  pl.rpb = (bmm_size + pl.sub - 1) / pl.sub;
+  pl.nblk = pl.nchunks * pl.sub;
+  pl.max_pairs = pl.rpb / num_rots + 2;
+  return pl;
 }
 
 extern "C" int64_t cppf_rot_bins_workspace_bytes(int B, int S, int max_kept, int num_rots, int bmm_size) {
   if (B <= 0 || S <= 0 || max_kept < 0 || num_rots <= 0 || bmm_size <= 0) return 0;
   const int64_t dense = align_up((int64_t)B * rb_max_chunks(max_kept, num_rots, bmm_size) * S * 8, 256);
-  const int64_t nblk = (max_kept + rw_ppb(num_rots, bmm_size) - 1) / rw_ppb(num_rots, bmm_size) + 1;
-  const int64_t window = align_up((int64_t)B * nblk * 2 * S * 8, 256) + align_up((int64_t)B * nblk * 4, 256);
+  const RwPlan pl = rw_plan(B, max_kept, num_rots, bmm_size);
+  const int64_t window = align_up((int64_t)B * pl.nblk * 2 * S * 8, 256);
   return dense > window ? dense : window;
 }
 
-extern "C" int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
-                             const int32_t* tup_off, const float* rot, int rot_col, const int32_t* kept_tuple,
-                             const int32_t* kept_count, const double* kept_wt, const int32_t* kept_row0, int max_kept,
-                             int num_rots, const float* cos_tab, const float* sin_tab, const float* sphere, int S,
-                             float cos_thr, int bmm_size, const int16_t* bin_lut, int lut_rows, int lut_cols,
-                             float* counts, int32_t* top_idx, float* top_count, void* workspace,
-                             int64_t workspace_bytes, void* stream) {
-  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && rot && kept_tuple && kept_count && kept_wt && kept_row0);
-  CPPF_CHECK_ARG(cos_tab && sin_tab && sphere && counts);
-  CPPF_CHECK_ARG(rot_col >= 0 && rot_col < 3 && S > 0 && num_rots > 0 && num_rots <= RB_MAX_CAND && bmm_size > 0);
-  CPPF_CHECK_ARG(bin_lut == nullptr || (lut_rows > 0 && lut_cols > 0 && S <= 32767));
-  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size));
-  hipStream_t st = (hipStream_t)stream;
+static int rot_bins_dense_launch(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                                 const int32_t* tup_off, const float* rot, int rot_col, const int32_t* kept_tuple,
+                                 const int32_t* kept_count, const double* kept_wt, const int32_t* kept_row0,
+                                 int max_kept, int num_rots, const float* cos_tab, const float* sin_tab,
+                                 const float* sphere, int S, float cos_thr, int bmm_size, float* counts,
+                                 int32_t* top_idx, float* top_count, void* workspace, hipStream_t st) {
   const int max_chunks = rb_max_chunks(max_kept, num_rots, bmm_size);
-  if (num_rots > bmm_size) {
-    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_rot_bins: bmm_size %d < num_rots %d unsupported", bmm_size, num_rots);
-    return CPPF_EUNSUPPORTED;
-  }
-  const size_t lut_lds = (size_t)S * 16 + (size_t)2 * S * 8;
-  if (bin_lut && lut_lds <= 60000 && max_kept > 0) {
-    const int ppb = rw_ppb(num_rots, bmm_size);
-    const int nblk = (max_kept + ppb - 1) / ppb;
-    double* partial = (double*)workspace;
-    int32_t* block_chunk = (int32_t*)((char*)workspace + align_up((int64_t)B * nblk * 2 * S * 8, 256));
-    hipLaunchKernelGGL(rot_bins_lut_kernel, dim3(nblk, B), dim3(RW_THREADS), lut_lds, st, pts, pt_off, idx, k, tup_off,
-                       rot, rot_col, kept_tuple, kept_count, kept_wt, kept_row0, ppb, num_rots, cos_tab, sin_tab,
-                       sphere, S, cos_thr, (const int4*)bin_lut, lut_rows, lut_cols, bmm_size, partial, block_chunk);
-    CPPF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rot_bins_fold_kernel, dim3(B), dim3(1024), 0, st, partial, block_chunk, nblk, S, counts,
-                       top_idx, top_count);
-    CPPF_LAUNCH_CHECK();
-    return CPPF_OK;
-  }
   double* sums = (double*)workspace;
   CPPF_HIP(hipMemsetAsync(sums, 0, (size_t)B * max_chunks * S * 8, st));
   if (max_kept > 0) {
@@ -1454,6 +1452,82 @@ extern "C" int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, con
                      top_count);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
+}
+
+// nax = 1: counts [B,S], top_* [B];  nax = 2: counts [2,B,S], top_* [2,B] (axis-major)
+static int rot_bins_impl(int nax, int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                         const int32_t* tup_off, const float* rot, int rot_col0, int rot_col1,
+                         const int32_t* kept_tuple, const int32_t* kept_count, const double* kept_wt,
+                         const int32_t* kept_row0, int max_kept, int num_rots, const float* cos_tab,
+                         const float* sin_tab, const float* sphere, int S, float cos_thr, int bmm_size,
+                         const int16_t* bin_lut, int lut_rows, int lut_cols, float* counts, int32_t* top_idx,
+                         float* top_count, void* workspace, int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && rot && kept_tuple && kept_count && kept_wt && kept_row0);
+  CPPF_CHECK_ARG(cos_tab && sin_tab && sphere && counts);
+  CPPF_CHECK_ARG(rot_col0 >= 0 && rot_col0 < 3 && rot_col1 >= 0 && rot_col1 < 3);
+  CPPF_CHECK_ARG(S > 0 && num_rots > 0 && num_rots <= RB_MAX_CAND && bmm_size > 0);
+  CPPF_CHECK_ARG(bin_lut == nullptr || (lut_rows > 0 && lut_cols > 0 && S <= 32767));
+  CPPF_CHECK_ARG((int64_t)max_kept * num_rots < 0x7fffffffLL);
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_rot_bins_workspace_bytes(B, S, max_kept, num_rots, bmm_size));
+  hipStream_t st = (hipStream_t)stream;
+  if (num_rots > bmm_size) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_rot_bins: bmm_size %d < num_rots %d unsupported", bmm_size, num_rots);
+    return CPPF_EUNSUPPORTED;
+  }
+  const RwPlan pl = rw_plan(B, max_kept, num_rots, bmm_size);
+  const size_t lut_lds = (size_t)S * 16 + (size_t)nax * S * 8 + (size_t)num_rots * 8 +
+                         (size_t)pl.max_pairs * (sizeof(RwFrame) + 4);
+  if (bin_lut && lut_lds <= 64000 && max_kept > 0) {
+    double* partial = (double*)workspace;
+    if (nax == 2)
+      hipLaunchKernelGGL(rot_bins_lut_kernel<2>, dim3(pl.nblk, B), dim3(RW_THREADS), lut_lds, st, pts, pt_off, idx, k,
+                         tup_off, rot, rot_col0, rot_col1, kept_tuple, kept_count, kept_wt, kept_row0, pl.rpb, pl.sub,
+                         pl.max_pairs, num_rots, cos_tab, sin_tab, sphere, S, cos_thr, (const int4*)bin_lut, lut_rows,
+                         lut_cols, bmm_size, partial);
+    else
+      hipLaunchKernelGGL(rot_bins_lut_kernel<1>, dim3(pl.nblk, B), dim3(RW_THREADS), lut_lds, st, pts, pt_off, idx, k,
+                         tup_off, rot, rot_col0, rot_col1, kept_tuple, kept_count, kept_wt, kept_row0, pl.rpb, pl.sub,
+                         pl.max_pairs, num_rots, cos_tab, sin_tab, sphere, S, cos_thr, (const int4*)bin_lut, lut_rows,
+                         lut_cols, bmm_size, partial);
+    CPPF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rot_bins_fold_kernel, dim3(B, nax), dim3(256), 0, st, partial, pl.nblk, pl.sub, nax, S, B, counts,
+                       top_idx, top_count);
+    CPPF_LAUNCH_CHECK();
+    return CPPF_OK;
+  }
+  for (int a = 0; a < nax; ++a) {
+    const int rc = rot_bins_dense_launch(B, pts, pt_off, idx, k, tup_off, rot, a ? rot_col1 : rot_col0, kept_tuple,
+                                         kept_count, kept_wt, kept_row0, max_kept, num_rots, cos_tab, sin_tab, sphere, S,
+                                         cos_thr, bmm_size, counts + (int64_t)a * B * S,
+                                         top_idx ? top_idx + (int64_t)a * B : nullptr,
+                                         top_count ? top_count + (int64_t)a * B : nullptr, workspace, st);
+    if (rc != CPPF_OK) return rc;
+  }
+  return CPPF_OK;
+}
+
+extern "C" int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                             const int32_t* tup_off, const float* rot, int rot_col, const int32_t* kept_tuple,
+                             const int32_t* kept_count, const double* kept_wt, const int32_t* kept_row0, int max_kept,
+                             int num_rots, const float* cos_tab, const float* sin_tab, const float* sphere, int S,
+                             float cos_thr, int bmm_size, const int16_t* bin_lut, int lut_rows, int lut_cols,
+                             float* counts, int32_t* top_idx, float* top_count, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  return rot_bins_impl(1, B, pts, pt_off, idx, k, tup_off, rot, rot_col, rot_col, kept_tuple, kept_count, kept_wt,
+                       kept_row0, max_kept, num_rots, cos_tab, sin_tab, sphere, S, cos_thr, bmm_size, bin_lut, lut_rows,
+                       lut_cols, counts, top_idx, top_count, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cppf_rot_bins2(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                              const int32_t* tup_off, const float* rot, int rot_col0, int rot_col1,
+                              const int32_t* kept_tuple, const int32_t* kept_count, const double* kept_wt,
+                              const int32_t* kept_row0, int max_kept, int num_rots, const float* cos_tab,
+                              const float* sin_tab, const float* sphere, int S, float cos_thr, int bmm_size,
+                              const int16_t* bin_lut, int lut_rows, int lut_cols, float* counts, int32_t* top_idx,
+                              float* top_count, void* workspace, int64_t workspace_bytes, void* stream) {
+  return rot_bins_impl(2, B, pts, pt_off, idx, k, tup_off, rot, rot_col0, rot_col1, kept_tuple, kept_count, kept_wt,
+                       kept_row0, max_kept, num_rots, cos_tab, sin_tab, sphere, S, cos_thr, bmm_size, bin_lut, lut_rows,
+                       lut_cols, counts, top_idx, top_count, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -89,7 +89,6 @@ class VotingPipeline:
         self.ws_bv_bytes = _L.cppf_backvote_workspace_bytes(self.Ntot, B)
         self.ws_rot_bytes = _L.cppf_rot_bins_workspace_bytes(B, self.S, self.max_kept, self.R, self.bmm)
         self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
-        self._side, self._ws2 = None, None
 
     # -- stages ---------------------------------------------------------------------------------
     def decode(self, pts, idx, logits, uniforms, prior=None):
@@ -127,25 +126,27 @@ class VotingPipeline:
                    "cppf_backvote_filter")
 
     def rot_bins(self, pts, idx, use_lut=True):
-        """Both rotation votes.  They are independent, so the second one runs on a side stream with its own workspace
-        (fork/join with events; inside a HIP-graph capture this becomes two parallel branches)."""
+        """Both rotation votes (eval.py:277-293; angle columns 0 and 2 of targets_rot) in one pass over the kept pairs."""
         lut = self.lut if use_lut else None
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-            self._ws2 = torch.empty((max(self.ws_rot_bytes, 256),), dtype=torch.uint8, device=self.dev)
-        self._side.wait_stream(cur)
-        for a, col, stream, ws in ((0, 0, cur, self.ws), (1, 2, self._side, self._ws2)):   # eval.py:278,287
-            with torch.cuda.stream(stream):
-                _lib.check(_L.cppf_rot_bins(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
-                                            ops._p(self.tup_off), ops._p(self.rot), col, ops._p(self.kept_tuple),
-                                            ops._p(self.kept_count), ops._p(self.kept_wt), ops._p(self.kept_row0),
-                                            self.max_kept, self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.sphere),
-                                            self.S, C.c_float(self.cos_thr), self.bmm, ops._p(lut), ops.LUT_ROWS,
-                                            ops.LUT_COLS, ops._p(self.counts[a]),
-                                            ops._p(self.top_idx[a]), ops._p(self.top_cnt[a]), ops._p(ws),
-                                            self.ws_rot_bytes, ops._stream()), "cppf_rot_bins")
-        cur.wait_stream(self._side)
+        _lib.check(_L.cppf_rot_bins2(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                     ops._p(self.tup_off), ops._p(self.rot), 0, 2, ops._p(self.kept_tuple),
+                                     ops._p(self.kept_count), ops._p(self.kept_wt), ops._p(self.kept_row0),
+                                     self.max_kept, self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.sphere),
+                                     self.S, C.c_float(self.cos_thr), self.bmm, ops._p(lut), ops.LUT_ROWS,
+                                     ops.LUT_COLS, ops._p(self.counts), ops._p(self.top_idx), ops._p(self.top_cnt),
+                                     ops._p(self.ws), self.ws_rot_bytes, ops._stream()), "cppf_rot_bins2")
+
+    def rot_bins_single(self, pts, idx, axis, use_lut=True):
+        """One rotation vote through the single-axis entry point (axis 0 = up, 1 = right); same results."""
+        lut = self.lut if use_lut else None
+        _lib.check(_L.cppf_rot_bins(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k,
+                                    ops._p(self.tup_off), ops._p(self.rot), (0, 2)[axis], ops._p(self.kept_tuple),
+                                    ops._p(self.kept_count), ops._p(self.kept_wt), ops._p(self.kept_row0),
+                                    self.max_kept, self.R, ops._p(self.cs), ops._p(self.sn), ops._p(self.sphere),
+                                    self.S, C.c_float(self.cos_thr), self.bmm, ops._p(lut), ops.LUT_ROWS,
+                                    ops.LUT_COLS, ops._p(self.counts[axis]), ops._p(self.top_idx[axis]),
+                                    ops._p(self.top_cnt[axis]), ops._p(self.ws), self.ws_rot_bytes, ops._stream()),
+                   "cppf_rot_bins")
 
     def kept_rows(self):
         """Global tuple rows of the pairs that survived the back-vote filter, int64 [B * max_kept], without a host sync:

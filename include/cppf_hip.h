@@ -36,7 +36,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 2
+#define CPPF_ABI_VERSION 3
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -219,6 +219,18 @@ int cppf_rot_bins(int B, const float* pts, const int32_t* pt_off, const int32_t*
                   const int16_t* bin_lut, int lut_rows, int lut_cols,
                   float* counts, int32_t* top_idx, float* top_count,
                   void* workspace, int64_t workspace_bytes, void* stream);
+/* Both rotation votes of eval.py:277-293 in one pass over the kept pairs (they share the pair frames and differ
+ * only in the angle column: rot_col0 = 0 for the up vote, rot_col1 = 2 for the "right" vote).  Outputs are
+ * axis-major: counts float32[2,B,S], top_idx int32[2,B], top_count float32[2,B]; per-axis results are identical to
+ * two cppf_rot_bins calls.  Same workspace size. */
+int cppf_rot_bins2(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                   const int32_t* tup_off, const float* rot, int rot_col0, int rot_col1,
+                   const int32_t* kept_tuple, const int32_t* kept_count, const double* kept_wt,
+                   const int32_t* kept_row0, int max_kept, int num_rots, const float* cos_tab, const float* sin_tab,
+                   const float* sphere, int S, float cos_thr, int bmm_size,
+                   const int16_t* bin_lut, int lut_rows, int lut_cols,
+                   float* counts, int32_t* top_idx, float* top_count,
+                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Stand-alone halves with the reference's own signatures (used by the drop-in wrappers):
  * vote_rotation -> up float32[n_valid, num_rots, 3] (valid pairs compacted in order), valid uint8[T];
