@@ -45,7 +45,9 @@
 #ifndef VC_QUANTUM
 #define VC_QUANTUM 4
 #endif
-#define VC_ARC_MARGIN 0.25f
+#ifndef VC_ARC_MARGIN
+#define VC_ARC_MARGIN 0.02f
+#endif
 
 struct SlabBest {
   int64_t idx;
@@ -154,20 +156,24 @@ __device__ __forceinline__ ArcSet slab_arcs(float cx, float invA, float phi, flo
   const float amin = acosf(fminf(cu, 1.0f)) * kappa;
   const float amax = acosf(fmaxf(cl, -1.0f)) * kappa;
   const float half = 0.5f * (float)num_rots;
-  const bool near_merge = amin <= VC_ARC_MARGIN + 1.0f;
-  const bool far_merge = (half - amax) <= VC_ARC_MARGIN + 1.0f;
+  // |theta - phi| in [amin, amax] (rotation-index units): the integer rotations inside each arc, rounded INWARD --
+  // everything that makes the bounds uncertain (rounding of the vote's x, of A, phi, acosf, the table's angles) is
+  // covered by `slop`, the 1e-6 in cosine space and VC_ARC_MARGIN, so no whole extra rotation per arc end is needed.
+  // The two arcs are merged where fewer than one rotation separates them (they would otherwise share an index).
+  const bool near_merge = amin <= 0.5f;
+  const bool far_merge = (half - amax) <= 0.5f;
   if (near_merge && far_merge) { o.n0 = num_rots; return o; }
   int b0;
   if (near_merge) {
-    o.a0 = (int)floorf(phi - amax - VC_ARC_MARGIN); b0 = (int)ceilf(phi + amax + VC_ARC_MARGIN);
+    o.a0 = (int)ceilf(phi - amax - VC_ARC_MARGIN); b0 = (int)floorf(phi + amax + VC_ARC_MARGIN);
   } else if (far_merge) {
-    o.a0 = (int)floorf(phi + amin - VC_ARC_MARGIN); b0 = (int)ceilf(phi + (float)num_rots - amin + VC_ARC_MARGIN);
+    o.a0 = (int)ceilf(phi + amin - VC_ARC_MARGIN); b0 = (int)floorf(phi + (float)num_rots - amin + VC_ARC_MARGIN);
   } else {
-    o.a0 = (int)floorf(phi + amin - VC_ARC_MARGIN); b0 = (int)ceilf(phi + amax + VC_ARC_MARGIN);
-    o.a1 = (int)floorf(phi - amax - VC_ARC_MARGIN);
-    o.n1 = (int)ceilf(phi - amin + VC_ARC_MARGIN) - o.a1 + 1;
+    o.a0 = (int)ceilf(phi + amin - VC_ARC_MARGIN); b0 = (int)floorf(phi + amax + VC_ARC_MARGIN);
+    o.a1 = (int)ceilf(phi - amax - VC_ARC_MARGIN);
+    o.n1 = max((int)floorf(phi - amin + VC_ARC_MARGIN) - o.a1 + 1, 0);
   }
-  o.n0 = b0 - o.a0 + 1;
+  o.n0 = max(b0 - o.a0 + 1, 0);
   if (o.n0 >= num_rots) { o.a0 = 0; o.n0 = num_rots; o.n1 = 0; }
   return o;
 }

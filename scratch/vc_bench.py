@@ -26,7 +26,8 @@ pipe.vote_center(pts, idx)
 pipe.backvote(pts, idx)
 pipe.rot_bins(pts, idx)
 torch.cuda.synchronize()
-fn = {"vote_center": lambda: pipe.vote_center(pts, idx), "backvote": lambda: pipe.backvote(pts, idx),
+pipe.vote_center(pts, idx, phase=1)
+fn = {"vote_center": lambda: pipe.vote_center(pts, idx), "vote_only": lambda: pipe.vote_center(pts, idx, phase=2), "backvote": lambda: pipe.backvote(pts, idx),
       "rot_bins": lambda: pipe.rot_bins(pts, idx), "decode": lambda: pipe.decode(pts, idx, logits, u)}[stage]
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,7 +38,7 @@ e1.record(); torch.cuda.synchronize()
 res = pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8)
 print(stage, "mode", mode, "B", B, "ms/launch %.3f" % (e0.elapsed_time(e1) / reps), "mean cells", res[:, 6].mean(), "argmax0", int(pipe.argmax[0]))
 
-if stage == "vote_center" and (mode & 0xff) in (0, 1):
+if stage in ("vote_center", "vote_only") and (mode & 0xff) in (0, 1) and os.environ.get("DIAG", "0") == "1":
     import ctypes
     smp = max((pipe.cells_cap + 36864 - 1) // 36864, 32)
     raw = pipe.ws[:B * smp * 16].cpu().numpy().view(np.uint32).reshape(B, smp, 4)
