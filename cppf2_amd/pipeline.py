@@ -88,11 +88,13 @@ class VotingPipeline:
         self.ws_vote_bytes = _L.cppf_vote_center_workspace_bytes(B, self.cells_cap, self.Ttot)
         self.ws_bv_bytes = _L.cppf_backvote_workspace_bytes(self.Ntot, B)
         self.ws_rot_bytes = _L.cppf_rot_bins_workspace_bytes(B, self.S, self.max_kept, self.R, self.bmm)
+        self.nb = 32
         self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
 
     # -- stages ---------------------------------------------------------------------------------
     def decode(self, pts, idx, logits, uniforms, prior=None):
         """prior (optional, same shape as logits) is added to the logits inside the kernel (== logits + prior)."""
+        self.nb = int(logits.shape[-1])
         _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), ops._p(prior), logits.shape[-1], ops._p(uniforms), ops._p(pts),
                                        ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
                                        self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
@@ -166,6 +168,34 @@ class VotingPipeline:
             out = torch.zeros((self.Ttot, values.shape[1]), dtype=values.dtype, device=self.dev)
         out[rows] = values
         return out
+
+    def pose_tensors(self):
+        """Views into the device result records: t float64 [B,3], R float64 [B,3,3], scale float32 [B,3], flags int32 [B]."""
+        r64 = self.results.view(torch.float64)                       # 160 B = 20 doubles per record
+        return (r64[:, 1:4], r64[:, 4:13].reshape(self.B, 3, 3), self.results[:, 104:116].view(torch.float32),
+                self.results[:, 140:144].view(torch.int32).reshape(self.B))
+
+    def alignment_loss(self, pts, idx, scale_norm, y_only):
+        """eval.py:358-363 for every scene, on the device (no host round trip): mean over the kept pairs of the clipped
+        L1 distance between their canonicalised points, (pc - T_est) @ R_est / pred_scale_norm in float64, and the
+        decoded (un-scaled) coordinates bins / 31 - 0.5; the y coordinate only for the up-symmetric categories.
+        scale_norm: float64 [B] (the DINO pass' scale norm, eval.py:308-310).  Returns float64 [B] (NaN if nothing kept)."""
+        B, mk = self.B, self.max_kept
+        t, R, _, _ = self.pose_tensors()
+        rows = self.kept_rows().reshape(B, mk)                                          # global tuple rows, padded
+        valid = torch.arange(mk, device=self.dev)[None, :] < self.kept_count[:, None]
+        base = self.pt_off[:-1].long()
+        pi = idx[rows.reshape(-1)][:, :2].long().reshape(B, mk, 2) + base[:, None, None]
+        p = pts[pi.reshape(-1)].reshape(B, mk, 2, 3).double()
+        canon = torch.einsum("bmpi,bij->bmpj", p - t[:, None, None, :], R) / scale_norm.double()[:, None, None, None]
+        nb = float(self.nb - 1)
+        pred = (self.bins[rows.reshape(-1)].to(torch.float32) / nb - 0.5).reshape(B, mk, 2, 3)   # eval.py:230
+        loss = (canon - pred.double()).abs()
+        if y_only:
+            loss = loss[..., 1]
+        loss = loss.clamp(0.0, 0.1).reshape(B, mk, -1)
+        w = valid[:, :, None].to(torch.float64)
+        return (loss * w).sum((1, 2)) / (w.sum((1, 2)) * loss.shape[2])
 
     def assemble(self, pred_scales=None):
         _lib.check(_L.cppf_assemble_pose(self.B, ops._p(self.sphere), ops._p(self.top_idx[0]), ops._p(self.top_cnt[0]),

@@ -2,31 +2,41 @@
 """Entry point with the reference's eval.py flag surface (eval.py:54-65):
 
     python eval.py --angle_tol=1. --imp_wt_margin=0.01 --backproj_ratio=.1 --num_pairs=50000 --num_rots=180 \
-                   --opt=False --geo_branch=True --visual_branch=True [--data=synthetic --num_scenes=16 --category=bottle]
+                   --opt=False --geo_branch=True --visual_branch=True \
+                   [--data=synthetic --num_scenes=16 --categories=bottle,mug | --category=bottle] [--ckpt_dir=ckpts]
 
-The per-instance loop of the reference (eval.py:153-372: tuple sampling -> SHOT -> two models -> decode -> centre
-vote -> back-vote filter -> rotation votes -> pose -> ensemble selection) runs here batched over all instances on
-the GPU through cppf2_amd.  What the image cannot provide is stated, not faked:
+Like the reference (eval.py:84-101) it sets up one DINO model + one SHOT model + one cfg per category of the whitelist
+(all six by default) and evaluates every object instance with both models, keeping the pose with the smaller
+alignment loss (eval.py:219-372).  The per-instance loop of the reference (tuple sampling -> SHOT -> two models ->
+decode -> centre vote -> back-vote filter -> rotation votes -> pose -> ensemble selection) runs here batched over all
+instances of a category on the GPU through cppf2_amd, with no host round trip before the final 160-byte records.
+What the image cannot provide is stated, not faked:
   * NOCS REAL275 images / SAR-Net masks / last.ckpt / DINOv2 weights are absent -> `--data=synthetic` (default)
-    evaluates seeded synthetic scenes (cppf2_amd.synth) with random-init or `--ckpt_*` weights plus a teacher
-    prior; `--data=depth` evaluates one depth+mask PNG pair (example_data layout) through backproject/downsample.
+    evaluates seeded synthetic instances (cppf2_amd.synth) with random-init weights (or the checkpoints found under
+    `--ckpt_dir`, laid out like the reference's: <ckpt_dir>/{dino,shot}/<cat>-num_more-3/{.hydra/config.yaml,
+    lightning_logs/version_0/checkpoints/last.ckpt}, eval.py:91-99) plus a teacher prior; `--data=depth` evaluates
+    one depth+mask PNG pair (example_data layout) through backproject/downsample.
   * the Adam/lietorch refinement (eval.py:319-355, `opt`) runs as one HIP kernel per batch
     (cppf_refine_pose); lietorch is absent, so its semantics are restated from the published algorithm and pinned
     only by the oracle (parity unpinned).
 Swapped flag names are kept: geo_branch gates model 0 (DINO), visual_branch gates model 1 (SHOT) (eval.py:367).
 """
 import json
+import os
 import sys
 
 import numpy as np
 import torch
 
 from cppf2_amd import geometry, ops, shot, synth
-from cppf2_amd.config import load_config
+from cppf2_amd.config import load_checkpoint_config, load_config
 from cppf2_amd.models import BeyondCPPFDino, BeyondCPPFShot, load_reference_checkpoint
 from cppf2_amd.pipeline import VotingPipeline
 
 id2category = {1: "bottle", 2: "bowl", 3: "camera", 4: "can", 5: "laptop", 6: "mug"}     # dataset.py:29-37
+category2id = {v: k for k, v in id2category.items()}
+WHITELIST = ["can", "bowl", "laptop", "bottle", "camera", "mug"]                          # eval.py:78
+UP_SYM = ("can", "bottle", "bowl")                                                        # eval.py:333,362
 
 
 def _flag(v):
@@ -40,80 +50,75 @@ def _flag(v):
     return v
 
 
-def alignment_loss(pc, T_est, R_est, scale_norm, idx_kept, pred_pairs_kept, up_sym):
-    """eval.py:358-363: clipped L1 between canonicalised points of the kept pairs and their predicted coordinates."""
-    pc_canon = (pc - T_est) @ R_est / scale_norm
-    loss = np.abs(pc_canon[idx_kept[:, :2]] - pred_pairs_kept)
-    if up_sym:
-        loss = loss[..., 1]
-    return float(np.clip(loss, 0, 0.1).mean())
+def load_category(cat_name, ckpt_dir=None, ckpt_shot=None, ckpt_dino=None, config_dir="config", device=None):
+    """eval.py:87-101 for one category: (cfg, dino_model, shot_model).  With a checkpoint directory each model is built
+    from the cfg saved next to its weights (`.hydra/config.yaml`) and the loop keeps the SHOT run's cfg (the last
+    assignment, eval.py:101); otherwise config/ + category group and random-init weights."""
+    dev = device or ops._dev()
+    cfg = load_config(config_dir, "config", ["category=%s" % cat_name])
+    cfgs = {"dino": cfg, "shot": cfg}
+    weights = {"dino": ckpt_dino, "shot": ckpt_shot}
+    if ckpt_dir:
+        for name in ("dino", "shot"):
+            root = os.path.join(ckpt_dir, name, "%s-num_more-3" % cat_name)               # eval.py:91,96
+            hy = os.path.join(root, ".hydra", "config.yaml")
+            if os.path.exists(hy):
+                cfgs[name] = load_checkpoint_config(hy)                                    # eval.py:92,97
+            ck = os.path.join(root, "lightning_logs", "version_0", "checkpoints", "last.ckpt")
+            if weights[name] is None and os.path.exists(ck):
+                weights[name] = ck
+    dino_model = BeyondCPPFDino(cfgs["dino"]).to(dev).eval()
+    shot_model = BeyondCPPFShot(cfgs["shot"]).to(dev).eval()
+    if weights["dino"]:
+        load_reference_checkpoint(dino_model, weights["dino"])
+    if weights["shot"]:
+        load_reference_checkpoint(shot_model, weights["shot"])
+    return cfgs["shot"], dino_model, shot_model
+
+
+def needed_cells(pc, res):
+    """Cells of the vote grid of one instance (train_dino.py:173-175: int32 truncation of the float32 extent / res, + 1)."""
+    ext = (pc.max(0) - pc.min(0)).astype(np.float32) / np.float32(res)
+    return int(np.prod(ext.astype(np.int64) + 1))
 
 
 @torch.no_grad()
-def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, num_rots=180, opt=True, debug=False,
-         use_grounded_sam=False, geo_branch=True, visual_branch=True, data="synthetic", num_scenes=8, num_points=4096,
-         category="bottle", seed=0, ckpt_shot=None, ckpt_dino=None, depth=None, mask=None, intrinsics=None,
-         depth_scale=1000.0, out=None, out_pkl=None):
-    cfg = load_config("config", "config", ["category=%s" % category])
+def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_pairs, num_rots, angle_tol=1.,
+                 imp_wt_margin=0.01, backproj_ratio=.1, opt=False, geo_branch=True, visual_branch=True, up_sym=False,
+                 priors=None, keep=False):
+    """eval.py:207-372 for a batch of instances of one category.  pcs: list of float32 [N_b,3]; descs: list of float32
+    [N_b,1024] (DINOv2 features at the points: inputs to the path); priors: optional callable(idx_global, base) -> logit
+    prior [T,6,nb] added to both models' logits.  Returns dict(records=[2 x structured array], losses float64 [2,B],
+    pick int [B], scale, scale_norm, idx, pipe, ...)."""
     dev = ops._dev()
-    up_sym = bool(cfg.get("up_sym", False))
+    B = len(pcs)
+    Ns = [int(p.shape[0]) for p in pcs]
     k = cfg.num_more + 2
-    torch.manual_seed(seed)
-    shot_model = BeyondCPPFShot(cfg).to(dev).eval()
-    dino_model = BeyondCPPFDino(cfg).to(dev).eval()
-    if ckpt_shot:
-        load_reference_checkpoint(shot_model, ckpt_shot)
-    if ckpt_dino:
-        load_reference_checkpoint(dino_model, ckpt_dino)
-
-    # ---- instances ("scenes") ---------------------------------------------------------------
-    if data == "depth":
-        from PIL import Image
-        d = np.array(Image.open(depth)).astype(np.float64) / float(depth_scale)
-        m = np.array(Image.open(mask))
-        m = (m[..., 0] if m.ndim == 3 else m) > 0
-        K = np.array(intrinsics if intrinsics is not None else
-                     [[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float64).reshape(3, 3)
-        pc, _ = ops.backproject(d, K, m, return_device=True)               # eval.py:185-189 (flip + f32 cast folded in)
-        pc = pc[ops.downsample(pc, cfg.res, seed, return_device=True)].cpu().numpy()   # eval.py:192
-        if pc.shape[0] > 50000:
-            pc = pc[np.random.RandomState(seed).randint(pc.shape[0], size=50000)]
-        scenes = [dict(pc=pc, pc_canon=None, R=None, t=None)]
-    else:
-        scenes = [synth.make_scene(seed, s, num_points) for s in range(num_scenes)]
-    B = len(scenes)
-    Ns = [s["pc"].shape[0] for s in scenes]
-    for s in scenes:
-        ext = (s["pc"].max(0) - s["pc"].min(0)).max() / cfg.res
-        assert ext <= 1000, "instance larger than 1000 cells is skipped by the reference (eval.py:200)"
-    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scenes])).to(dev)
+    for p in pcs:                                                                          # eval.py:200
+        if ((p.max(0) - p.min(0)).max() / cfg.res) > 1000:
+            raise ValueError("instance larger than 1000 cells: the reference skips it (eval.py:200); drop it from the batch")
+    cap = max(1 << 18, max(needed_cells(p, cfg.res) for p in pcs))
+    cap = 1 << int(np.ceil(np.log2(cap)))
+    if cap * B > (1 << 33):
+        raise ValueError("vote grids of %d cells x %d instances do not fit one batch; evaluate fewer instances per call" % (cap, B))
+    pts = torch.from_numpy(np.concatenate(pcs)).to(dev)
     pipe = VotingPipeline(Ns, [num_pairs] * B, k=k, res=cfg.res, num_rots=num_rots, angle_tol=angle_tol,
                           backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, cfg_up=cfg.up,
-                          cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=1 << 24 if data == "depth" else 1 << 21)
-
+                          cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
     # eval.py:207 -- one tuple table per instance, shared by both models
-    idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in enumerate(Ns)])
+    idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in zip(scene_ids, Ns)])
     # eval.py:210-216
     shot_feat, normal = shot.compute_device(pts, pipe.pt_off, cfg.res * 10, cfg.res * 10)
     shot_feat = torch.nan_to_num_(shot_feat, nan=0.0)
     normal = torch.nan_to_num_(normal, nan=0.0)
-    # DINOv2 features are inputs to the path (weights absent): seeded unit vectors stand in for them
-    g = torch.Generator(device="cpu").manual_seed(seed + 1)
-    desc = torch.nn.functional.normalize(torch.randn((pts.shape[0], 1024), generator=g), dim=-1).to(dev)
-
+    desc = torch.from_numpy(np.concatenate(descs)).to(dev)
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
-    prior = None
-    if scenes[0]["pc_canon"] is not None:
-        canon = torch.from_numpy(np.concatenate([s["pc_canon"] for s in scenes])).to(dev)
-        coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(-1, 6)
-        pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
-        kb = torch.arange(32, device=dev, dtype=torch.float32)
-        prior = (-0.5 * ((kb[None, None, :] - pos[..., None]) / 0.6) ** 2)
+    prior = priors(idx, base) if priors is not None else None
 
     feat_shot = shot_model.encode_points(shot_feat)
-    results, losses = [], []
-    pred_scale = pred_scale_norm = None
-    for model_idx in (0, 1):                                                   # eval.py:219
+    records, losses, kept = [], [], []
+    scale = scale_norm = None
+    for model_idx in (0, 1):                                                               # eval.py:219
         if model_idx == 0:
             # batched forward: indices are scene-local, tables are concatenated -> add the scene base
             x = dino_model.prepare_tuple_inputs(pts, desc, idx + base[:, None].to(torch.int32))
@@ -123,75 +128,160 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         else:
             x = ops.encode_tuples_shot(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off)
             pred_cls, pred_scales = shot_model.heads(x)
+        raw_cls = pred_cls
         if prior is not None:
             pred_cls = pred_cls + prior
-        u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in range(B)])
+        u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
         pipe.vote(pts, idx, pred_cls.contiguous(), u, pred_scales.contiguous())
         if opt:
-            pipe.refine(pts, idx, up_sym)                                      # eval.py:319-355
-        rec = pipe.results_to_numpy()
-        if model_idx == 0:                                                     # eval.py:308-310
-            pred_scale = rec["scale"].astype(np.float64)
-            pred_scale_norm = np.linalg.norm(pred_scale, axis=-1)
-        mask = pipe.mask.cpu().numpy().astype(bool)
-        pp = ((pipe.bins.cpu().numpy().astype(np.float32) / np.float32(31)) - np.float32(0.5)).reshape(-1, 2, 3)
-        idx_np = idx.cpu().numpy()
-        ls = []
-        for b in range(B):
-            sl = slice(b * num_pairs, (b + 1) * num_pairs)
-            mk = mask[sl]
-            ls.append(alignment_loss(scenes[b]["pc"].astype(np.float64), rec["t"][b], rec["R"][b],
-                                     pred_scale_norm[b] if pred_scale_norm[b] > 0 else 1.0,
-                                     idx_np[sl][mk], pp[sl][mk], up_sym))
-        results.append(rec)
-        losses.append(ls)
+            pipe.refine(pts, idx, up_sym)                                                  # eval.py:319-355
+        rec = pipe.results_to_numpy()                                                      # the 160-byte records
+        bad = np.nonzero(rec["flags"] & 6)[0]
+        if bad.size:
+            raise RuntimeError("instances %s were not voted (flags %s: grid above cells_cap / int32)" %
+                               (bad.tolist(), rec["flags"][bad].tolist()))
+        if model_idx == 0:                                                                 # eval.py:308-310
+            scale = rec["scale"].copy()                                                    # float32 [B,3]
+            scale_norm = np.array([np.linalg.norm(s_) for s_ in scale], dtype=np.float32)  # np.linalg.norm per instance
+            sn = torch.from_numpy(np.where(scale_norm > 0, scale_norm, 1).astype(np.float64)).to(dev)
+        losses.append(pipe.alignment_loss(pts, idx, sn, up_sym))                           # eval.py:358-363, on the device
+        records.append(rec)
+        if keep:
+            kept.append(dict(bins=pipe.bins.cpu().numpy(), mask=pipe.mask.cpu().numpy().astype(bool),
+                             pred_cls=pred_cls.cpu().numpy(), raw_cls=raw_cls.cpu().numpy(), pred_scales=pred_scales.cpu().numpy(), u=u.cpu().numpy(),
+                             counts=pipe.counts.cpu().numpy()))
+    losses = torch.stack(losses).cpu().numpy()                                             # [2,B] float64
+    # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first ----------------------
+    pick = np.full((B,), -1, dtype=np.int64)
+    best = np.full((B,), np.inf)
+    for model_idx in (0, 1):
+        enabled = (geo_branch and model_idx == 0) or (visual_branch and model_idx == 1)
+        take = (losses[model_idx] < best) & enabled
+        best = np.where(take, losses[model_idx], best)
+        pick = np.where(take, model_idx, pick)
+    out = dict(records=records, losses=losses, pick=pick, best=best, scale=scale.astype(np.float64),
+               scale_norm=scale_norm.astype(np.float64), idx=idx, pipe=pipe, pts=pts)
+    if keep:
+        out["kept"] = kept
+        out["shot_feat"], out["normal"] = shot_feat.cpu().numpy(), normal.cpu().numpy()
+    return out
 
-    # ---- ensemble selection (eval.py:367-372) -------------------------------------------------
-    summary = []
-    for b in range(B):
-        best_loss, pick = np.inf, None
-        for model_idx in (0, 1):
-            enabled = (geo_branch and model_idx == 0) or (visual_branch and model_idx == 1)
-            if losses[model_idx][b] < best_loss and enabled:
-                best_loss, pick = losses[model_idx][b], model_idx
-        if pick is None:
-            continue
-        r = results[pick][b]
-        RT = np.eye(4)
-        RT[:3, :3] = r["R"] * pred_scale_norm[b]
-        RT[:3, 3] = r["t"]
-        item = dict(scene=b, model=["dino", "shot"][pick], loss=best_loss, pred_RT=RT.tolist(),
-                    pred_scale=(pred_scale[b] / pred_scale_norm[b]).tolist() if pred_scale_norm[b] > 0 else None)
-        if scenes[b]["R"] is not None:
-            item["tr_err_cm"] = float(np.linalg.norm(r["t"] - scenes[b]["t"]) * 100)
-            item["rot_err_deg"] = geometry.rot_err_deg(r["R"], scenes[b]["R"], up_sym)
-        summary.append(item)
-    report = dict(category=category, instances=B, opt_refinement="100 Adam steps (cppf_refine_pose)" if opt else "off",
-                  results=summary)
-    if summary and "rot_err_deg" in summary[0]:
-        ok = [s["rot_err_deg"] < 5 and s["tr_err_cm"] < 5 for s in summary]
-        report["acc_5deg_5cm"] = float(np.mean(ok))
-    # the reference's per-image result record (eval.py:143-147, 370-372, 399): pred_RTs [n,4,4] (rotation scaled by the
-    # scale norm), pred_scales [n,3] (normalised); identity / ones for instances no enabled branch produced
+
+def _teacher_prior(canon, dev):
+    canon = torch.from_numpy(canon).to(dev)
+    kb = torch.arange(32, device=dev, dtype=torch.float32)
+
+    def prior(idx, base):
+        coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(-1, 6)
+        pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
+        return -0.5 * ((kb[None, None, :] - pos[..., None]) / 0.6) ** 2
+    return prior
+
+
+def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, num_rots=180, opt=True, debug=False,
+         use_grounded_sam=False, geo_branch=True, visual_branch=True, data="synthetic", num_scenes=8, num_points=4096,
+         category=None, categories=None, seed=0, ckpt_dir=None, ckpt_shot=None, ckpt_dino=None, depth=None, mask=None,
+         intrinsics=None, depth_scale=1000.0, out=None, out_pkl=None):
+    if categories is None:
+        if category:
+            categories = [category]
+        elif data == "depth":
+            categories = ["bottle"]                       # a single depth + mask pair is one instance of one category
+        else:
+            categories = [id2category[i] for i in range(1, 7)]                             # eval.py:87-90
+    elif isinstance(categories, str):
+        categories = [c for c in categories.replace(" ", "").split(",") if c]
+    categories = [c for c in categories if c in WHITELIST]
+    dev = ops._dev()
+    torch.manual_seed(seed)
+    # eval.py:84-101: models and cfgs of every category up front
+    setups = {c: load_category(c, ckpt_dir, ckpt_shot, ckpt_dino, device=dev) for c in categories}
+
     from cppf2_amd import metrics
-    cls_id = int(cfg.get("category", 0))
-    pred_RTs, pred_scales = np.stack([np.eye(4) for _ in range(B)]), np.ones((B, 3))
-    for item in summary:
-        pred_RTs[item["scene"]] = np.array(item["pred_RT"])
-        if item["pred_scale"] is not None:
-            pred_scales[item["scene"]] = np.array(item["pred_scale"])
+    summary, all_cls, all_RT, all_scale, all_gt = [], [], [], [], []
+    inst = 0
+    for ci, cat in enumerate(categories):
+        cfg, dino_model, shot_model = setups[cat]
+        up_sym = cat in UP_SYM
+        # ---- instances ---------------------------------------------------------------------------
+        if data == "depth":
+            from PIL import Image
+            d = np.array(Image.open(depth)).astype(np.float64) / float(depth_scale)
+            m = np.array(Image.open(mask))
+            m = (m[..., 0] if m.ndim == 3 else m) > 0
+            K = np.array(intrinsics if intrinsics is not None else
+                         [[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float64).reshape(3, 3)
+            pc, _ = ops.backproject(d, K, m, return_device=True)               # eval.py:185-189 (flip + f32 cast folded in)
+            pc = pc[ops.downsample(pc, cfg.res, seed, return_device=True)].cpu().numpy()   # eval.py:192
+            if pc.shape[0] > 50000:
+                pc = pc[np.random.RandomState(seed).randint(pc.shape[0], size=50000)]
+            scenes = [dict(pc=pc, pc_canon=None, R=None, t=None)]
+        else:
+            scenes = [synth.make_scene(seed, inst + s, num_points) for s in range(num_scenes)]
+        scenes = [s for s in scenes if ((s["pc"].max(0) - s["pc"].min(0)).max() / cfg.res) <= 1000]     # eval.py:200
+        B = len(scenes)
+        if B == 0:
+            continue
+        scene_ids = list(range(inst, inst + B))
+        # DINOv2 features are inputs to the path (weights absent): seeded unit vectors stand in for them
+        g = torch.Generator(device="cpu").manual_seed(seed + 1 + ci)
+        descs = [torch.nn.functional.normalize(torch.randn((s["pc"].shape[0], 1024), generator=g), dim=-1).numpy()
+                 for s in scenes]
+        priors = None
+        if scenes[0]["pc_canon"] is not None:
+            priors = _teacher_prior(np.concatenate([s["pc_canon"] for s in scenes]), dev)
+        r = run_ensemble(cfg, dino_model, shot_model, [s["pc"] for s in scenes], descs, seed, scene_ids, num_pairs,
+                         num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch, visual_branch,
+                         up_sym, priors)
+        cls_id = category2id[cat]
+        for b in range(B):
+            RT, sc = np.eye(4), np.ones(3)                                      # eval.py:143-144 defaults
+            item = dict(scene=inst + b, category=cat, model=None)
+            if r["pick"][b] >= 0:                                               # eval.py:367-372
+                rec = r["records"][r["pick"][b]][b]
+                RT[:3, :3] = rec["R"] * r["scale_norm"][b]
+                RT[:3, 3] = rec["t"]
+                if r["scale_norm"][b] > 0:
+                    sc = r["scale"][b] / r["scale_norm"][b]
+                item.update(model=["dino", "shot"][r["pick"][b]], loss=float(r["best"][b]),
+                            losses=[float(r["losses"][0][b]), float(r["losses"][1][b])], pred_RT=RT.tolist(),
+                            pred_scale=sc.tolist())
+                if scenes[b]["R"] is not None:
+                    item["tr_err_cm"] = float(np.linalg.norm(rec["t"] - scenes[b]["t"]) * 100)
+                    item["rot_err_deg"] = geometry.rot_err_deg(rec["R"], scenes[b]["R"], up_sym)
+            summary.append(item)
+            all_cls.append(cls_id); all_RT.append(RT); all_scale.append(sc)
+            if scenes[b]["R"] is not None:                  # synthetic instances carry their pose: unit-scale ground truth
+                gt = np.eye(4)
+                gt[:3, :3], gt[:3, 3] = scenes[b]["R"], scenes[b]["t"]
+                all_gt.append(gt)
+        inst += B
+
+    report = dict(categories=categories, instances=len(summary),
+                  opt_refinement="100 Adam steps (cppf_refine_pose)" if opt else "off", results=summary)
+    if len(categories) == 1:
+        report["category"] = categories[0]
+    scored = [s for s in summary if "rot_err_deg" in s]
+    if scored:
+        report["acc_5deg_5cm"] = float(np.mean([s["rot_err_deg"] < 5 and s["tr_err_cm"] < 5 for s in scored]))
+        report["acc_5deg_5cm_per_category"] = {
+            c: float(np.mean([s["rot_err_deg"] < 5 and s["tr_err_cm"] < 5 for s in scored if s["category"] == c]))
+            for c in categories if any(s["category"] == c for s in scored)}
+    # the reference's per-image result record (eval.py:143-147, 370-372, 399): pred_RTs [n,4,4] (rotation scaled by the
+    # scale norm), pred_scales [n,3] (normalised); all instances of the run form one record, like those of one image
+    n = len(summary)
     gt = {}
-    if scenes[0]["R"] is not None:                      # synthetic scenes carry their pose: unit-scale ground truth
-        gt_RTs = np.stack([np.eye(4) for _ in range(B)])
-        for b_, sc in enumerate(scenes):
-            gt_RTs[b_, :3, :3], gt_RTs[b_, :3, 3] = sc["R"], sc["t"]
-        gt = dict(gt_class_ids=np.full((B,), cls_id), gt_RTs=gt_RTs, gt_scales=np.ones((B, 3)))
-    # all instances of the run form one record, like the instances of one image in the reference
-    record = metrics.make_result_record(np.full((B,), cls_id), pred_RTs, pred_scales, None, **gt)
-    if gt and 0 < cls_id < len(metrics.SYNSET_NAMES):
+    if n and len(all_gt) == n:
+        gt = dict(gt_class_ids=np.array(all_cls), gt_RTs=np.stack(all_gt), gt_scales=np.ones((n, 3)))
+    record = metrics.make_result_record(np.array(all_cls, dtype=np.int64), np.stack(all_RT) if n else np.zeros((0, 4, 4)),
+                                        np.stack(all_scale) if n else np.zeros((0, 3)), None, **gt)
+    if gt:
         aps = metrics.pose_mAP([record])                # eval.py:400-410 (degree / cm part)
-        report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): float(aps[cls_id, i_, j_])
+        report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): float(np.mean([aps[category2id[c], i_, j_] for c in categories]))
                              for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
+        report["pose_AP_per_category"] = {c: {"%ddeg_%dcm" % (d_, s_): float(aps[category2id[c], i_, j_])
+                                              for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
+                                          for c in categories}
     if out_pkl:
         import pickle
         with open(out_pkl, "wb") as f:

@@ -48,3 +48,63 @@ def run_scene_full(weights, pc, seed, scene_id, num_tuples, res=2e-3, num_rots=1
     out = O.run_scene(pc, idx, logits, scales, u, cfg_up, cfg_right, cfg_front, res, num_rots=num_rots, trig=trig)
     out["idx"] = idx
     return out
+
+
+def mlp_dino(weights, pc, desc, idx):
+    """BeyondCPPF(DINO).forward (train_dino.py:91-97, 128-133) in NumPy float32, in the reference's order: gather the
+    1024-d descriptors of the k tuple points, desc_transform each, concatenate, desc_pair_transform."""
+    idx = np.asarray(idx).astype(np.int64)
+    k = idx.shape[1]
+    desc = np.asarray(desc, dtype=np.float32)
+    wt, bt = weights["desc_transform.weight"], weights["desc_transform.bias"]
+    parts = [(desc[idx[:, i]] @ wt.T + bt).astype(np.float32) for i in range(k)]                 # train_dino.py:95
+    dp = (np.concatenate(parts, -1) @ weights["desc_pair_transform.weight"].T
+          + weights["desc_pair_transform.bias"]).astype(np.float32)                              # train_dino.py:96
+    x = np.concatenate([O.tuple_coord_inputs(pc, idx), dp], -1).astype(np.float32)
+    f = _stack(x, weights, "tuple_encoder")
+    scales = _stack(f, weights, "scale_encoder")
+    logits = _stack(f, weights, "logit_encoder").reshape(f.shape[0], 6, -1)
+    return logits, scales
+
+
+def alignment_loss(pc, T_est, R_est, pred_scale_norm, idx_filtered, pred_pairs_filtered, y_only):
+    """eval.py:358-363: clipped L1 between the canonicalised points of the kept pairs and their decoded (un-scaled)
+    coordinates; float32 points minus a float64 centre -> float64 throughout."""
+    pc_canon = (np.asarray(pc, dtype=np.float32) - T_est) @ R_est / pred_scale_norm             # eval.py:358
+    loss = np.abs(pc_canon[idx_filtered[:, :2]] - pred_pairs_filtered)                           # eval.py:359
+    if y_only:
+        loss = loss[..., 1]                                                                      # eval.py:360-361
+    loss = np.clip(loss, 0, 0.1)                                                                 # eval.py:362
+    return loss.mean()                                                                           # eval.py:363
+
+
+def run_instance_ensemble(pc, idx, per_model, cfg_up, cfg_right, cfg_front, res, num_rots=180, y_only=False,
+                          geo_branch=True, visual_branch=True, trig=None, angle_tol=1.0, backproj_ratio=0.1,
+                          imp_wt_margin=0.01):
+    """eval.py:217-372 for one instance (opt off): both models vote, each pose is scored by the alignment loss, the
+    smaller one wins.  per_model: [(pred_cls, pred_scales, uniforms) for the DINO model, ... for the SHOT model] -- the
+    networks' outputs are inputs here (mlp_dino / mlp_shot produce them).  Reproduced quirks: the scale (median of the
+    kept pairs' scale head) is taken from model 0 only and reused for model 1 (eval.py:308-310); geo_branch gates
+    model 0 and visual_branch model 1 (eval.py:367); strict '<' against best_loss = inf."""
+    best_loss, best_idx = np.inf, -1
+    pred_scale = pred_scale_norm = None
+    outs = []
+    for model_idx, (pred_cls, pred_scales, uniforms) in enumerate(per_model):
+        o = O.run_scene(pc, idx, pred_cls, pred_scales, uniforms, cfg_up, cfg_right, cfg_front, res, num_rots=num_rots,
+                        angle_tol=angle_tol, backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, trig=trig)
+        if model_idx == 0:
+            pred_scale = o["pred_scale"]                                                         # eval.py:309
+            pred_scale_norm = np.linalg.norm(pred_scale)                                         # eval.py:310 (float32)
+        mask = o["pairs_mask"]
+        o["loss"] = alignment_loss(pc, o["T_est"], o["R_est"], pred_scale_norm, np.asarray(idx)[mask],
+                                   o["pred_pairs"][mask], y_only)
+        if o["loss"] < best_loss and ((geo_branch and model_idx == 0) or (visual_branch and model_idx == 1)):
+            best_loss, best_idx = o["loss"], model_idx                                           # eval.py:367-369
+        outs.append(o)
+    RT = np.eye(4)
+    scale = np.ones(3)
+    if best_idx >= 0:
+        RT[:3, :3] = outs[best_idx]["R_est"] * pred_scale_norm                                   # eval.py:370
+        RT[:3, 3] = outs[best_idx]["T_est"]                                                      # eval.py:371
+        scale = pred_scale / pred_scale_norm                                                     # eval.py:372
+    return dict(models=outs, pick=best_idx, loss=best_loss, pred_RT=RT, pred_scale=scale, scale_norm=pred_scale_norm)

@@ -67,6 +67,23 @@ def main():
         g["%s_R_est" % name] = R_est
         g["%s_right_orth" % name] = right_orth
 
+    # ensemble score, eval.py:358-363 (inline in eval.main): the same statements on the reference's own T_est / R_est /
+    # pairs_mask of the two axis conventions, decoded coordinates drawn at random (their values do not matter here)
+    pp = (rng.randint(0, 32, (T, 2, 3)).astype(np.float32) / np.float32(31) - np.float32(0.5))
+    pred_scale = np.array([0.31, 0.52, 0.29], dtype=np.float32)
+    pred_scale_norm = np.linalg.norm(pred_scale)                                     # eval.py:310
+    g.update(loss_pred_pairs=pp, loss_pred_scale=pred_scale)
+    for name in AXES:
+        T_est, R_est, pairs_mask = g[name + "_T_est"], g[name + "_R_est"], g[name + "_pairs_mask"]
+        point_idxs_all_filtered = idx[pairs_mask]                                    # eval.py:267
+        for y_only in (False, True):
+            pc_canon = (pc - T_est) @ R_est / pred_scale_norm                        # eval.py:358
+            loss = np.abs(pc_canon[point_idxs_all_filtered[:, :2]] - pp[pairs_mask])  # eval.py:359
+            if y_only:
+                loss = loss[..., 1]                                                  # eval.py:360-361
+            loss = np.clip(loss, 0, 0.1)                                             # eval.py:362
+            g["%s_loss_%s" % (name, "y" if y_only else "xyz")] = np.float64(loss.mean())   # eval.py:363
+
     # a4: softmax of seeded logits (eval.py:226-228); float32 like the model output
     tg = torch.Generator().manual_seed(77)
     logits = (torch.randn((64, 6, 32), generator=tg) * 3.0)

@@ -81,7 +81,7 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import eval as ev
     rep = ev.main(num_pairs=6000, num_rots=72, num_scenes=3, num_points=1024, opt=False, out=str(tmp_path / "r.json"),
-                  out_pkl=str(tmp_path / "r.pkl"))
+                  out_pkl=str(tmp_path / "r.pkl"), category="bottle")
     assert rep["instances"] == 3 and len(rep["results"]) == 3
     import pickle
     res = pickle.load(open(tmp_path / "r.pkl", "rb"))
@@ -96,7 +96,7 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     for r in rep["results"]:
         assert r["model"] in ("dino", "shot") and np.isfinite(r["loss"])
     # branch gating keeps the reference's swapped names: geo_branch gates the DINO model
-    rep2 = ev.main(num_pairs=3000, num_rots=36, num_scenes=1, num_points=512, opt=False, geo_branch=False)
+    rep2 = ev.main(num_pairs=3000, num_rots=36, num_scenes=1, num_points=512, opt=False, geo_branch=False, category="bottle")
     assert rep2["results"][0]["model"] == "shot"
 
 

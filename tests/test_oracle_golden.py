@@ -261,3 +261,70 @@ def test_category_yaml_keys_match_the_reference_fixture():
         mine = yaml.safe_load(f)
     assert norm({k: v for k, v in mine.items() if k not in ("defaults", "hydra", "opt")}) == base
     assert mine["defaults"] == want["config"]["defaults"]
+
+
+def test_alignment_loss_matches_reference_statements(axes_g):
+    """eval.py:358-363 (ensemble score) on the reference's own poses of both axis conventions."""
+    from oracle import pipeline_oracle as PO
+    g = axes_g
+    norm = np.linalg.norm(g["loss_pred_scale"])
+    for name in ("default", "camera"):
+        mask = g[name + "_pairs_mask"]
+        for y_only, tag in ((False, "xyz"), (True, "y")):
+            got = PO.alignment_loss(g["pc"], g[name + "_T_est"], g[name + "_R_est"], norm, g["idx"][mask],
+                                    g["loss_pred_pairs"][mask], y_only)
+            assert got == float(g["%s_loss_%s" % (name, tag)])
+
+
+def test_oracle_mlps_match_reference_forward():
+    """oracle.pipeline_oracle.mlp_shot / mlp_dino (NumPy) against forward outputs of the reference's own modules
+    (model_shot.npz carries the weights; model_dino.npz the seed its weights were drawn with -- the module's parameter
+    creation order is the reference's, so torch.manual_seed(seed) reproduces them)."""
+    import torch
+    from oracle import pipeline_oracle as PO
+    from cppf2_amd.models import BeyondCPPFDino
+
+    g = np.load(os.path.join(GOLDEN, "model_shot.npz"))
+    w = {k[3:]: g[k] for k in g.files if k.startswith("w::")}
+    logits, scales = PO.mlp_shot(w, g["pc"], g["idx"], g["shot_raw"], g["normal"])
+    assert np.abs(logits - g["pred_cls"]).max() < 2e-4 and np.abs(scales - g["pred_scales"]).max() < 2e-4
+
+    g = np.load(os.path.join(GOLDEN, "model_dino.npz"))
+
+    class Cfg:
+        num_more = 3
+    torch.manual_seed(int(g["seed"]))
+    m = BeyondCPPFDino(Cfg())
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    w = {k: v.numpy() for k, v in sd.items()}
+    logits, scales = PO.mlp_dino(w, g["pc"], g["desc"].astype(np.float32), g["idx"])
+    assert np.abs(logits - g["pred_cls"]).max() < 2e-4 and np.abs(scales - g["pred_scales"]).max() < 2e-4
+
+
+def test_run_instance_ensemble_selection_rules():
+    """eval.py:217,365-372: strict '<' from inf, model 0 first, swapped branch flags, model-0 scale reused."""
+    from oracle import pipeline_oracle as PO
+    from cppf2_amd import synth
+    rng = np.random.RandomState(0)
+    N, T, R = 300, 1500, 36
+    scene = synth.make_scene(5, 0, N)
+    idx = synth.host_sample_tuples(5, 0, T, 5, N).astype(np.int64)
+    good = synth.teacher_logits(scene["pc_canon"], idx, 32, 0.6)
+    bad = good + rng.randn(T, 6, 32).astype(np.float32) * 6.0
+    u0, u1 = O.philox_uniform(5, 0, 1, T, 6), O.philox_uniform(5, 0, 2, T, 6)
+    # model 0's scale head = the true object diagonal (canonical coordinates are metres / diagonal, eval.py:358)
+    sc0 = (np.full((T, 3), scene["diag"] / np.sqrt(3.0)) + rng.randn(T, 3) * 1e-4).astype(np.float32)
+    sc1 = np.abs(rng.randn(T, 3)).astype(np.float32) + 5.0
+    axes = ([0, 1, 0], [1, 0, 0], [0, 0, 1])
+    r = PO.run_instance_ensemble(scene["pc"], idx, [(bad, sc0, u0), (good, sc1, u1)], *axes, 2e-3, num_rots=R, y_only=True)
+    assert r["pick"] == 1 and r["models"][1]["loss"] < r["models"][0]["loss"] and r["loss"] == r["models"][1]["loss"]
+    # the scale always comes from model 0, also when model 1 wins (eval.py:308-310)
+    assert np.array_equal(r["pred_scale"] * r["scale_norm"], r["models"][0]["pred_scale"])
+    assert np.allclose(r["pred_RT"][:3, :3], r["models"][1]["R_est"] * r["scale_norm"])
+    r2 = PO.run_instance_ensemble(scene["pc"], idx, [(bad, sc0, u0), (good, sc1, u1)], *axes, 2e-3, num_rots=R, y_only=True,
+                                  visual_branch=False)                     # visual_branch gates model 1 (SHOT)
+    assert r2["pick"] == 0
+    r3 = PO.run_instance_ensemble(scene["pc"], idx, [(bad, sc0, u0), (good, sc1, u1)], *axes, 2e-3, num_rots=R, y_only=True,
+                                  geo_branch=False, visual_branch=False)
+    assert r3["pick"] == -1 and np.array_equal(r3["pred_RT"], np.eye(4)) and np.array_equal(r3["pred_scale"], np.ones(3))
