@@ -67,8 +67,8 @@ class Cfg:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes-per-gpu", type=int, default=64)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--tuples", type=int, default=20000)
@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--eager-scale-head", action="store_true",
                     help="run the scale head on every tuple like the reference's forward (default: only on the pairs "
                          "that survive the back-vote filter, the only rows eval.py:272 ever reads)")
+    ap.add_argument("--no-reference-order", action="store_true",
+                    help="skip the second timed loop that measures the other scale-head placement (value_reference_order)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -90,10 +92,12 @@ class Step:
               "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "scale_head_torch", "assemble_pose", "gather"]
 
     def __init__(self, args, rank, world, dev):
+        from cppf2_amd import dist as cdist
         from cppf2_amd import ops, synth
         from cppf2_amd.models import BeyondCPPFShot
         from cppf2_amd.pipeline import VotingPipeline
-        self.ops, self.args, self.rank, self.world, self.dev = ops, args, rank, world, dev
+        self.ops, self.dist, self.args, self.rank, self.world, self.dev = ops, cdist, args, rank, world, dev
+        assert cdist.shard(args.scenes_per_gpu * world, rank, world) == (rank * args.scenes_per_gpu, (rank + 1) * args.scenes_per_gpu)
         B, N, T = args.scenes_per_gpu, args.points, args.tuples
         self.B, self.N, self.T = B, N, T
         self.scene0 = rank * B
@@ -115,9 +119,10 @@ class Step:
         self.prior = (-0.5 * ((kbin[None, None, :] - pos[..., None]) / 0.6) ** 2).contiguous()
         self.shot = torch.empty((B * N, 352), dtype=torch.float32, device=dev)
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
-        self.gathered = [torch.empty((B, 160), dtype=torch.uint8, device=dev) for _ in range(world)]
+        self.all_records = None
         self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
         self.side = torch.cuda.Stream(device=dev)
+        self.eager = bool(args.eager_scale_head)
         self.ev = None
 
     def _mark(self, name):
@@ -145,7 +150,8 @@ class Step:
         self._mark("shot_encoder_torch")
         x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
         self._mark("encode_tuples")
-        logits, feat = self.model.heads(x, lazy_scale=not a.eager_scale_head)
+        eager = self.eager
+        logits, feat = self.model.heads(x, lazy_scale=not eager)
         self._mark("tuple_mlp_torch")
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
@@ -156,7 +162,7 @@ class Step:
         self._mark("vote_center")
         pipe.backvote(self.pts, idx)
         self._mark("backvote_filter")
-        if a.eager_scale_head:
+        if eager:
             scales = feat                                # heads() already ran the scale head on every tuple
         else:
             # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples),
@@ -168,15 +174,13 @@ class Step:
                 scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
         pipe.rot_bins(self.pts, idx)
         self._mark("rot_bins")
-        if not a.eager_scale_head:
+        if not eager:
             torch.cuda.current_stream().wait_stream(self.side)
         self._mark("scale_head_torch")
         pipe.assemble(scales)
         self._mark("assemble_pose")
-        if self.world > 1:
-            torch.distributed.all_gather(self.gathered, pipe.results)
-        else:
-            self.gathered[0] = pipe.results
+        # the one collective of the path: 160-byte records of every rank's scenes, global scene order
+        self.all_records = self.dist.gather_results(pipe.results, B * self.world)
         self._mark("gather")
         return self.ev
 
@@ -204,16 +208,16 @@ def algorithmic_bytes(stage, B, N, T, R, S, G):
 STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_cov_kernel", "shot352": "shot_hist_kernel",
                 "encode_tuples": "encode_shot_kernel<5, 16>", "decode_bins": "decode_bins_kernel<32>",
                 "vote_frames": "vote_frames_kernel", "vote_center": "vote_center_persist_kernel", "backvote_filter": "backvote_kernel",
-                "rot_bins": "rot_bins_lut_kernel", "assemble_pose": "assemble_pose_kernel"}
+                "rot_bins": "rot_bins_lut_kernel<2>", "assemble_pose": "assemble_pose_kernel"}
 
 
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r1_pmc_traffic.json, produced by scratch/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
+    (profiles/rN_pmc_traffic.json of the latest round, produced by scratch/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
     KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     try:
-        with open(path) as f:
+        cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
+        with open(os.path.join(ROOT, "profiles", cands[-1])) as f:       # the latest round's passes
             d = json.load(f).get(STAGE_KERNEL.get(stage, ""), None)
         if not d:
             return None
@@ -278,17 +282,31 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    evs = []
-    for _ in range(args.steps):
-        evs.append(step.run(timed=True))
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed_loop(k):
+        """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds."""
+        sync()
+        t0 = time.perf_counter()
+        evs_ = []
+        for _ in range(k):
+            evs_.append(step.run(timed=True))
+        sync()
+        dt_ = time.perf_counter() - t0
+        tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+        if world > 1:
+            if torch.distributed.get_backend() == "gloo":
+                tmax = tmax.cpu()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), evs_
+
+    dt, evs = timed_loop(args.steps)
+    # the other placement of the scale head (see --eager-scale-head), measured the same way right after the headline
+    # loop (untimed for the headline): the reference's forward order when the headline uses the kept-pairs-only order
+    dt_other = None
+    if not args.no_reference_order:
+        step.eager = not step.eager
+        step.run()
+        dt_other, _ = timed_loop(args.steps)
+        step.eager = not step.eager
 
     # per-stage HIP-event times (ms per launch, averaged over the timed steps) on the stream the kernels ran on
     stage_ms = {}
@@ -299,23 +317,44 @@ def main():
     if rank == 0:
         B, N, T, R, S = step.B, step.N, step.T, args.rots, step.pipe.S
         res = step.pipe.results_to_numpy()
+        all_rec = step.pipe.results_to_numpy(step.all_records)
+        assert all_rec.shape[0] == B * world and np.array_equal(all_rec[:B].tobytes(), res.tobytes())
         G = int(np.mean(res["ncell"]))
         hip_stages = [s for s in Step.STAGES if "torch" not in s and s != "gather"]
-        launches = {}                         # launches of the stage's dominant kernel per step (all 1)
-        dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0) / launches.get(s, 1))
+        dominant = max(hip_stages, key=lambda s: stage_ms.get(s, 0.0))
         rows = []
+        per_kernel = {}
         for s in Step.STAGES:
             ms = stage_ms.get(s, 0.0)
             ab = algorithmic_bytes(s, B, N, T, R, S, G)
-            rows.append((s, ms, ab / 1e6, (ab / 1e9) / (ms / 1e3) if ms > 0 and ab else 0.0))
-        dom_ms = stage_ms[dominant] / launches.get(dominant, 1)
-        dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G) / launches.get(dominant, 1)
+            gbs = (ab / 1e9) / (ms / 1e3) if ms > 0 and ab else 0.0
+            rows.append((s, ms, ab / 1e6, gbs))
+            if s in hip_stages:
+                tr = pmc_traffic(s)
+                per_kernel[s] = dict(kernel=STAGE_KERNEL.get(s), ms=round(ms, 4), alg_MB=round(ab / 1e6, 2),
+                                     alg_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                                     pmc_MB=None if tr is None else round(tr / 1e6, 2),
+                                     pmc_frac=None if (tr is None or ms <= 0) else round(tr / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4))
+        dom_ms = stage_ms[dominant]
+        dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G)
         achieved = (dom_bytes / 1e9) / (dom_ms / 1e3)
+        hip_only_ms = sum(stage_ms.get(s, 0.0) for s in hip_stages)
+        path_bytes = sum(algorithmic_bytes(s, B, N, T, R, S, G) for s in hip_stages)
+        step_ms = 1e3 * dt / args.steps
         roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms,
                         kernel_name=STAGE_KERNEL.get(dominant),
                         algorithmic_bytes_per_launch=dom_bytes,
                         algorithmic_model="SURVEY.md 8d per-scene bytes x %d scenes per launch" % B,
+                        # the whole path's algorithmic bytes (HIP stages; ~54 MB/scene) over the whole step
+                        # (MLP included) and over the HIP stages alone, as fractions of the HBM peak
+                        pipeline_bytes_per_step=path_bytes,
+                        pipeline_frac=(path_bytes / 1e9) / (step_ms / 1e3) / HBM_PEAK_GBS,
+                        hip_only_ms=hip_only_ms,
+                        hip_only_frac=(path_bytes / 1e9) / (hip_only_ms / 1e3) / HBM_PEAK_GBS if hip_only_ms > 0 else None,
+                        hip_only_scenes_per_s=B * world / (hip_only_ms / 1e3) if hip_only_ms > 0 else None,
+                        torch_mlp_ms=sum(stage_ms.get(s, 0.0) for s in Step.STAGES if "torch" in s),
+                        per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
         ok = 0
@@ -352,6 +391,10 @@ def main():
                                    "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s"
                                    % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only"),
                        "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
+            # the same run with the scale head on every tuple (the reference's forward order), same loop protocol
+            "value_reference_order" if not args.eager_scale_head else "value_kept_pairs_order":
+                (total_scenes / dt_other) if dt_other else None,
+            "records_gathered": int(all_rec.shape[0]),
             "roofline": roofline, "cpu_baseline": cpu,
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,
         }

@@ -48,12 +48,20 @@ def gather_results(local_records, num_scenes):
         return local_records[:num_scenes]
     world, rank = dist.get_world_size(), dist.get_rank()
     cap = max_shard(num_scenes, world)
-    buf = torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=local_records.device)
-    buf[:local_records.shape[0]] = local_records
-    out = torch.empty((world, cap, RECORD_BYTES), dtype=torch.uint8, device=local_records.device)
-    dist.all_gather_into_tensor(out, buf) if local_records.is_cuda else dist.all_gather(list(out.unbind(0)), buf)
+    dev = local_records.device
+    # gloo (CPU tests, and the one-GPU dry run of the N > 1 bench) gathers host tensors; RCCL gathers in place on the device
+    stage = local_records.is_cuda and dist.get_backend() == "gloo"
+    src = local_records.cpu() if stage else local_records
+    buf = torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=src.device)
+    buf[:src.shape[0]] = src
+    out = torch.empty((world, cap, RECORD_BYTES), dtype=torch.uint8, device=src.device)
+    if src.is_cuda:
+        dist.all_gather_into_tensor(out, buf)
+    else:
+        dist.all_gather(list(out.unbind(0)), buf)
     parts = []
     for r in range(world):
         lo, hi = shard(num_scenes, r, world)
         parts.append(out[r, :hi - lo])
-    return torch.cat(parts, 0)
+    res = torch.cat(parts, 0)
+    return res.to(dev) if stage else res

@@ -1,0 +1,80 @@
+"""The N > 1 path on one GPU (scenes shard, one gather of the 160-byte records).
+
+* records do not depend on the world size: scenes 0..7 as one batch == two 4-scene "ranks" (global scene id keys every
+  RNG stream; byte-identical records);
+* bench.py --gpus 2 as two fresh processes sharing GPU 0 (gloo), started by tests/conftest.py before this process
+  touched the GPU: rank 0's JSON line reports both ranks' scenes and the gathered records.
+Needs an MI355X: run with `pytest -m gpu`.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _args(scenes_per_gpu, points=2048, tuples=8000, rots=90):
+    return types.SimpleNamespace(scenes_per_gpu=scenes_per_gpu, points=points, tuples=tuples, rots=rots, seed=0,
+                                 vote_mode=0, eager_scale_head=False)
+
+
+def test_records_do_not_depend_on_the_world_size():
+    import bench
+    dev = torch.device("cuda")
+    whole = bench.Step(_args(8), 0, 1, dev)
+    whole.run()
+    want = whole.pipe.results_to_numpy()
+    parts = []
+    for rank in range(2):
+        st = bench.Step(_args(4), rank, 2, dev)
+        assert st.scene0 == 4 * rank
+        st.run()
+        parts.append(st.pipe.results_to_numpy())
+    got = np.concatenate(parts)
+    # everything the HIP path computes is identical; `scale` is the median of the PyTorch scale head's fp32 outputs, and
+    # hipBLASLt picks its GEMM tiling (hence the accumulation order) by the row count -- 1 ulp.  (Under bench.py's weak
+    # scaling every rank has the same batch size at every world size, so there even `scale` does not move.)
+    for f in ("argmax", "t", "peak", "kept", "up_idx", "right_idx", "up_count", "right_count", "R", "flags", "ncell"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.allclose(got["scale"], want["scale"], rtol=3e-7, atol=0)
+    g2, w2 = got.copy(), want.copy()
+    g2["scale"] = w2["scale"] = 0
+    assert g2.tobytes() == w2.tobytes()
+    # the same block of scenes at the same batch size: byte-identical, whatever the world size says
+    again = bench.Step(_args(4), 1, 4, dev)
+    again.run()
+    assert again.pipe.results_to_numpy().tobytes() == parts[1].tobytes()
+    # and the poses are the synthetic ground truth's (teacher prior): the batch really ran
+    for b in range(8):
+        assert np.linalg.norm(want["t"][b] - whole.scenes[b]["t"]) < 5e-3
+
+
+def test_bench_two_ranks_on_one_gpu():
+    from conftest import BENCH2
+    if "procs" not in BENCH2:
+        pytest.skip("two-rank bench job was not started (%s)" % BENCH2.get("error", "not a -m gpu run"))
+    outs = []
+    for proc, out, err in BENCH2["procs"]:
+        rc = proc.wait(timeout=900)
+        assert rc == 0, open(err).read()[-3000:]
+        outs.append(open(out).read())
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]     # rank 0 prints the line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak" and j["unit"] == "scenes/s"
+    assert j["records_gathered"] == 8 and j["config"]["scenes_per_gpu"] == 4
+    assert j["value"] > 0 and abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    assert j["cpu_baseline"] is None                       # rank 0 at N = 1 only
+    assert j["roofline"]["frac"] > 0 and "per_kernel" in j["roofline"] and j["roofline"]["pipeline_frac"] > 0
+    assert j["pose_5deg5cm_vs_gt"] == 1.0
