@@ -19,6 +19,13 @@
  *  - 3x3 symmetric eigenproblems use cyclic Jacobi in double (PCL: closed-form float eigen33 for
  *    normals, Eigen::SelfAdjointEigenSolver<Matrix3d> for the LRF).
  *
+ * "PCL-arithmetic" mode (shot_oracle_compute_ex, mode = 1) removes the three deviations as far as a restatement can:
+ * neighbours in (distance, index) order for every sum, the normal's covariance single-pass in float on raw coordinates
+ * (computeMeanAndCovarianceMatrix of 1.9.1) with the closed-form float eigen33 / computeRoots, float viewpoint flip.
+ * (Eigen's iterative SelfAdjointEigenSolver<Matrix3d> of the LRF stays a double Jacobi: both are accurate to ~1e-15.)
+ * tests/test_shot.py reports the difference between the two modes on the bench clouds -- the measured size of the
+ * stated deviations, i.e. the bound to quote for "deviation from PCL's arithmetic".
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
  */
@@ -199,14 +206,20 @@ static int shot_lrf(const float* pts, int n, int i, float radius, float rf[9]) {
 
 /* one neighbour's contribution (SHOTEstimation::interpolateSingleChannel body); returns nothing, adds into shot[] */
 static void shot_accumulate(const float* p, const float* q, float d2, const float* nq, const float rf[9], double radius,
-                            float* shot) {
+                            float* shot, double* margin) {
   /* createBinDistanceShape */
   if (!isfinite(nq[0]) || !isfinite(nq[1]) || !isfinite(nq[2])) return;
   double cosd = (double)((nq[0] * rf[6] + nq[1] * rf[7]) + nq[2] * rf[8]);
   if (cosd > 1.0) cosd = 1.0;
   if (cosd < -1.0) cosd = -1.0;
   double bin_distance = ((1.0 + cosd) * NR_BINS) / 2;
-
+  /* PCL's "quadrilinear interpolation" adds the SUM of the four 1-D weights to the neighbour's own bin and only the
+   * individual complements to the adjacent bins, so the descriptor is a discontinuous function of the neighbour: it
+   * jumps by (w - 0.5) / |h| wherever the neighbour crosses a decision boundary -- a cosine step (bin_distance = k + 0.5),
+   * the radial shell (distance = r/2), the equator of the frame (zf = 0), an azimuth octant (xf = 0, yf = 0,
+   * |xf| = |yf|) -- and where it enters the support (distance = r).  `margin` records how close this neighbour comes to
+   * the nearest of them (dimensionless), so a test can tell a rounding-induced jump from an error. */
+  const double cos_margin = fabs((bin_distance - floor(bin_distance)) - 0.5);
   const double distance = sqrt((double)d2);
   if (fabs(distance) < 1e-15) return;
   const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
@@ -217,6 +230,19 @@ static void shot_accumulate(const float* p, const float* q, float d2, const floa
   if (fabs(xf) < 1e-30) xf = 0;
   if (fabs(zf) < 1e-30) zf = 0;
   const double r12 = radius / 2.0, r14 = radius / 4.0, r34 = radius * 3.0 / 4.0;
+  if (margin) {
+    double mg = cos_margin;
+    const double m_rad = fabs(distance - r12) / radius;
+    const double m_el = fabs(zf) / distance;
+    const double ax = fabs(xf), ay = fabs(yf);
+    double m_az = ax < ay ? ax : ay;
+    if (fabs(ax - ay) < m_az) m_az = fabs(ax - ay);
+    m_az /= distance;
+    if (m_rad < mg) mg = m_rad;
+    if (m_el < mg) mg = m_el;
+    if (m_az < mg) mg = m_az;
+    if (mg < *margin) *margin = mg;
+  }
 
   const int bit4 = ((yf > 0) || ((yf == 0.0) && (xf < 0))) ? 1 : 0;
   const int bit3 = ((xf > 0) || ((xf == 0.0) && (yf > 0))) ? !bit4 : bit4;
@@ -297,11 +323,247 @@ void shot_oracle_compute(const float* pts, int n, float normal_r, float shot_r, 
       const float* q = pts + 3 * j;
       const float d2 = sqdist(p, q);
       if (!(d2 < r2)) continue;
-      shot_accumulate(p, q, d2, out_normal + 3 * j, rf, (double)shot_r, shot);
+      shot_accumulate(p, q, d2, out_normal + 3 * j, rf, (double)shot_r, shot, NULL);
     }
     double acc = 0.0;
     for (int c = 0; c < SHOT_LEN; ++c) acc += (double)shot[c] * (double)shot[c];
     acc = sqrt(acc);
     for (int c = 0; c < SHOT_LEN; ++c) shot[c] /= (float)acc;
   }
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * PCL-arithmetic mode
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* pcl::computeRoots2 / computeRoots (common/impl/eigen.hpp), Scalar = float: eigenvalues ascending */
+static void pcl_roots2(float b, float c, float roots[3]) {
+  roots[0] = 0.0f;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+static void pcl_roots(const float m[3][3], float roots[3]) {
+  const float c0 = m[0][0] * m[1][1] * m[2][2] + 2.0f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] -
+                   m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+  const float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] -
+                   m[1][2] * m[1][2];
+  const float c2 = m[0][0] + m[1][1] + m[2][2];
+  if (fabsf(c0) < 1.1920929e-07f) { pcl_roots2(c2, c1, roots); return; }
+  const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0f) q = 0.0f;
+  const float rho = sqrtf(-a_over_3);
+  const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+  roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  if (roots[0] >= roots[1]) { const float t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  if (roots[1] >= roots[2]) {
+    const float t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+    if (roots[0] >= roots[1]) { const float u = roots[0]; roots[0] = roots[1]; roots[1] = u; }
+  }
+  if (roots[0] <= 0.0f) pcl_roots2(c2, c1, roots);
+}
+
+/* pcl::eigen33 (smallest eigenvalue's eigenvector of a symmetric float 3x3) */
+static void pcl_eigen33(const float cov[3][3], float vec[3]) {
+  float scale = 0.0f;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) scale = fmaxf(scale, fabsf(cov[i][j]));
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float m[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) m[i][j] = cov[i][j] / scale;
+  float roots[3];
+  pcl_roots(m, roots);
+  for (int i = 0; i < 3; ++i) m[i][i] -= roots[0];
+  float v[3][3];
+  const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+  float len[3];
+  for (int k = 0; k < 3; ++k) {
+    const float* a = m[pr[k][0]];
+    const float* b = m[pr[k][1]];
+    v[k][0] = a[1] * b[2] - a[2] * b[1];
+    v[k][1] = a[2] * b[0] - a[0] * b[2];
+    v[k][2] = a[0] * b[1] - a[1] * b[0];
+    len[k] = v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2];
+  }
+  int best = 2;
+  if (len[0] >= len[1] && len[0] >= len[2]) best = 0;
+  else if (len[1] >= len[0] && len[1] >= len[2]) best = 1;
+  const float inv = sqrtf(len[best]);
+  for (int c = 0; c < 3; ++c) vec[c] = v[best][c] / inv;
+}
+
+/* (distance, index)-sorted neighbours of point i within `radius` (strict <), like a sorted FLANN radius search */
+static int sorted_neighbours(const float* pts, int n, int i, float radius, Nb* nb) {
+  const float r2 = radius * radius;
+  int m = 0;
+  for (int j = 0; j < n; ++j) {
+    const float d2 = sqdist(pts + 3 * i, pts + 3 * j);
+    if (d2 < r2) { nb[m].d2 = d2; nb[m].idx = j; ++m; }
+  }
+  qsort(nb, (size_t)m, sizeof(Nb), nb_cmp);
+  return m;
+}
+
+static void pcl_normal(const float* pts, int i, const Nb* nb, int m, float* o) {
+  if (m < 3) { o[0] = o[1] = o[2] = NAN; return; }
+  float accu[9] = {0};
+  for (int t = 0; t < m; ++t) {                      /* computeMeanAndCovarianceMatrix: raw coordinates, float */
+    const float* q = pts + 3 * nb[t].idx;
+    accu[0] += q[0] * q[0]; accu[1] += q[0] * q[1]; accu[2] += q[0] * q[2];
+    accu[3] += q[1] * q[1]; accu[4] += q[1] * q[2]; accu[5] += q[2] * q[2];
+    accu[6] += q[0]; accu[7] += q[1]; accu[8] += q[2];
+  }
+  for (int c = 0; c < 9; ++c) accu[c] /= (float)m;
+  float cov[3][3];
+  cov[0][0] = accu[0] - accu[6] * accu[6];
+  cov[0][1] = accu[1] - accu[6] * accu[7];
+  cov[0][2] = accu[2] - accu[6] * accu[8];
+  cov[1][1] = accu[3] - accu[7] * accu[7];
+  cov[1][2] = accu[4] - accu[7] * accu[8];
+  cov[2][2] = accu[5] - accu[8] * accu[8];
+  cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+  float v[3];
+  pcl_eigen33(cov, v);
+  const float* p = pts + 3 * i;                      /* flipNormalTowardsViewpoint, viewpoint (0,0,0), float */
+  const float vx = 0.0f - p[0], vy = 0.0f - p[1], vz = 0.0f - p[2];
+  const float ct = vx * v[0] + vy * v[1] + vz * v[2];
+  if (ct < 0.0f) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+}
+
+/* getLocalRF over a distance-sorted list; diag (optional): eigenvalues descending, the two sign tallies */
+static int shot_lrf_sorted(const float* pts, int i, const Nb* nb, int m, float radius, float rf[9], double* diag) {
+  const float* p = pts + 3 * i;
+  double cov[6] = {0}, sum = 0.0;
+  int valid = 0;
+  for (int t = 0; t < m; ++t) {
+    const float* q = pts + 3 * nb[t].idx;
+    if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) continue;
+    const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+    const double w = (double)radius - (double)sqrtf(nb[t].d2);
+    cov[0] += w * (x * x); cov[1] += w * (x * y); cov[2] += w * (x * z);
+    cov[3] += w * (y * y); cov[4] += w * (y * z); cov[5] += w * (z * z);
+    sum += w;
+    ++valid;
+  }
+  if (diag) { diag[0] = diag[1] = diag[2] = NAN; diag[3] = diag[4] = 0; }
+  if (valid < 5) { for (int c = 0; c < 9; ++c) rf[c] = NAN; return 0; }
+  for (int c = 0; c < 6; ++c) cov[c] /= sum;
+  double w[3], v[3][3];
+  jacobi3(cov, w, v);
+  if (!isfinite(w[0]) || !isfinite(w[1]) || !isfinite(w[2])) { for (int c = 0; c < 9; ++c) rf[c] = NAN; return 0; }
+  double v1[3] = {v[0][2], v[1][2], v[2][2]};
+  double v3[3] = {v[0][0], v[1][0], v[2][0]};
+  int plus1 = 0, plus3 = 0;
+  int* vidx = (int*)malloc(sizeof(int) * (size_t)valid);
+  int k = 0;
+  for (int t = 0; t < m; ++t) {
+    const float* q = pts + 3 * nb[t].idx;
+    if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) continue;
+    vidx[k++] = nb[t].idx;
+    const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+    if ((x * v1[0] + y * v1[1]) + z * v1[2] >= 0.0) ++plus1;
+    if ((x * v3[0] + y * v3[1]) + z * v3[2] >= 0.0) ++plus3;
+  }
+  plus1 = 2 * plus1 - valid;
+  plus3 = 2 * plus3 - valid;
+  if (diag) { diag[0] = w[2]; diag[1] = w[1]; diag[2] = w[0]; diag[3] = plus1; diag[4] = plus3; }
+  if (plus1 == 0 || plus3 == 0) {
+    const int med = valid / 2;
+    int c1 = 0, c3 = 0;
+    for (int t = -2; t <= 2; ++t) {
+      const float* q = pts + 3 * vidx[med - t];
+      const double x = (double)(q[0] - p[0]), y = (double)(q[1] - p[1]), z = (double)(q[2] - p[2]);
+      if ((x * v1[0] + y * v1[1]) + z * v1[2] > 0.0) ++c1;
+      if ((x * v3[0] + y * v3[1]) + z * v3[2] > 0.0) ++c3;
+    }
+    if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
+    if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
+  }
+  free(vidx);
+  if (plus1 < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
+  if (plus3 < 0) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+  rf[0] = (float)v1[0]; rf[1] = (float)v1[1]; rf[2] = (float)v1[2];
+  rf[6] = (float)v3[0]; rf[7] = (float)v3[1]; rf[8] = (float)v3[2];
+  rf[3] = rf[7] * rf[2] - rf[8] * rf[1];
+  rf[4] = rf[8] * rf[0] - rf[6] * rf[2];
+  rf[5] = rf[6] * rf[1] - rf[7] * rf[0];
+  return 1;
+}
+
+/* mode 0: the oracle's own arithmetic (shot_oracle_compute) + diagnostics; mode 1: PCL arithmetic (see header).
+ * out_diag (optional) [n,DIAG_LEN] doubles: LRF eigenvalues (descending), sign tally of x (2*plus - n), sign tally of z,
+ * smallest margin of a neighbour to a decision boundary of the interpolation (see shot_accumulate), L2 norm of the
+ * histogram before normalisation, neighbours within shot_r, smallest |d^2 - r^2| / r^2 over ALL points (how close a
+ * point comes to entering / leaving the support: its contribution does not vanish at the rim, so that is a jump too). */
+#define DIAG_LEN 9
+void shot_oracle_compute_ex(const float* pts, int n, float normal_r, float shot_r, int mode, float* out_shot,
+                            float* out_normal, float* out_rf, double* out_diag) {
+  Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)(n > 0 ? n : 1));
+  if (mode == 1) {
+    for (int i = 0; i < n; ++i) {
+      const int m = sorted_neighbours(pts, n, i, normal_r, nb);
+      pcl_normal(pts, i, nb, m, out_normal + 3 * i);
+    }
+  } else {
+    shot_oracle_normals(pts, n, normal_r, out_normal);
+  }
+  for (int i = 0; i < n; ++i) {
+    const float* p = pts + 3 * i;
+    float* shot = out_shot + (size_t)SHOT_LEN * i;
+    float rf[9];
+    const int m = sorted_neighbours(pts, n, i, shot_r, nb);
+    int ok;
+    if (mode == 1) {
+      ok = shot_lrf_sorted(pts, i, nb, m, shot_r, rf, out_diag ? out_diag + DIAG_LEN * i : NULL);
+    } else {
+      float tmp[9];
+      shot_lrf_sorted(pts, i, nb, m, shot_r, tmp, out_diag ? out_diag + DIAG_LEN * i : NULL);   /* diagnostics only */
+      ok = shot_lrf(pts, n, i, shot_r, rf);
+    }
+    if (out_rf) memcpy(out_rf + 9 * i, rf, sizeof(rf));
+    double wrap = 1e300;
+    double* wd = out_diag ? &wrap : NULL;
+    if (out_diag) {
+      const double r2d = (double)(shot_r * shot_r);
+      double edge = 1e300;
+      for (int j = 0; j < n; ++j) {
+        const double e = fabs((double)sqdist(p, pts + 3 * j) - r2d) / r2d;
+        if (e < edge) edge = e;
+      }
+      out_diag[DIAG_LEN * i + 5] = NAN; out_diag[DIAG_LEN * i + 6] = NAN; out_diag[DIAG_LEN * i + 7] = m;
+      out_diag[DIAG_LEN * i + 8] = edge;
+    }
+    if (!ok || m < 5) { for (int c = 0; c < SHOT_LEN; ++c) shot[c] = NAN; continue; }
+    memset(shot, 0, sizeof(float) * SHOT_LEN);
+    if (mode == 1) {
+      for (int t = 0; t < m; ++t)
+        shot_accumulate(p, pts + 3 * nb[t].idx, nb[t].d2, out_normal + 3 * nb[t].idx, rf, (double)shot_r, shot, wd);
+    } else {
+      const float r2 = shot_r * shot_r;
+      for (int j = 0; j < n; ++j) {
+        const float d2 = sqdist(p, pts + 3 * j);
+        if (!(d2 < r2)) continue;
+        shot_accumulate(p, pts + 3 * j, d2, out_normal + 3 * j, rf, (double)shot_r, shot, wd);
+      }
+    }
+    double acc = 0.0;
+    for (int c = 0; c < SHOT_LEN; ++c) acc += (double)shot[c] * (double)shot[c];
+    acc = sqrt(acc);
+    if (out_diag) { out_diag[DIAG_LEN * i + 5] = wrap; out_diag[DIAG_LEN * i + 6] = acc; }
+    for (int c = 0; c < SHOT_LEN; ++c) shot[c] /= (float)acc;
+  }
+  free(nb);
 }

@@ -27,6 +27,9 @@ def _load():
         _lib = C.CDLL(_SO)
         _lib.shot_oracle_compute.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.shot_oracle_compute.restype = None
+        _lib.shot_oracle_compute_ex.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
+        _lib.shot_oracle_compute_ex.restype = None
         _lib.shot_oracle_normals.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         _lib.shot_oracle_normals.restype = None
     return _lib
@@ -49,3 +52,19 @@ def normals(pc, normal_r):
     out = np.empty((pc.shape[0], 3), np.float32)
     _load().shot_oracle_normals(pc.ctypes.data, pc.shape[0], C.c_float(normal_r), out.ctypes.data)
     return out
+
+
+def compute_ex(pc, normal_r, shot_r, pcl_arithmetic=False):
+    """Like compute(), plus diagnostics and the PCL-arithmetic mode (see shot_oracle.c).  Returns (shot, normal, rf,
+    diag f64[N,9]): LRF eigenvalues (descending), the sign tallies 2*plus - n of the x and z axes, the smallest
+    margin of a neighbour to a decision boundary of PCL's interpolation (cosine step, radial shell, equator, octant), the histogram's L2 norm, the neighbour count,
+    the smallest |d^2 - r^2| / r^2 over all points (proximity of a point to the rim of the support)."""
+    pc = np.ascontiguousarray(pc, dtype=np.float32).reshape(-1, 3)
+    n = pc.shape[0]
+    shot = np.empty((n, 352), np.float32)
+    normal = np.empty((n, 3), np.float32)
+    rf = np.empty((n, 9), np.float32)
+    diag = np.empty((n, 9), np.float64)
+    _load().shot_oracle_compute_ex(pc.ctypes.data, n, C.c_float(normal_r), C.c_float(shot_r), int(bool(pcl_arithmetic)),
+                                   shot.ctypes.data, normal.ctypes.data, rf.ctypes.data, diag.ctypes.data)
+    return shot, normal, rf, diag

@@ -165,10 +165,21 @@ def test_shot_neighbour_list_paths(n, rn, rs):
         assert 512 < cnt.max() <= 1024
     if n == 6000:
         assert cnt.max() > 1024
-    # dense volumetric balls have near-degenerate covariances: a few frames flip between equally valid axes
+    # PCL's SHOT is a discontinuous function of each neighbour (oracle/shot_oracle.c: shot_accumulate): a neighbour whose
+    # cosine / radius / elevation / azimuth lies within float rounding of a decision boundary may land in the adjacent
+    # bin (the kernel interpolates in float, the oracle in double like PCL), moving (w - 0.5) / |h| of weight.  Rows may
+    # differ ONLY there, or where the LRF itself is ambiguous; every other row agrees to 2e-5.
+    _, _, _, diag = S.compute_ex(pc, rn, rs)
     err = np.abs(hs[ok] - os_[ok]).max(1)
-    assert np.mean(err < 2e-5) > 0.98, float(np.mean(err < 2e-5))
-    assert np.allclose(hn[ok], on[ok], atol=5e-6) or np.mean(np.abs(hn[ok] - on[ok]).max(1) < 5e-6) > 0.98
+    d = diag[ok]
+    gap = np.minimum(d[:, 0] - d[:, 1], d[:, 1] - d[:, 2]) / d[:, 0]
+    exempt = (d[:, 5] < 1e-6) | (d[:, 8] < 4e-7) | (np.abs(d[:, 3]) <= 1) | (np.abs(d[:, 4]) <= 1) | (gap < 1e-9)
+    assert np.all(err[~exempt] < 2e-5), (int((err[~exempt] >= 2e-5).sum()), float(err[~exempt].max()))
+    moved = err >= 2e-5
+    assert moved.mean() < 5e-3, float(moved.mean())
+    # a jump moves at most a few neighbours' total weight (<= 4 each): bounded by 12 / |h|
+    assert np.all(err[moved] <= 12.0 / d[moved, 6])
+    assert np.allclose(hn[ok], on[ok], atol=5e-6)
 
 
 def test_vote_center_persistent_equals_per_workgroup_and_global_paths():

@@ -67,6 +67,48 @@ def test_oracle_rigid_motion_invariance():
     assert np.abs(n1 @ R.T - n2).max(1).mean() < 1e-3
 
 
+def test_oracle_deviation_from_pcl_arithmetic_is_bounded():
+    """The oracle's stated deviations from PCL 1.9.1 (double covariance about the query point, Jacobi, index-ordered sums)
+    against its PCL-arithmetic mode (single-pass float covariance on raw coordinates, closed-form eigen33, distance-ordered
+    sums) on bench clouds (4096 points, r = 2 cm, ~0.8 m from the camera).  This is the measured size of the deviations:
+    SHOT parity stays UNPINNED (no PCL here), but it is bounded by these numbers, printed for DESIGN.md."""
+    stats = []
+    for sid in (0, 1):
+        sc = synth.make_scene(0, sid, 4096)
+        s0, n0, rf0, d0 = S.compute_ex(sc["pc"], 0.02, 0.02, pcl_arithmetic=False)
+        s1, n1, rf1, d1 = S.compute_ex(sc["pc"], 0.02, 0.02, pcl_arithmetic=True)
+        assert np.array_equal(np.isnan(s0), np.isnan(s1))
+        ok = ~np.isnan(s0).any(1)
+        ang = np.degrees(np.arccos(np.clip((n0 * n1).sum(1), -1, 1)))
+        dd = np.abs(s0[ok] - s1[ok]).max(1)
+        flips = ((rf0[ok, 0:3] * rf1[ok, 0:3]).sum(1) < 0.5) | ((rf0[ok, 6:9] * rf1[ok, 6:9]).sum(1) < 0.5)
+        stats.append(dict(normal_deg_median=float(np.median(ang)), normal_deg_max=float(ang.max()),
+                          desc_median=float(np.median(dd)), desc_p90=float(np.percentile(dd, 90)),
+                          desc_jump_rows=float((dd > 1e-2).mean()), desc_max=float(dd.max()), lrf_flips=float(flips.mean())))
+    print("oracle vs PCL-arithmetic mode:", stats)
+    for st in stats:
+        # float covariance on raw coordinates at z ~ 0.8 m tilts normals by a few hundredths of a degree
+        assert st["normal_deg_median"] < 0.1 and st["normal_deg_max"] < 1.0
+        # the LRF (double in both modes) does not move
+        assert st["lrf_flips"] == 0.0
+        # the descriptor follows continuously (1e-4 level) except where a neighbour's normal crosses one of PCL's cosine
+        # steps -- a jump of PCL's own interpolation (see shot_accumulate) that hits a minority of rows
+        assert st["desc_median"] < 1e-3 and st["desc_jump_rows"] < 0.15 and st["desc_max"] < 0.5
+
+
+def test_oracle_modes_agree_when_the_covariance_is_well_conditioned():
+    """Same cloud moved to the origin (no cancellation in the float covariance): the two modes give the same normals to
+    float rounding -- the deviation measured above is the float covariance's, nothing structural."""
+    sc = synth.make_scene(0, 0, 1500)
+    pc = (sc["pc"] - sc["pc"].mean(0)).astype(np.float32)
+    _, n0, rf0, _ = S.compute_ex(pc, 0.02, 0.02, pcl_arithmetic=False)
+    _, n1, rf1, _ = S.compute_ex(pc, 0.02, 0.02, pcl_arithmetic=True)
+    # (the viewpoint flip may differ for normals perpendicular to the view ray; compare up to sign)
+    ang = np.degrees(np.arccos(np.clip(np.abs((n0 * n1).sum(1)), -1, 1)))
+    assert np.median(ang) < 2e-3 and np.percentile(ang, 99) < 0.05
+    assert np.allclose(rf0, rf1, atol=1e-6, equal_nan=True)
+
+
 @pytest.mark.gpu
 def test_hip_shot_vs_oracle():
     torch = pytest.importorskip("torch")
@@ -115,3 +157,33 @@ def test_hip_shot_nan_policy_and_plane():
     assert np.isnan(s).all()
     n = n.reshape(-1, 3)
     assert np.isnan(n[3]).all() and not np.isnan(n[0]).any()
+
+
+@pytest.mark.gpu
+def test_hip_shot_bench_size_vs_oracle():
+    """BASELINE-size clouds (4096 points, normal and descriptor radius 2 cm = 10 x res, eval.py:210), a batch of two:
+    normals and frames to float rounding; descriptors within 2e-5 except where the oracle itself says a neighbour sits on
+    a decision boundary of PCL's interpolation (margin < 1e-6) -- there the float / double evaluation may pick the other
+    bin.  (Parity with PCL itself stays unpinned; see test_oracle_deviation_from_pcl_arithmetic_is_bounded.)"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from cppf2_amd import ops, shot
+    scs = [synth.make_scene(0, s, 4096) for s in (0, 1)]
+    pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
+    pt_off = ops._offsets([4096, 4096], pts.device)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True)
+    hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
+    for b, sc in enumerate(scs):
+        sl = slice(4096 * b, 4096 * (b + 1))
+        os_, on, orf, d = S.compute_ex(sc["pc"], 0.02, 0.02)
+        assert np.array_equal(np.isnan(os_), np.isnan(hs[sl]))
+        assert np.allclose(hn[sl], on, atol=2e-6, equal_nan=True)
+        assert np.allclose(hrf[sl], orf, atol=2e-5, equal_nan=True)
+        ok = ~np.isnan(os_).any(1)
+        assert ok.mean() > 0.99
+        err = np.abs(hs[sl][ok] - os_[ok]).max(1)
+        exempt = (d[ok, 5] < 1e-6) | (d[ok, 8] < 4e-7)
+        assert np.all(err[~exempt] < 2e-5), float(err[~exempt].max())
+        assert (err >= 2e-5).mean() < 5e-3
+        assert np.allclose(np.linalg.norm(hs[sl][ok], axis=1), 1.0, atol=1e-5)
