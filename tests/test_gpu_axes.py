@@ -133,3 +133,31 @@ def test_pipeline_with_category_config_vs_oracle(category):
             assert np.degrees(np.arccos(min(cosang, 1.0))) < tol, (category, col)
         assert abs(np.linalg.det(r["R"]) - 1) < 1e-5
         t0 += T
+
+
+def test_decode_bins_draws_from_the_reference_softmax(axes_g):
+    """a4: the kernel's inverse-CDF draw against the probabilities torch.softmax produced in the reference run
+    (eval.py:228; tests/golden/axes.npz): bin = first k with cdf_ref[k] > u; a draw may differ only where u lies within
+    1e-5 of a CDF edge (expf / summation ulps)."""
+    logits, prob = axes_g["softmax_logits"], axes_g["softmax_prob"]
+    T = logits.shape[0]
+    rng = np.random.RandomState(0)
+    pc = rng.rand(50, 3).astype(np.float32)
+    idx = rng.randint(0, 50, (T, 5)).astype(np.int32)
+    flips = total = 0
+    for stream in range(8):                                  # 8 x 384 draws from the same distributions
+        u = O.philox_uniform(123, 0, stream, T, 6)
+        out = ops.decode_bins(logits, u, pc, idx, [0, 1, 0], [0, 0, 1], [1, 0, 0])
+        bins = out["bins"].cpu().numpy()
+        cdf = np.cumsum(prob.astype(np.float64), -1)
+        want = np.minimum((cdf <= u[..., None].astype(np.float64)).sum(-1), 31)
+        margin = np.abs(cdf - u[..., None]).min(-1)
+        diff = bins != want
+        assert np.all(margin[diff] < 1e-5)
+        flips += int(diff.sum()); total += diff.size
+    assert flips <= max(2, total // 500)
+    # edge rows: one-hot row always draws its bin, uniform rows follow u * 32
+    u = O.philox_uniform(123, 0, 0, T, 6)
+    bins = ops.decode_bins(logits, u, pc, idx, [0, 1, 0], [0, 0, 1], [1, 0, 0])["bins"].cpu().numpy()
+    assert bins[1, 0] == 5
+    assert abs(int(bins[0, 0]) - int(u[0, 0] * 32)) <= 1 and abs(int(bins[2, 0]) - int(u[2, 0] * 32)) <= 1
