@@ -1,6 +1,7 @@
 // cppf_vote.hip -- centre Hough vote + first-max, back-vote filter, rotation vote + sphere bins,
 // pose assembly.  gfx950 only.  See include/cppf_hip.h for the contract of each entry point.
 #include "cppf_common.h"
+#include <mutex>
 
 // =============================================================================================
 // a6. vote_center (train_dino.py:171-215)
@@ -35,8 +36,10 @@
 #endif
 #define VC_ARG_BLOCKS 32
 #ifndef VC_MAX_LDS_ROTS
-#define VC_MAX_LDS_ROTS 1024
+#define VC_MAX_LDS_ROTS 512            // rotation tables kept in LDS (twice, so a quantum never wraps): 2 x (2*512+4) floats
 #endif
+#define VC_TAB_LEN (2 * VC_MAX_LDS_ROTS + 4)
+#define VC_LDS_WORDS (VC_SLAB_CELLS + 2 * VC_TAB_LEN + (VC_THREADS / 64) * 64)
 #ifndef VC_MIN_WAVES
 #define VC_MIN_WAVES 4
 #endif
@@ -88,12 +91,6 @@ __device__ __forceinline__ int vote_cell(float cx, float cy, float cz, float xx,
   if (!ok) return -1;
   return ((int)fx * gy + (int)fy) * gz + (int)fz;
 }
-
-// Cell of a vote without the IEEE division (vote_cell_packed below).  num = (c+off)-c0 exactly as the reference
-// computes it; the reference's value is t_ref = fl(fl(num/res) + 0.5).  t = fma(num, rinv, 0.5) differs from it by at
-// most (|q|+1) * 3e-7 (rounded reciprocal + one rounding vs quotient rounding + add rounding), so whenever t is
-// farther than m = (g+2)*1e-6 from every integer, floor(t) == trunc(t_ref) and both validity tests (cell > 0,
-// cell < g) agree.  Otherwise (t on a cell boundary, NaN, far outside) the vote is redone with the exact arithmetic.
 
 // Vote weight in accumulator units: 1 per vote when no weights are given (the reference, train_dino.py:204);
 // otherwise round(w * 256), w clamped to [0, 4] (deterministic integer accumulation: the "uncertainty-weighted"
@@ -203,38 +200,102 @@ __device__ __forceinline__ int wave_incl_scan_max(int x) {   // values >= 0
 typedef float vc_f2 __attribute__((ext_vector_type(2)));
 
 struct GridFast {
-  float c0x, res, rinv, hm;     // hm = 0.5 - rounding margin
-  vc_f2 c0yz;
+  float c0x, c0y, c0z, rinv;
+  float lo_m, hi_m;             // a fractional part inside [lo_m, hi_m] is farther than the rounding margin from a cell boundary
   int gx, gy, gz;
 };
 
-// Flat cell of one vote on the fast path, or a negative value; `sure` is cleared when the caller has to redo the vote
-// with vote_cell_exact below.  The decision procedure described above (multiply by the rounded reciprocal;
-// whenever a coordinate lands within the rounding margin of a cell boundary -- or is NaN / huge -- the exact IEEE
-// divisions decide), arranged branch-free for the packed-fp32 pipe: y and z travel as one register pair.  x is
-// clamped to [0, gx] instead of tested: x-layer 0 and layer gx fall outside every slab's valid window (lo_eff in the
-// kernel), which is where the reference's `> 0` / `< grid_res` tests put them.
-__device__ __forceinline__ int vote_cell_packed(float cx, vc_f2 cyz, float xx, vc_f2 xyz, float yx, vc_f2 yyz,
-                                                float cs, float sn, const GridFast& gc, bool& sure) {
-  const float ox = cs * xx + sn * yx;
-  const vc_f2 oyz = cs * xyz + sn * yyz;
-  const float nx = (cx + ox) - gc.c0x;
-  const vc_f2 nyz = (cyz + oyz) - gc.c0yz;
-  const float tx = fmaf(nx, gc.rinv, 0.5f);
-  const float ty = fmaf(nyz.x, gc.rinv, 0.5f), tz = fmaf(nyz.y, gc.rinv, 0.5f);
-  const float e = fmaxf(fmaxf(fabsf(__builtin_amdgcn_fractf(tx) - 0.5f), fabsf(__builtin_amdgcn_fractf(ty) - 0.5f)),
-                        fabsf(__builtin_amdgcn_fractf(tz) - 0.5f));
-  sure = e <= gc.hm;
-  // floor + convert in one instruction each; x clamped with one median; 24-bit multiply-adds (see `narrow`)
-  int ix, iy, iz, lin;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(tx));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(ty));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iz) : "v"(tz));
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(ix) : "v"(ix), "s"(gc.gx));
-  const bool ok = ((unsigned)(iy - 1) < (unsigned)(gc.gy - 1)) & ((unsigned)(iz - 1) < (unsigned)(gc.gz - 1));
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(ix), "s"(gc.gy), "v"(iy));
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(lin), "s"(gc.gz), "v"(iz));
-  return ok ? lin : -1;
+__device__ __forceinline__ vc_f2 vc_pk_fma(vc_f2 a, vc_f2 b, vc_f2 c) {
+  vc_f2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int vc_flr(float t) {
+  int i;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(t));
+  return i;
+}
+__device__ __forceinline__ int vc_mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float vc_min3(float a, float b, float c) {
+  float d;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float vc_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// One coordinate of two consecutive rotations on the packed-fp32 pipe: t = fma((c + (cs*a + sn*b)) - c0, 1/res, half),
+// every operation rounded where the reference rounds it (train_dino.py:195-197: mul, mul, add, add, sub; the division by
+// res is replaced by the fused multiply with the rounded reciprocal -- see the decision procedure below).
+__device__ __forceinline__ vc_f2 vc_coord2(vc_f2 cs, vc_f2 sn, float a, float b, float c, float c0, vc_f2 rinv2,
+                                           vc_f2 half2) {
+  const vc_f2 o = cs * a + sn * b;
+  const vc_f2 nrm = (c + o) - c0;
+  return vc_pk_fma(nrm, rinv2, half2);
+}
+
+// The VC_QUANTUM = 4 votes of one quantum (consecutive rotations rr .. rr+3 of one pair) on the fast path: relative cell
+// index of each vote (unsigned: anything >= n is "not in this slab"), validity bits, and `sure`, cleared when any
+// of the 12 coordinates lands within the rounding margin of a cell boundary -- or is NaN / huge -- in which case the
+// caller redoes the quantum with the exact IEEE divisions (vote_cell_exact below).
+//   num = (c+off)-c0 exactly as the reference computes it; the reference's value is t_ref = fl(fl(num/res) + 0.5).
+//   t = fma(num, rinv, 0.5) differs from it by at most (|q|+1) * 3e-7 (rounded reciprocal + one rounding vs quotient
+//   rounding + add rounding), so whenever t is farther than m = (g+2)*1e-6 from every integer, floor(t) ==
+//   trunc(t_ref) and both validity tests (cell > 0, cell < g) agree.
+// y and z are evaluated one cell lower (half = -0.5): floor gives cell - 1 directly, which is what the validity test
+// 0 < cell < g  <=>  (unsigned)(cell - 1) < g - 1 wants; the constant is folded into `base`.  x is clamped to [0, gx]
+// instead of tested: layer gx lies beyond the last slab, and layer 0 (train_dino.py:199 keeps indices > 0) is wiped
+// by the caller after the votes.  Rotation pairs travel as one register pair (v_pk_*), cos/sin come from LDS tables
+// laid out twice in a row so that rr + 3 never wraps.
+struct QuantumCells {
+  unsigned rel[VC_QUANTUM];
+  bool ok[VC_QUANTUM];
+  float fmin[VC_QUANTUM], fmax[VC_QUANTUM];   // smallest / largest fractional part of each vote's three coordinates
+};
+
+__device__ __forceinline__ QuantumCells vote_quantum(float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                                     float yy, float yz, const float* s_cos, const float* s_sin, int rr,
+                                                     const GridFast& gc, unsigned base, bool& sure) {
+  static_assert(VC_QUANTUM == 4, "vote_quantum is written for quanta of 4 rotations");
+  const vc_f2 c01 = {s_cos[rr], s_cos[rr + 1]}, c23 = {s_cos[rr + 2], s_cos[rr + 3]};
+  const vc_f2 s01 = {s_sin[rr], s_sin[rr + 1]}, s23 = {s_sin[rr + 2], s_sin[rr + 3]};
+  const vc_f2 rinv2 = {gc.rinv, gc.rinv}, hp = {0.5f, 0.5f}, hm = {-0.5f, -0.5f};
+  const vc_f2 tx01 = vc_coord2(c01, s01, xx, yx, cx, gc.c0x, rinv2, hp), tx23 = vc_coord2(c23, s23, xx, yx, cx, gc.c0x, rinv2, hp);
+  const vc_f2 ty01 = vc_coord2(c01, s01, xy, yy, cy, gc.c0y, rinv2, hm), ty23 = vc_coord2(c23, s23, xy, yy, cy, gc.c0y, rinv2, hm);
+  const vc_f2 tz01 = vc_coord2(c01, s01, xz, yz, cz, gc.c0z, rinv2, hm), tz23 = vc_coord2(c23, s23, xz, yz, cz, gc.c0z, rinv2, hm);
+  const float tx[4] = {tx01.x, tx01.y, tx23.x, tx23.y}, ty[4] = {ty01.x, ty01.y, ty23.x, ty23.y},
+              tz[4] = {tz01.x, tz01.y, tz23.x, tz23.y};
+  float fr[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fr[3 * j] = __builtin_amdgcn_fractf(tx[j]); fr[3 * j + 1] = __builtin_amdgcn_fractf(ty[j]);
+    fr[3 * j + 2] = __builtin_amdgcn_fractf(tz[j]);
+  }
+  QuantumCells q;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    q.fmin[j] = vc_min3(fr[3 * j], fr[3 * j + 1], fr[3 * j + 2]);
+    q.fmax[j] = vc_max3(fr[3 * j], fr[3 * j + 1], fr[3 * j + 2]);
+  }
+  const float mn = fminf(vc_min3(q.fmin[0], q.fmin[1], q.fmin[2]), q.fmin[3]);
+  const float mx = fmaxf(vc_max3(q.fmax[0], q.fmax[1], q.fmax[2]), q.fmax[3]);
+  sure = (mn >= gc.lo_m) & (mx <= gc.hi_m);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int ix = vc_flr(tx[j]);
+    const int iy = vc_flr(ty[j]), iz = vc_flr(tz[j]);                 // cell - 1
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(ix) : "v"(ix), "s"(gc.gx));
+    q.ok[j] = ((unsigned)iy < (unsigned)(gc.gy - 1)) & ((unsigned)iz < (unsigned)(gc.gz - 1));
+    q.rel[j] = (unsigned)vc_mad24(vc_mad24(ix, gc.gy, iy), gc.gz, iz) + base;   // flat cell - first cell of the slab
+  }
+  return q;
 }
 
 // the same vote with the reference's arithmetic (train_dino.py:195-203); out of line (rare) and with every argument by
@@ -265,16 +326,64 @@ __device__ __forceinline__ FrameRegs load_frame(const float* __restrict__ fr, in
   return f;
 }
 
+// The quantum a lane works on in one window and the frame of the pair that owns it.
+struct OwnerRegs {
+  float cx, cy, cz, xx, xy, xz, yx, yy, yz;
+  int rr, len;          // first rotation (index into the doubled tables) and rotations left in the arc (<= 0: idle lane)
+  uint32_t wv;
+};
+
+// Lane l of the window starting at quantum qb takes quantum qb + l of the wavefront's arcs.  Its owner pair is found
+// without a search: every owner drops (window tag | lane id) at the window slot of its first quantum in a 64-entry LDS
+// strip, and a DPP max-scan of the strip spreads it over the owner's quanta (stale entries of older windows carry
+// smaller tags, so the strip is never cleared).  The owner's frame then comes across lanes with ds_bpermute.
+template <bool WEIGHTED>
+__device__ __forceinline__ OwnerRegs find_owner(int qb, int WQ, int incl, int excl, int nq, int pk0, int pk1, uint32_t wv,
+                                                float cx, float cy, float cz, float xx, float xy, float xz, float yx,
+                                                float yy, float yz, int lane, uint32_t* s_mark, int& tag) {
+  tag += 64;
+  const int first = __popcll(__ballot(incl <= qb));            // owner of quantum qb (< 64 because qb < WQ)
+  const unsigned wslot = (unsigned)(excl - qb);
+  if (nq > 0 && wslot < 64u) s_mark[wslot] = (uint32_t)(tag | lane);
+  __builtin_amdgcn_wave_barrier();
+  int m = (int)s_mark[lane];
+  __builtin_amdgcn_wave_barrier();
+  m = (lane == 0) ? (tag | first) : m;
+  const int src = wave_incl_scan_max(m) & 63;
+  OwnerRegs o;
+  o.cx = __shfl(cx, src); o.cy = __shfl(cy, src); o.cz = __shfl(cz, src);
+  o.xx = __shfl(xx, src); o.xy = __shfl(xy, src); o.xz = __shfl(xz, src);
+  o.yx = __shfl(yx, src); o.yy = __shfl(yy, src); o.yz = __shfl(yz, src);
+  const int opk0 = __shfl(pk0, src), opk1 = __shfl(pk1, src);
+  const int ql = qb + lane - __shfl(excl, src);                 // quantum index inside the owner
+  o.wv = WEIGHTED ? (uint32_t)__shfl((int)wv, src) : 1u;
+  const int onq0 = opk0 >> 21;
+  const bool second = ql >= onq0;
+  const int qa = (second ? ql - onq0 : ql) * VC_QUANTUM;
+  const int opk = second ? opk1 : opk0;
+  o.rr = (opk & 1023) + qa;                                     // < 2 R: the tables are laid out twice in a row
+  const int len = ((opk >> 10) & 2047) - qa;
+  o.len = (qb + lane < WQ) ? len : 0;
+  return o;
+}
+
 // One work item of the slab scheme: scene b, slab s (n cells from flat cell lo), part pc of Pl of the scene's pair
 // list.  Called by the one-item-per-workgroup kernel (small batches) and by the persistent kernel (work list).
-template <bool ARCS>
+// LDS: slab[VC_SLAB_CELLS] counters | cos[VC_TAB_LEN] | sin[VC_TAB_LEN] (the table twice in a row + 4) | 64 owner
+// marks per wavefront.
+template <bool ARCS, bool WEIGHTED>
 __device__ __forceinline__ void vote_slab_item(
-    uint32_t* slab, const float2* s_trig, volatile int* s_mark, int& tag, int b, int s, int pc, int Pl,
+    uint32_t* slab, int& tag, int b, int s, int pc, int Pl,
     const CppfSceneGrid& g, int G, const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off,
     float res, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
     SlabBest* __restrict__ slab_best, int s_max, int P, uint32_t* __restrict__ part, int* __restrict__ tickets) {
+#ifdef VC_DIAG
   const long long t_start = wall_clock64();
+#endif
+  const float* s_cos = reinterpret_cast<const float*>(slab + VC_SLAB_CELLS);
+  const float* s_sin = s_cos + VC_TAB_LEN;
+  uint32_t* s_mark = slab + VC_SLAB_CELLS + 2 * VC_TAB_LEN + (threadIdx.x >> 6) * 64;     // this wavefront's strip
   const int lo = s * VC_SLAB_CELLS;
   const int n = min(VC_SLAB_CELLS, G - lo);
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
@@ -292,15 +401,15 @@ __device__ __forceinline__ void vote_slab_item(
   const int gyz = gy * gz;
   const int xl = lo / gyz, xh = (lo + n - 1) / gyz;            // x-layers this slab touches
   GridFast gf;
-  gf.c0x = c0x; gf.res = res; gf.rinv = 1.0f / res; gf.c0yz.x = c0y; gf.c0yz.y = c0z;
-  gf.hm = 0.5f - (float)(max(gx, max(gy, gz)) + 2) * 1e-6f;
+  gf.c0x = c0x; gf.c0y = c0y; gf.c0z = c0z; gf.rinv = 1.0f / res;
+  gf.lo_m = (float)(max(gx, max(gy, gz)) + 2) * 1e-6f;
+  gf.hi_m = 1.0f - gf.lo_m;
   gf.gx = gx; gf.gy = gy; gf.gz = gz;
   // the packed cell index uses 24-bit multiplies: (gx + 1) * gy must stay below 2^23 (any grid the reference
   // accepts, eval.py:200, is far below); wider grids take the exhaustive sweep with 32-bit arithmetic
   const bool narrow = (int64_t)(gx + 1) * gy < (1 << 23) && gz < (1 << 23);
-  // valid cells of this slab: x-layer 0 is never a valid cell (train_dino.py:199 keeps indices > 0)
-  const int lo_eff = max(lo, gyz);
-  const unsigned n_eff = (lo + n > lo_eff) ? (unsigned)(lo + n - lo_eff) : 0u;
+  // vote_quantum works with (cell_y - 1, cell_z - 1): flat cell = (ix*gy + iy')*gz + iz' + (gz + 1); relative to the slab
+  const unsigned base = (unsigned)(gz + 1 - lo);
   const int lane = wave_lane();
   // frames of the next block of pairs are requested before the current block is processed (register double buffer)
   FrameRegs nf = load_frame(fr, total, (int64_t)t0 + ts + (int)threadIdx.x, ts + (int)threadIdx.x < te);
@@ -315,11 +424,7 @@ __device__ __forceinline__ void vote_slab_item(
     if (ARCS && narrow) {
       // Arc lengths are very uneven (a circle lying in the slab's layers keeps all its rotations, most keep a
       // handful, many none), so the wavefront's arcs are cut into quanta of VC_QUANTUM rotations (never straddling
-      // the two arcs of a pair) and the quanta are dealt out evenly, 64 at a time: lane l of window w takes quantum
-      // 64 w + l.  Its owner pair is found without a search: every owner drops (window tag | lane id) at the window
-      // slot of its first quantum in a 64-entry LDS strip, and a DPP max-scan of the strip spreads it over the
-      // owner's quanta (stale entries of older windows carry smaller tags, so the strip is never cleared).  The
-      // owner's frame then comes across lanes with ds_bpermute.
+      // the two arcs of a pair) and the quanta are dealt out evenly, 64 at a time (find_owner).
       ArcSet arcs = slab_arcs(cx, invA, phi, c0x, res, xl, xh, num_rots);
       arcs.a0 += (arcs.a0 < 0) ? num_rots : 0; arcs.a0 += (arcs.a0 < 0) ? num_rots : 0;
       arcs.a0 -= (arcs.a0 >= num_rots) ? num_rots : 0; arcs.a0 -= (arcs.a0 >= num_rots) ? num_rots : 0;
@@ -332,64 +437,35 @@ __device__ __forceinline__ void vote_slab_item(
       const int incl = wave_incl_scan_add(nq);
       const int excl = incl - nq;
       const int WQ = __builtin_amdgcn_readlane(incl, 63);
-      const vc_f2 cyz = {cy, cz}, xyz = {xy, xz}, yyz = {yy, yz};
       for (int qb = 0; qb < WQ; qb += 64) {
-        tag += 64;
 #ifdef VC_DIAG
         ++nwin;
 #endif
-        const int first = __popcll(__ballot(incl <= qb));            // owner of quantum qb (< 64 because qb < WQ)
-        const unsigned wslot = (unsigned)(excl - qb);
-        if (nq > 0 && wslot < 64u) s_mark[wslot] = tag | lane;
-        __builtin_amdgcn_wave_barrier();
-        int m = s_mark[lane];
-        __builtin_amdgcn_wave_barrier();
-        m = (lane == 0) ? (tag | first) : m;
-        const int src = wave_incl_scan_max(m) & 63;
-        const float ocx = __shfl(cx, src), oxx = __shfl(xx, src), oyx = __shfl(yx, src);
-        vc_f2 ocyz, oxyz, oyyz;
-        ocyz.x = __shfl(cyz.x, src); ocyz.y = __shfl(cyz.y, src);
-        oxyz.x = __shfl(xyz.x, src); oxyz.y = __shfl(xyz.y, src);
-        oyyz.x = __shfl(yyz.x, src); oyyz.y = __shfl(yyz.y, src);
-        const int opk0 = __shfl(pk0, src), opk1 = __shfl(pk1, src);
-        const int ql = qb + lane - __shfl(excl, src);                 // quantum index inside the owner
-        const uint32_t owv = (uint32_t)__shfl((int)wv, src);
-        const int onq0 = opk0 >> 21;
-        const bool second = ql >= onq0;
-        const int qa = (second ? ql - onq0 : ql) * VC_QUANTUM;
-        const int opk = second ? opk1 : opk0;
-        int rr = (opk & 1023) + qa;                                   // < 2 R
-        rr -= (rr >= num_rots) ? num_rots : 0;
-        int len = ((opk >> 10) & 2047) - qa;
-        len = (qb + lane < WQ) ? len : 0;
-        // the quantum's rotations are independent: table reads first, then all cells branch-free (so the
-        // compiler interleaves them), the rare boundary cases redone exactly, then the counters
-        float2 tg[VC_QUANTUM];
+        // (issuing the lookup of window w + 1 before the votes of window w -- a depth-2 software pipeline -- was measured:
+        // 125 VGPRs and 3 % slower; the four wavefronts per SIMD already cover the lookup's latency)
+        const OwnerRegs cur = find_owner<WEIGHTED>(qb, WQ, incl, excl, nq, pk0, pk1, wv, cx, cy, cz, xx, xy, xz, yx, yy, yz,
+                                                   lane, s_mark, tag);
+        bool sure;
+        QuantumCells q = vote_quantum(cur.cx, cur.cy, cur.cz, cur.xx, cur.xy, cur.xz, cur.yx, cur.yy, cur.yz, s_cos, s_sin,
+                                      cur.rr, gf, base, sure);
+        const int len = cur.len, rr = cur.rr;
+        if (__builtin_expect(!sure && len > 0, 0)) {
+          // rare (a coordinate within the rounding margin of a cell boundary): the reference's own arithmetic decides,
+          // for the votes concerned only
 #pragma unroll
-        for (int jj = 0; jj < VC_QUANTUM; ++jj) {
-          tg[jj] = s_trig[rr];
-          ++rr;
-          rr = (rr == num_rots) ? 0 : rr;
+          for (int jj = 0; jj < VC_QUANTUM; ++jj) {
+            if (jj < len && !((q.fmin[jj] >= gf.lo_m) & (q.fmax[jj] <= gf.hi_m))) {
+              const int lin = vote_cell_exact(cur.cx, cur.cy, cur.cz, cur.xx, cur.xy, cur.xz, cur.yx, cur.yy, cur.yz,
+                                              s_cos[rr + jj], s_sin[rr + jj], c0x, c0y, c0z, res, gx, gy, gz);
+              q.ok[jj] = lin >= 0;
+              q.rel[jj] = (unsigned)(lin - lo);
+            }
+          }
         }
-        int lin[VC_QUANTUM];
-        unsigned redo = 0;
-#pragma unroll
-        for (int jj = 0; jj < VC_QUANTUM; ++jj) {
-          bool sure;
-          const int l = vote_cell_packed(ocx, ocyz, oxx, oxyz, oyx, oyyz, tg[jj].x, tg[jj].y, gf, sure);
-          lin[jj] = (jj < len) ? l : -1;
-          redo |= (jj < len && !sure) ? (1u << jj) : 0u;
-        }
-        if (__builtin_expect(redo != 0, 0)) {
-#pragma unroll
-          for (int jj = 0; jj < VC_QUANTUM; ++jj)
-            if (redo & (1u << jj))
-              lin[jj] = vote_cell_exact(ocx, ocyz.x, ocyz.y, oxx, oxyz.x, oxyz.y, oyx, oyyz.x, oyyz.y, tg[jj].x, tg[jj].y, c0x,
-                                        c0y, c0z, res, gx, gy, gz);
-        }
+        const uint32_t owv = WEIGHTED ? cur.wv : 1u;
 #pragma unroll
         for (int jj = 0; jj < VC_QUANTUM; ++jj)
-          if ((unsigned)(lin[jj] - lo_eff) < n_eff) atomicAdd(&slab[lin[jj] - lo], owv);
+          if (q.ok[jj] && jj < len && q.rel[jj] < (unsigned)n) atomicAdd(&slab[q.rel[jj]], owv);
       }
     } else if (cx == cx) {
       for (int r = 0; r < num_rots; ++r) {
@@ -401,6 +477,12 @@ __device__ __forceinline__ void vote_slab_item(
     }
   }
   __syncthreads();
+  if (ARCS && narrow && s == 0) {
+    // x-layer 0 is never a valid cell (train_dino.py:199 keeps indices > 0); the fast path clamps x instead of testing
+    // it, so whatever landed there is wiped here
+    for (int i = threadIdx.x; i < min(n, gyz); i += VC_THREADS) slab[i] = 0u;
+    __syncthreads();
+  }
 #ifdef VC_DIAG
   const long long t_b = wall_clock64();
 #endif
@@ -444,8 +526,9 @@ __device__ __forceinline__ void vote_slab_item(
     if (threadIdx.x == 0) {
       for (int w = 1; w < VC_THREADS / 64; ++w) argmax_combine(bv, bi, s_v[w], s_i[w]);
       SlabBest o; o.idx = bi; o.val = bv;
-      o.pad = (uint32_t)(wall_clock64() - t_start);     // workgroup duration in 100 MHz ticks (diagnostics)
+      o.pad = 0;
 #ifdef VC_DIAG
+      o.pad = (uint32_t)(wall_clock64() - t_start);     // item duration in 100 MHz ticks (scratch/vc_bench.py, DIAG=1)
       if (VC_DIAG == 1) o.pad = (uint32_t)(t_a - t_start);
       if (VC_DIAG == 2) o.pad = (uint32_t)(t_b - t_a);
       if (VC_DIAG == 3) o.pad = (uint32_t)(wall_clock64() - t_b);
@@ -464,17 +547,28 @@ __device__ __forceinline__ void vote_slab_item(
 
 // (scene, part, slab rank) -> one item per workgroup: small batches (pair lists split P ways, merged with global
 // atomics) and the exhaustive A/B mode
-template <bool ARCS>
+// rotation tables into LDS, twice in a row (+4) so that the 4 rotations of a quantum never wrap; owner marks cleared
+__device__ __forceinline__ void vote_stage_tables(uint32_t* slab, int num_rots, const float* __restrict__ cos_tab,
+                                                  const float* __restrict__ sin_tab) {
+  float* s_cos = reinterpret_cast<float*>(slab + VC_SLAB_CELLS);
+  float* s_sin = s_cos + VC_TAB_LEN;
+  for (int i = threadIdx.x; i < 2 * num_rots + 4; i += VC_THREADS) {
+    const int r = i % num_rots;
+    s_cos[i] = cos_tab[r];
+    s_sin[i] = sin_tab[r];
+  }
+  slab[VC_SLAB_CELLS + 2 * VC_TAB_LEN + threadIdx.x] = 0u;
+}
+
+// (scene, part, slab rank) -> one item per workgroup: small batches (pair lists split P ways, merged with global
+// atomics) and the exhaustive A/B mode
+template <bool ARCS, bool WEIGHTED>
 __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_kernel(
     const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
     SlabBest* __restrict__ slab_best, int s_max, int P) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
-  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);   // [num_rots] (cos, sin) (ARCS only)
-  // per-wavefront strip of 64 owner marks (ARCS only), behind the largest table the arcs path accepts
-  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
-                         (threadIdx.x >> 6) * 64;
   int tag = 0;
   const int pc = blockIdx.y, rank = blockIdx.z;
   const int b = (blockIdx.x + rank) % gridDim.x;
@@ -485,12 +579,9 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   // centre-out permutation of 0..nslab-1: mid, mid-1, mid+1, mid-2, ... (heavy central slabs dispatched first)
   const int mid = nslab >> 1, dd = (rank + 1) >> 1;
   const int s = (rank & 1) ? mid - dd : mid + dd;
-  if (ARCS) {
-    for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
-    s_mark[threadIdx.x & 63] = 0;
-  }
-  vote_slab_item<ARCS>(slab, s_trig, s_mark, tag, b, s, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
-                       grid, grid_off, cells_cap, slab_best, s_max, P, nullptr, nullptr);
+  if (ARCS) vote_stage_tables(slab, num_rots, cos_tab, sin_tab);
+  vote_slab_item<ARCS, WEIGHTED>(slab, tag, b, s, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
+                                 grid, grid_off, cells_cap, slab_best, s_max, P, nullptr, nullptr);
 }
 
 // Work list of the persistent kernel: one entry (scene | slab << 16) per existing slab, in the order they should start
@@ -550,6 +641,7 @@ __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid
 // Persistent form for throughput-sized batches: one workgroup per CU pulls (scene, slab) items from the work
 // list -- no empty workgroups (the (scene, rank) launch has ~5 per real one, each needing a CU's whole LDS just to
 // exit), list scheduling in the intended order regardless of the dispatcher, the table staged once per CU.
+template <bool WEIGHTED>
 __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_kernel(
     const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off, float res, int num_rots,
     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, const CppfSceneGrid* __restrict__ grids,
@@ -557,13 +649,9 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
     SlabBest* __restrict__ slab_best, int s_max, const uint32_t* __restrict__ list, int* __restrict__ ctl,
     uint32_t* __restrict__ part, int* __restrict__ tickets) {
   extern __shared__ __attribute__((aligned(16))) uint32_t slab[];
-  float2* s_trig = reinterpret_cast<float2*>(slab + VC_SLAB_CELLS);
-  volatile int* s_mark = reinterpret_cast<volatile int*>(slab + VC_SLAB_CELLS + 2 * VC_MAX_LDS_ROTS) +
-                         (threadIdx.x >> 6) * 64;
   __shared__ int s_item;
   int tag = 0;
-  for (int i = threadIdx.x; i < num_rots; i += VC_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
-  s_mark[threadIdx.x & 63] = 0;
+  vote_stage_tables(slab, num_rots, cos_tab, sin_tab);
   const int count = ctl[1], parts = ctl[2];
   for (;;) {
     __syncthreads();                                   // previous item's epilogue is done with the slab and s_item
@@ -574,8 +662,8 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
     const uint32_t e = list[item / parts];                // the parts of a slab are consecutive work items
     const int b = (int)(e & 0xffffu), s = (int)(e >> 16);
     const CppfSceneGrid g = grids[b];
-    vote_slab_item<true>(slab, s_trig, s_mark, tag, b, s, item % parts, parts, g, g.ncell, fr, total, tup_off, res,
-                         num_rots, cos_tab, sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1, part, tickets);
+    vote_slab_item<true, WEIGHTED>(slab, tag, b, s, item % parts, parts, g, g.ncell, fr, total, tup_off, res, num_rots,
+                                   cos_tab, sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1, part, tickets);
   }
 }
 
@@ -736,22 +824,25 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       if (P > pmax) P = pmax;
       if (P < 1) P = 1;
     }
-    const int lds_bytes = VC_SLAB_CELLS * 4 + 2 * VC_MAX_LDS_ROTS * 4 + (VC_THREADS / 64) * 64 * 4;
-    // per device, on first use: the kernels' dynamic-LDS limit and the CU count (read-only afterwards)
+    const int lds_bytes = VC_LDS_WORDS * 4;
+    // per device, on first use: the kernels' dynamic-LDS limit and the CU count (written once under a lock, read-only
+    // afterwards -- the library keeps no other state, see cppf_hip.h)
+    static std::mutex cu_mutex;
     static int cu_count[64] = {0};
     int dev = 0;
     CPPF_HIP(hipGetDevice(&dev));
     const int dslot = dev & 63;
-    if (cu_count[dslot] == 0) {
-      hipDeviceProp_t prop;
-      CPPF_HIP(hipGetDeviceProperties(&prop, dev));
-      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_slab_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      CPPF_HIP(hipFuncSetAttribute((const void*)vote_center_persist_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      cu_count[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+      std::lock_guard<std::mutex> lock(cu_mutex);
+      if (cu_count[dslot] == 0) {
+        hipDeviceProp_t prop;
+        CPPF_HIP(hipGetDeviceProperties(&prop, dev));
+        const void* fns[] = {(const void*)vote_center_slab_kernel<true, false>, (const void*)vote_center_slab_kernel<true, true>,
+                             (const void*)vote_center_slab_kernel<false, false>, (const void*)vote_center_slab_kernel<false, true>,
+                             (const void*)vote_center_persist_kernel<false>, (const void*)vote_center_persist_kernel<true>};
+        for (const void* f : fns) CPPF_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        cu_count[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
     }
     const int num_cus = cu_count[dslot];
     // arcs need >1 slab to pay off and the table in LDS; mode 3 forces the exhaustive sweep (A/B reference)
@@ -787,9 +878,14 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
         CPPF_LAUNCH_CHECK();
       }
       if (frames_only) return CPPF_OK;
-      hipLaunchKernelGGL(vote_center_persist_kernel, dim3(num_cus), dim3(VC_THREADS), lds_bytes, st, frames,
-                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, grid, grid_off, cells_cap, best,
-                         s_max_parts, ws_list, ws_ctl, max_parts > 1 ? ws_grid : (uint32_t*)nullptr, ws_tickets);
+      if (vote_wt)
+        hipLaunchKernelGGL(vote_center_persist_kernel<true>, dim3(num_cus), dim3(VC_THREADS), lds_bytes, st, frames,
+                           total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, grid, grid_off, cells_cap, best,
+                           s_max_parts, ws_list, ws_ctl, max_parts > 1 ? ws_grid : (uint32_t*)nullptr, ws_tickets);
+      else
+        hipLaunchKernelGGL(vote_center_persist_kernel<false>, dim3(num_cus), dim3(VC_THREADS), lds_bytes, st, frames,
+                           total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, grid, grid_off, cells_cap, best,
+                           s_max_parts, ws_list, ws_ctl, max_parts > 1 ? ws_grid : (uint32_t*)nullptr, ws_tickets);
       CPPF_LAUNCH_CHECK();
       hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap, res,
                          out_argmax, out_peak, out_world);
@@ -802,14 +898,15 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
       CPPF_LAUNCH_CHECK();
     }
     if (frames_only) return CPPF_OK;
-    if (arcs)
-      hipLaunchKernelGGL(vote_center_slab_kernel<true>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
-                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
-                         best, s_max_parts, P);
-    else
-      hipLaunchKernelGGL(vote_center_slab_kernel<false>, dim3(B, P, s_max), dim3(VC_THREADS), lds_bytes, st, frames,
-                         total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap,
-                         best, s_max_parts, P);
+    {
+      const dim3 gr(B, P, s_max), bl(VC_THREADS);
+#define VC_LAUNCH_SLAB(A, W)                                                                                          \
+  hipLaunchKernelGGL((vote_center_slab_kernel<A, W>), gr, bl, lds_bytes, st, frames, total_tuples, tup_off, res32,       \
+                     num_rots, cos_tab, sin_tab, grids, g_use, goff_use, cells_cap, best, s_max_parts, P)
+      if (arcs) { if (vote_wt) VC_LAUNCH_SLAB(true, true); else VC_LAUNCH_SLAB(true, false); }
+      else      { if (vote_wt) VC_LAUNCH_SLAB(false, true); else VC_LAUNCH_SLAB(false, false); }
+#undef VC_LAUNCH_SLAB
+    }
     CPPF_LAUNCH_CHECK();
     if (P == 1) {
       hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap,
