@@ -294,7 +294,12 @@ extern "C" int cppf_encode_tuples_shot_f16(int B, const float* pts, const float*
   if (total_tuples <= 0) return CPPF_OK;
   const int np = k * (k - 1) / 2;
   const int64_t per_scene = (total_tuples + B - 1) / B * (np + k * (feat_dim / 8));
-  if (per_scene >= 0x7fffffffLL) return CPPF_EUNSUPPORTED;
+  // item ids are 32-bit per scene and the batch may be ragged: bound by the worst case (one scene holds every tuple)
+  if (total_tuples * (int64_t)(np + k * (feat_dim / 8)) >= 0x7fffffffLL) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_encode_tuples_shot_f16: %lld tuples x %d items exceed 2^31; split the batch",
+             (long long)total_tuples, np + k * (feat_dim / 8));
+    return CPPF_EUNSUPPORTED;
+  }
   int64_t bx = (per_scene + 255) / 256;
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
@@ -316,8 +321,10 @@ extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* nor
   int64_t bx = (per_scene + 255) / 256;
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
-  if (per_scene >= 0x7fffffffLL) {
-    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_encode_tuples_shot: more than 2^31 items per scene");
+  // item ids are 32-bit per scene and the batch may be ragged: bound by the worst case (one scene holds every tuple)
+  if (total_tuples * (int64_t)(np + k * (feat_dim / 4)) >= 0x7fffffffLL) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_encode_tuples_shot: %lld tuples x %d items exceed 2^31; split the batch",
+             (long long)total_tuples, np + k * (feat_dim / 4));
     return CPPF_EUNSUPPORTED;
   }
   if (k == 5 && feat_dim == 64)

@@ -19,16 +19,24 @@ from . import _lib, ops
 
 _L = _lib.load()
 
-_WS = {}
+_WS = {}          # (device, stream) -> scratch buffer
+_PREPARED = {}    # (device, stream) -> (B, n, pts pointer) of the last prepare_device, checked by describe_device
+
+
+def _key(dev):
+    return (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
 
 
 def _workspace(B, n, dev):
-    """One cached scratch buffer per (device): grown on demand, reused by every call on that device."""
+    """One cached scratch buffer per (device, stream): grown on demand and reused by every call issued on that stream,
+    so calls on different streams (or threads using their own streams) never share scratch memory."""
     need = _L.cppf_shot352_workspace_bytes(B, n)
-    ws = _WS.get(str(dev))
+    key = _key(dev)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-        _WS[str(dev)] = ws
+        _WS[key] = ws
+        _PREPARED.pop(key, None)          # a new buffer holds no prepared state
     return ws
 
 
@@ -42,6 +50,7 @@ def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
     out_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
     out_rf = torch.empty((n, 9), dtype=torch.float32, device=dev) if want_rf else None
     ws = _workspace(B, n, dev)
+    _PREPARED.pop(_key(dev), None)
     _lib.check(_L.cppf_shot352(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
                                ops._p(out_shot), ops._p(out_normal), ops._p(out_rf), ops._p(ws), ws.numel(),
                                ops._stream()), "cppf_shot352")
@@ -54,6 +63,7 @@ def normals_device(pts, pt_off, normal_r, out=None):
     n = pts.shape[0]
     out = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out is None else out
     ws = _workspace(pt_off.numel() - 1, n, pts.device)
+    _PREPARED.pop(_key(pts.device), None)
     _lib.check(_L.cppf_estimate_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r),
                                         ops._p(out), ops._p(ws), ws.numel(), ops._stream()), "cppf_estimate_normals")
     return out
@@ -63,6 +73,7 @@ def descriptors_device(pts, pt_off, normals, shot_r, out=None):
     n = pts.shape[0]
     out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
     ws = _workspace(pt_off.numel() - 1, n, pts.device)
+    _PREPARED.pop(_key(pts.device), None)
     _lib.check(_L.cppf_shot352_from_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, ops._p(normals),
                                             C.c_float(shot_r), ops._p(out), None, ops._p(ws), ws.numel(),
                                             ops._stream()), "cppf_shot352_from_normals")
@@ -77,6 +88,7 @@ def prepare_device(pts, pt_off, normal_r, shot_r, out_normal=None):
     ws = _workspace(B, n, pts.device)
     _lib.check(_L.cppf_shot_prepare(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
                                     ops._p(out_normal), ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_prepare")
+    _PREPARED[_key(pts.device)] = (B, n, pts.data_ptr(), float(shot_r), ws.data_ptr())
     return out_normal
 
 
@@ -87,6 +99,11 @@ def describe_device(pts, pt_off, normals, shot_r, out=None, nan_to_zero=False):
     B = pt_off.numel() - 1
     out = torch.empty((n, 352), dtype=torch.float32, device=pts.device) if out is None else out
     ws = _workspace(B, n, pts.device)
+    # the workspace carries prepare_device's cell tables, frames and neighbour lists: it must be the same buffer, on the
+    # same stream, prepared for the same cloud, with no other SHOT call in between
+    if _PREPARED.get(_key(pts.device)) != (B, n, pts.data_ptr(), float(shot_r), ws.data_ptr()):
+        raise _lib.CppfError("describe_device must directly follow prepare_device on the same stream with the same "
+                             "points, batch layout and descriptor radius")
     _lib.check(_L.cppf_shot_describe(B, ops._p(pts), ops._p(pt_off), n, ops._p(normals), C.c_float(shot_r),
                                      int(bool(nan_to_zero)), ops._p(out), None, ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_describe")
     return out

@@ -1,11 +1,14 @@
-"""Writes profiles/r1_summary.md from the committed rocprofv3 kernel stats, PMC traffic passes and bench line."""
-import csv, json, os
+"""Writes profiles/<round>_summary.md from the committed rocprofv3 kernel stats, PMC traffic passes and bench line.
+usage: python scratch/profile_table.py [r2]"""
+import csv, json, os, sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "r2"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
-stats = list(csv.DictReader(open(os.path.join(P, "r1_kernel_stats.csv"))))
-pmc = json.load(open(os.path.join(P, "r1_pmc_traffic.json")))
-bench = json.load(open(os.path.join(P, "r1_bench_n1.json")))
-steps = 7                                   # bench.py --steps 5 --warmup 2 under rocprofv3
+stats = list(csv.DictReader(open(os.path.join(P, RND + "_kernel_stats.csv"))))
+pmc = json.load(open(os.path.join(P, RND + "_pmc_traffic.json")))
+bench = json.load(open(os.path.join(P, RND + "_bench_n1.json")))
+# passes of the step under rocprofv3 = launches of a kernel that runs exactly once per pass (priming + warm-up + timed)
+steps = next(int(r["Calls"]) for r in stats if r["Name"].startswith("vote_worklist_kernel") or "vote_worklist_kernel" in r["Name"])
 rows, gemm_ns, elt_ns = [], 0.0, 0.0
 for r in stats:
     n = r["Name"]
@@ -18,12 +21,12 @@ for r in stats:
     hbm = (2 * t.get("FETCH_SIZE_KB_per_launch", 0) + t.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 if t else None
     rows.append((key, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, hbm))
 rows.sort(key=lambda x: -x[1] * x[2])
-with open(os.path.join(P, "r1_summary.md"), "w") as f:
-    f.write("# Round-1 profile summary (one MI355X, `python bench.py --steps 5 --warmup 2`)\n\n")
-    f.write("Sources: `r1_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `r1_pmc_traffic.json` = "
+with open(os.path.join(P, RND + "_summary.md"), "w") as f:
+    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --no-reference-order`, %d passes incl. priming)\n\n" % (RND, steps))
+    f.write("Sources: `%s_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `%s_pmc_traffic.json` = "
             "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (KB per launch; HBM bytes = "
-            "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `r1_bench_n1.json` = the bench line of the same build. "
-            "Regenerate with `scratch/refresh_profiles.sh` + `scratch/profile_table.py`.\n\n")
+            "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `%s_bench_n1.json` = the bench line of the same build. "
+            "Regenerate with `scratch/refresh_profiles.sh` + `scratch/profile_table.py`.\n\n" % (RND, RND, RND))
     f.write("Bench: %.0f scenes/s, %.2f ms/step (64 scenes); dominant HIP kernel `%s` %.3f ms per launch, "
             "roofline %.0f GB/s of %d (frac %.3f), PMC traffic %.0f MB per launch.\n\n"
             % (bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_name"], bench["roofline"]["launch_ms"],
@@ -39,4 +42,4 @@ with open(os.path.join(P, "r1_summary.md"), "w") as f:
     f.write("| hipBLASLt / rocBLAS GEMMs (tuple MLP + point encoder, PyTorch) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
     f.write("| PyTorch elementwise / copies | | | %.3f | | |\n" % (elt_ns / steps / 1e6))
     f.write("\nPer-stage HIP-event times of the bench (ms per step): `%s`\n" % json.dumps(bench["roofline"]["per_stage_ms"]))
-print(open(os.path.join(P, "r1_summary.md")).read())
+print(open(os.path.join(P, RND + "_summary.md")).read())

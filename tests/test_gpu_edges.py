@@ -212,3 +212,35 @@ def test_vote_center_persistent_equals_per_workgroup_and_global_paths():
         for a, b_ in zip(outs[0][3], other[3]):
             assert np.array_equal(a, b_)
     assert outs[0][1].min() > 10
+
+
+def test_shot_describe_refuses_a_workspace_it_was_not_prepared_for():
+    """The two-call SHOT form keeps its state (cell tables, frames, neighbour lists) in a per-(device, stream) workspace:
+    describe_device raises instead of reading another call's state; separate streams get separate workspaces."""
+    from cppf2_amd._lib import CppfError
+    sc = synth.make_scene(3, 0, 900)
+    pts = torch.as_tensor(sc["pc"]).cuda()
+    off = ops._offsets([900], pts.device)
+    other = torch.as_tensor(synth.make_scene(3, 1, 500)["pc"]).cuda()
+    off2 = ops._offsets([500], pts.device)
+    nrm = shot.prepare_device(pts, off, 0.02, 0.02)
+    want = shot.describe_device(pts, off, nrm, 0.02)
+    shot.compute_device(other, off2, 0.02, 0.02)                  # another SHOT call on the same stream: state is gone
+    with pytest.raises(CppfError):
+        shot.describe_device(pts, off, nrm, 0.02)
+    shot.prepare_device(pts, off, 0.02, 0.02)
+    with pytest.raises(CppfError):
+        shot.describe_device(pts, off, nrm, 0.015)                # other radius than the one prepared for
+    # a second stream has its own workspace: interleaving the halves of two clouds on two streams is fine
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    n1 = shot.prepare_device(pts, off, 0.02, 0.02)
+    with torch.cuda.stream(s2):
+        n2 = shot.prepare_device(other, off2, 0.02, 0.02)
+    a = shot.describe_device(pts, off, n1, 0.02)
+    with torch.cuda.stream(s2):
+        b = shot.describe_device(other, off2, n2, 0.02)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(want))
+    ref_b, _ = shot.compute_device(other, off2, 0.02, 0.02)
+    assert torch.allclose(torch.nan_to_num(b), torch.nan_to_num(ref_b), atol=1e-6)
