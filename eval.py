@@ -276,12 +276,16 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
     record = metrics.make_result_record(np.array(all_cls, dtype=np.int64), np.stack(all_RT) if n else np.zeros((0, 4, 4)),
                                         np.stack(all_scale) if n else np.zeros((0, 3)), None, **gt)
     if gt:
-        aps = metrics.pose_mAP([record])                # eval.py:400-410 (degree / cm part)
+        # eval.py:400-411: degree / cm AP over the instances matched at 3-D IoU > 0.1, and the 3-D IoU AP itself
+        thr = np.linspace(0, 1, 101)
+        iou_aps, aps = metrics.degree_cm_mAP([record], metrics.SYNSET_NAMES, (5, 10, 15), (5, 10, 15), thr, 0.1, True)
         report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): float(np.mean([aps[category2id[c], i_, j_] for c in categories]))
                              for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
         report["pose_AP_per_category"] = {c: {"%ddeg_%dcm" % (d_, s_): float(aps[category2id[c], i_, j_])
                                               for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
                                           for c in categories}
+        report["iou_AP"] = {"IoU%d" % t_: float(np.mean([iou_aps[category2id[c], t_] for c in categories]))
+                            for t_ in (25, 50, 75)}
     if out_pkl:
         import pickle
         with open(out_pkl, "wb") as f:

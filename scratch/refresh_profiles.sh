@@ -5,6 +5,7 @@ cd /tmp; rm -rf $R/gpurun_out/prof_cur
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cur -o $RND -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order > $R/gpurun_out/prof_cur.log 2>&1
 cd $R
 bash scratch/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1
+mkdir -p gpurun_out/profiles_new
 cp gpurun_out/pmc_traffic.json profiles/${RND}_pmc_traffic.json 2>/dev/null
 cp gpurun_out/prof_cur/${RND}_kernel_stats.csv profiles/${RND}_kernel_stats.csv 2>/dev/null
 python3 bench.py > gpurun_out/bench_cur.json 2> gpurun_out/bench_cur.err
@@ -12,3 +13,5 @@ tail -1 gpurun_out/bench_cur.json > profiles/${RND}_bench_n1.json
 tail -1 gpurun_out/bench_cur.json | cut -c1-400
 head -25 gpurun_out/prof_cur/${RND}_kernel_stats.csv | cut -c1-150
 python3 scratch/profile_table.py $RND > /dev/null
+# only gpurun_out/ travels back from the GPU box: leave copies there (copy them into profiles/ and commit)
+cp profiles/${RND}_* gpurun_out/profiles_new/

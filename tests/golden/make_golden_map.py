@@ -74,14 +74,48 @@ def main():
     import copy
     results = make_results()
     names = ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+    thr = np.linspace(0, 1, 101)
     with tempfile.TemporaryDirectory() as d:
         iou_aps, pose_aps = ref.util.compute_degree_cm_mAP(copy.deepcopy(results), names, d, degree_thresholds=[5, 10, 15],
                                                            shift_thresholds=[5, 10, 15],
-                                                           iou_3d_thresholds=np.linspace(0, 1, 101),
+                                                           iou_3d_thresholds=thr,
                                                            iou_pose_thres=0.1, use_matches_for_pose=False, num_proc=2)
+    # the call eval.py:400-411 makes: pose AP over the instances matched at 3-D IoU > 0.1
+    with tempfile.TemporaryDirectory() as d:
+        iou_aps_m, pose_aps_m = ref.util.compute_degree_cm_mAP(copy.deepcopy(results), names, d, degree_thresholds=[5, 10, 15],
+                                                               shift_thresholds=[5, 10, 15], iou_3d_thresholds=thr,
+                                                               iou_pose_thres=0.1, use_matches_for_pose=True, num_proc=2)
+    # oriented-box IoU on its own (utils/util.py:475-547 -> utils/iou.py, utils/box.py): random box pairs per class rule
+    rng = np.random.RandomState(5)
+    pairs = []
+    for k in range(60):
+        RT1, RT2 = np.eye(4), np.eye(4)
+        RT1[:3, :3] = rand_rot(rng) * rng.uniform(0.5, 2.0)
+        RT1[:3, 3] = rng.randn(3) * 0.1
+        RT2[:3, :3] = (small_rot(rng, rng.choice([0.0, 3.0, 20.0, 70.0])) @ RT1[:3, :3]) * rng.uniform(0.8, 1.2)
+        RT2[:3, 3] = RT1[:3, 3] + rng.randn(3) * rng.choice([0.0, 0.02, 0.1, 0.5])
+        s1 = rng.uniform(0.2, 1.0, 3)
+        s2 = s1 * rng.uniform(0.7, 1.3, 3)
+        cls = names[1 + k % 6]
+        hv = int(rng.randint(0, 2))
+        iou = ref.util.compute_3d_iou_new(RT1.copy(), RT2.copy(), s1.copy(), s2.copy(), hv, cls, cls)
+        pairs.append(dict(RT1=RT1, RT2=RT2, s1=s1, s2=s2, cls=cls, hv=hv, iou=float(iou)))
+    # identical, disjoint, contained, face-touching
+    I = np.eye(4)
+    sh = np.eye(4); sh[:3, 3] = [2.0, 0, 0]
+    half = np.eye(4); half[:3, 3] = [0.5, 0, 0]
+    for RT1, RT2, s1, s2 in ((I, I, [1, 1, 1], [1, 1, 1]), (I, sh, [1, 1, 1], [1, 1, 1]), (I, I, [1, 1, 1], [.5, .4, .3]),
+                             (I, half, [1, 1, 1], [1, 1, 1]), (I, half, [1.0, 2.0, 0.5], [1.0, 1.0, 1.0])):
+        s1, s2 = np.array(s1, float), np.array(s2, float)
+        iou = ref.util.compute_3d_iou_new(RT1.copy(), RT2.copy(), s1.copy(), s2.copy(), 1, "laptop", "laptop")
+        pairs.append(dict(RT1=RT1.copy(), RT2=RT2.copy(), s1=s1, s2=s2, cls="laptop", hv=1, iou=float(iou)))
+    print("pair IoUs:", [round(p_["iou"], 4) for p_ in pairs])
     with open(os.path.join(HERE, "map_results.pkl"), "wb") as f:
-        pickle.dump(dict(results=results, synset_names=names, pose_aps=pose_aps), f, protocol=4)
+        pickle.dump(dict(results=results, synset_names=names, pose_aps=pose_aps, iou_aps=iou_aps, iou_thresholds=thr,
+                         pose_aps_matched=pose_aps_m, iou_aps_matched=iou_aps_m, iou_pairs=pairs), f, protocol=4)
     print(pose_aps[-1])
+    print(pose_aps_m[-1])
+    print("IoU25 / IoU50 / IoU75 mean AP:", iou_aps[-1, 25], iou_aps[-1, 50], iou_aps[-1, 75])
 
 
 if __name__ == "__main__":

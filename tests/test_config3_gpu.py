@@ -123,7 +123,7 @@ def test_eval_main_all_six_categories(ev, tmp_path):
     rec = pickle.load(open(tmp_path / "r.pkl", "rb"))
     assert rec["pred_RTs"].shape == (12, 4, 4) and rec["pred_class_ids"].tolist() == [1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6]
     from cppf2_amd import metrics
-    aps = metrics.pose_mAP([rec])
+    _, aps = metrics.degree_cm_mAP([rec], use_matches_for_pose=True)
     for c in rep["categories"]:
         assert abs(aps[ev.category2id[c], 2, 2] - rep["pose_AP_per_category"][c]["15deg_15cm"]) < 1e-12
     rep2 = ev.main(num_pairs=3000, num_rots=36, num_scenes=1, num_points=512, opt=False, categories="mug,can",

@@ -92,7 +92,9 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     from cppf2_amd import metrics
     assert set(metrics.RESULT_KEYS) <= set(res) and res["gt_RTs"].shape == (3, 4, 4)
     assert rep["pose_AP"]["15deg_15cm"] >= rep["pose_AP"]["5deg_5cm"] >= 0.0
-    assert abs(metrics.pose_mAP([res])[1, 0, 0] - rep["pose_AP"]["5deg_5cm"]) < 1e-12
+    _, aps_m = metrics.degree_cm_mAP([res], use_matches_for_pose=True)          # the call eval.py:400-411 makes
+    assert abs(aps_m[1, 0, 0] - rep["pose_AP"]["5deg_5cm"]) < 1e-12
+    assert 0.0 <= rep["iou_AP"]["IoU75"] <= rep["iou_AP"]["IoU50"] <= rep["iou_AP"]["IoU25"] <= 1.0
     for r in rep["results"]:
         assert r["model"] in ("dino", "shot") and np.isfinite(r["loss"])
     # branch gating keeps the reference's swapped names: geo_branch gates the DINO model

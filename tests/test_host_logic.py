@@ -165,3 +165,43 @@ def test_pose_map_scorer_matches_the_reference_toolkit():
     perfect = [metrics.make_result_record(r["gt_class_ids"], r["gt_RTs"], r["gt_scales"], None, r["gt_class_ids"],
                                           r["gt_RTs"], r["gt_scales"], r["gt_handle_visibility"]) for r in g["results"]]
     assert np.allclose(metrics.pose_mAP(perfect, g["synset_names"])[1:, 0, 0], 1.0)
+
+
+def test_oriented_box_iou_matches_the_reference_toolkit():
+    """box_iou_3d / iou_3d against compute_3d_iou_new (utils/util.py:475-547 -> utils/iou.py, utils/box.py) on random and
+    special box pairs, every class symmetry rule (golden: tests/golden/make_golden_map.py)."""
+    import pickle
+    from cppf2_amd import metrics
+    with open(os.path.join(GOLDEN, "map_results.pkl"), "rb") as f:
+        g = pickle.load(f)
+    worst = 0.0
+    for p in g["iou_pairs"]:
+        got = metrics.iou_3d(p["RT1"], p["RT2"], p["s1"], p["s2"], p["hv"], p["cls"], p["cls"])
+        worst = max(worst, abs(got - p["iou"]))
+    assert worst < 1e-9, worst
+    tail = [p["iou"] for p in g["iou_pairs"][-5:]]
+    assert abs(tail[0] - 1.0) < 1e-12 and tail[1] == 0.0 and abs(tail[2] - 0.06) < 1e-12 and abs(tail[3] - 1 / 3) < 1e-12
+    # symmetric class: a rotation about y that is a multiple of 10 degrees does not change the score
+    p = g["iou_pairs"][0]
+    assert p["cls"] == "bottle"
+    turned = p["RT1"] @ metrics._y_rotation(np.radians(50.0))
+    assert abs(metrics.iou_3d(turned, p["RT2"], p["s1"], p["s2"], 1, "bottle", "bottle") - p["iou"]) < 1e-9
+
+
+def test_degree_cm_map_with_iou_matches_the_reference_toolkit():
+    """compute_degree_cm_mAP's two outputs (3-D IoU AP at 101 thresholds, pose AP) for use_matches_for_pose False and
+    True (the latter is what eval.py:400-411 calls) on 40 synthetic images."""
+    import pickle
+    from cppf2_amd import metrics
+    with open(os.path.join(GOLDEN, "map_results.pkl"), "rb") as f:
+        g = pickle.load(f)
+    iou_aps, pose_aps = metrics.degree_cm_mAP(g["results"], g["synset_names"], (5, 10, 15), (5, 10, 15),
+                                              g["iou_thresholds"], 0.1, False)
+    assert np.allclose(iou_aps, g["iou_aps"], rtol=0, atol=1e-9, equal_nan=True)
+    assert np.allclose(pose_aps, g["pose_aps"], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(pose_aps, metrics.pose_mAP(g["results"], g["synset_names"]), equal_nan=True)
+    iou_m, pose_m = metrics.degree_cm_mAP(g["results"], g["synset_names"], (5, 10, 15), (5, 10, 15), g["iou_thresholds"],
+                                          0.1, True)
+    assert np.allclose(iou_m, g["iou_aps_matched"], rtol=0, atol=1e-9, equal_nan=True)
+    assert np.allclose(pose_m, g["pose_aps_matched"], rtol=0, atol=1e-12, equal_nan=True)
+    assert pose_m[-1, 0, 0] > pose_aps[-1, 0, 0] and 0 < iou_aps[-1, 75] < iou_aps[-1, 50] < iou_aps[-1, 25] <= 1
