@@ -244,3 +244,46 @@ def test_shot_describe_refuses_a_workspace_it_was_not_prepared_for():
     assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(want))
     ref_b, _ = shot.compute_device(other, off2, 0.02, 0.02)
     assert torch.allclose(torch.nan_to_num(b), torch.nan_to_num(ref_b), atol=1e-6)
+
+
+def test_vote_center_64_scene_full_size_batch():
+    """BASELINE-size batch (64 scenes x 4096 points x 20 000 tuples x 180 rotations): the throughput configuration of the
+    persistent vote kernel (B > 48: one part per slab, no merge area).  Full grids of all 64 scenes equal the global-atomic
+    path's (the independent A/B implementation) cell for cell; two scenes are checked against the oracle's int64 grid."""
+    from oracle import cppf_oracle as O
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    B, N, T, R = 64, 4096, 20000, 180
+    scs = [synth.make_scene(0, b, N) for b in range(B)]
+    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scs])).to(dev)
+    idx = ops.sample_tuples(N, T, 5, 0, tuple(range(B)))
+    canon = torch.from_numpy(np.concatenate([s["pc_canon"] for s in scs])).to(dev)
+    base = (torch.arange(B, device=dev, dtype=torch.int64) * N).repeat_interleave(T)
+    coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(B * T, 6)
+    pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
+    kb = torch.arange(32, device=dev, dtype=torch.float32)
+    lg = (-0.5 * ((kb[None, None, :] - pos[..., None]) / 0.6) ** 2).contiguous()
+    u = ops.philox_uniform(T, 6, 0, 1, tuple(range(B)))
+    outs = []
+    for mode in (0, 2):
+        pipe = VotingPipeline([N] * B, [T] * B, num_rots=R, vote_mode=mode, cells_cap=1 << 19)
+        pipe.decode(pts, idx, lg, u)
+        grid = torch.zeros(B * pipe.cells_cap, dtype=torch.int32, device=dev)
+        goff = torch.arange(B, dtype=torch.int64, device=dev) * pipe.cells_cap
+        pipe.vote_center(pts, idx, grid=grid, grid_off=goff)
+        torch.cuda.synchronize()
+        outs.append((pipe.argmax.cpu().numpy().copy(), pipe.peak.cpu().numpy().copy(), pipe.world.cpu().numpy().copy(), grid,
+                     pipe.grids.cpu().numpy().view(np.int32).reshape(B, 8).copy(), pipe.tr.cpu().numpy().copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][3], outs[1][3])                       # 64 full grids, cell for cell
+    ncell = outs[0][4][:, 6]
+    assert ncell.min() > 100000 and ncell.max() <= (1 << 19) and outs[0][1].min() > 500
+    g = outs[0][3].cpu().numpy().reshape(B, -1)
+    trig = (pipe.cs.cpu().numpy(), pipe.sn.cpu().numpy())
+    idx_np = idx.cpu().numpy()
+    for b in (0, 37):
+        sl = slice(b * T, (b + 1) * T)
+        grid_o, cand = O.vote_center(scs[b]["pc"], outs[0][5][sl], 2e-3, idx_np[sl][:, :2], R, trig=trig)
+        assert grid_o.size == ncell[b] and np.array_equal(grid_o.reshape(-1), g[b, :ncell[b]].astype(np.int64))
+        assert int(np.argmax(grid_o)) == int(outs[0][0][b]) and np.array_equal(cand, outs[0][2][b])
