@@ -434,6 +434,10 @@ extern "C" int cppf_encode_tuples_dino(int B, const float* tables, int k, int D,
 
 // NB > 0: bin count known at compile time, the CDF lives in registers.  NB == 0: generic bin count,
 // three passes over the (L1-resident) logit line instead of a runtime-indexed array (which would spill).
+// Each thread reads its own 128-byte row with 8 consecutive 16-byte loads -- one cache line per thread, every byte of
+// it used.  (Fetching the block's rows with lane-consecutive loads and transposing them through padded LDS was built
+// and measured: 0.39 ms instead of 0.23 ms at 64 x 20 000 tuples without a prior; the line-per-thread form already
+// moves 4.9 TB/s.)
 template <int NB>
 __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
     int B, const float* __restrict__ logits, const float* __restrict__ prior, int nb_rt,
