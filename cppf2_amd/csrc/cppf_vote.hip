@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
 
 // float32 counts of one (scene, axis): per chunk, the float64 sum of its sub-block partials in sub-block order, one
 // float32 rounding per chunk (eval.py:45), then first maximum
-__global__ __launch_bounds__(256) void rot_bins_fold_kernel(const double* __restrict__ partial, int nblk,
+__global__ __launch_bounds__(1024) void rot_bins_fold_kernel(const double* __restrict__ partial, int nblk,
                                                             int sub_blocks, int nax, int S, int B,
                                                             float* __restrict__ counts, int32_t* __restrict__ top_idx,
                                                             float* __restrict__ top_count) {
@@ -1442,7 +1442,14 @@ __global__ __launch_bounds__(256) void rot_bins_fold_kernel(const double* __rest
     float c = 0.0f;
     for (int i0 = 0; i0 < nblk; i0 += sub_blocks) {
       double acc = 0.0;
-      for (int i = i0; i < i0 + sub_blocks; ++i) acc += part[i * bstride + s];
+      for (int k0 = 0; k0 < sub_blocks; k0 += 8) {
+        // 8 independent loads in flight, then their sum in sub-block order (absent ones add an exact 0.0)
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (k0 + k < sub_blocks) ? part[(i0 + k0 + k) * bstride + s] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+      }
       c = (float)((double)c + acc);
     }
     counts[((int64_t)a * B + b) * S + s] = c;
@@ -1454,8 +1461,8 @@ __global__ __launch_bounds__(256) void rot_bins_fold_kernel(const double* __rest
     const int oi = __shfl_xor(besti, off);
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
-  __shared__ float s_b[4];
-  __shared__ int s_i[4];
+  __shared__ float s_b[16];
+  __shared__ int s_i[16];
   if (wave_lane() == 0) { s_b[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = besti; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1593,7 +1600,8 @@ static int rot_bins_impl(int nax, int B, const float* pts, const int32_t* pt_off
                          pl.max_pairs, num_rots, cos_tab, sin_tab, sphere, S, cos_thr, (const int4*)bin_lut, lut_rows,
                          lut_cols, bmm_size, partial);
     CPPF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rot_bins_fold_kernel, dim3(B, nax), dim3(256), 0, st, partial, pl.nblk, pl.sub, nax, S, B, counts,
+    const int fold_threads = S >= 1024 ? 1024 : ((S + 63) / 64) * 64;          // one bin per thread when they fit
+    hipLaunchKernelGGL(rot_bins_fold_kernel, dim3(B, nax), dim3(fold_threads), 0, st, partial, pl.nblk, pl.sub, nax, S, B, counts,
                        top_idx, top_count);
     CPPF_LAUNCH_CHECK();
     return CPPF_OK;
@@ -1751,6 +1759,7 @@ extern "C" int cppf_sphere_counts(const float* cand, int64_t M, const double* wt
 // =============================================================================================
 // a11. pose assembly (eval.py:295-313) + lower median of the scale head over kept pairs (eval.py:309)
 // =============================================================================================
+#define ASM_STAGE 4096
 __global__ __launch_bounds__(256) void assemble_pose_kernel(
     const float* __restrict__ sphere, const int32_t* __restrict__ up_idx, const float* __restrict__ up_count,
     const int32_t* __restrict__ right_idx, const float* __restrict__ right_count, int up_axis, int right_axis,
@@ -1769,11 +1778,28 @@ __global__ __launch_bounds__(256) void assemble_pose_kernel(
     __shared__ int s_misc[4];
     const int t0 = tup_off[b];
     const int target = (kept - 1) / 2;
+    // the kept pairs' rows are scattered over the [T,3] scale-head output: fetch them once (order-preserving keys) and
+    // select from LDS; longer lists than the staging area select straight from memory
+    __shared__ uint32_t s_keys[3][ASM_STAGE];
+    const bool staged = kept <= ASM_STAGE;
+    if (staged) {
+      for (int i = threadIdx.x; i < kept; i += blockDim.x) {
+        const float* row = pred_scales + (int64_t)(t0 + kept_tuple[t0 + i]) * 3;
+        s_keys[0][i] = float_key(row[0]); s_keys[1][i] = float_key(row[1]); s_keys[2][i] = float_key(row[2]);
+      }
+      __syncthreads();
+    }
     for (int col = 0; col < 3; ++col) {
       int n_le;
-      const uint32_t k = radix_select_keys(
-          [=](int i) { return float_key(pred_scales[(int64_t)(t0 + kept_tuple[t0 + i]) * 3 + col]); }, kept, target,
-          s_hist, s_misc, &n_le);
+      uint32_t k;
+      if (staged) {
+        const uint32_t* keys = s_keys[col];
+        k = radix_select_keys([=](int i) { return keys[i]; }, kept, target, s_hist, s_misc, &n_le);
+      } else {
+        k = radix_select_keys(
+            [=](int i) { return float_key(pred_scales[(int64_t)(t0 + kept_tuple[t0 + i]) * 3 + col]); }, kept, target,
+            s_hist, s_misc, &n_le);
+      }
       if (threadIdx.x == 0) s_med[col] = key_float(k);
     }
   }
