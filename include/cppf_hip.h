@@ -15,7 +15,9 @@
  *  - all pointers are DEVICE pointers unless the name starts with h_ (host).  The caller
  *    owns every buffer (inputs, outputs, workspace); the library allocates nothing.
  *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); functions
- *    are re-entrant; there is no global mutable state.
+ *    are re-entrant.  The only process-wide state is a per-device cache written once under a mutex on
+ *    first use (CU count, the vote kernels' dynamic-LDS attribute); calls keep their state in the caller's
+ *    workspace (cppf_shot_prepare -> cppf_shot_describe share one: same workspace, same stream, in that order).
  *  - batch-first: B independent scenes per call.  Ragged scenes are described by device
  *    offset arrays pt_off[B+1] (points) and tup_off[B+1] (tuples), int32, plus host-side
  *    maxima used only to size launches.
