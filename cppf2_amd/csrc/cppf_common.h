@@ -132,6 +132,29 @@ __device__ __forceinline__ void target_pair(float ax, float ay, float az, float 
   }
 }
 
+// atan2 where an angle only selects a bin / cell (SHOT interpolation angles, rotation-vote lookup cells): octant reduction + degree-8 polynomial in t^2 (near-minimax fit of
+// atan(t)/t on [0, 1], max abs error 1.3e-7 rad evaluated in float = the rounding of the result itself), one v_rcp.
+// Inputs are never both zero here (magnitudes below 1e-30 were flushed and the caller tests the pair).
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float s = t * t;
+  float p = 0.0028340641874819994f;
+  p = fmaf(p, s, -0.016005029901862144f);
+  p = fmaf(p, s, 0.042587608098983765f);
+  p = fmaf(p, s, -0.07495445758104324f);
+  p = fmaf(p, s, 0.10636754333972931f);
+  p = fmaf(p, s, -0.14202570915222168f);
+  p = fmaf(p, s, 0.19992484152317047f);
+  p = fmaf(p, s, -0.3333306610584259f);
+  p = fmaf(p, s, 1.0f);
+  float r = p * t;
+  r = (ay > ax) ? 1.5707963267948966f - r : r;
+  r = (x < 0.0f) ? 3.141592653589793f - r : r;
+  return copysignf(r, y);
+}
+
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (CPPF_WAVE - 1); }
 
 // first-maximum reduction on (value, index) pairs: larger value wins, ties -> smaller index.

@@ -128,28 +128,7 @@ __device__ __forceinline__ float sqdist3(float px, float py, float pz, float qx,
 #define RAD_135 2.3561944901923449288469825374596
 #define RAD_PI_7_8 2.7488935718910690836548129603691
 
-// atan2 for the two interpolation angles: octant reduction + degree-8 polynomial in t^2 (near-minimax fit of
-// atan(t)/t on [0, 1], max abs error 1.3e-7 rad evaluated in float = the rounding of the result itself), one v_rcp.
-// Inputs are never both zero here (magnitudes below 1e-30 were flushed and the caller tests the pair).
-__device__ __forceinline__ float shot_atan2(float y, float x) {
-  const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
-  const float t = mn * __builtin_amdgcn_rcpf(mx);
-  const float s = t * t;
-  float p = 0.0028340641874819994f;
-  p = fmaf(p, s, -0.016005029901862144f);
-  p = fmaf(p, s, 0.042587608098983765f);
-  p = fmaf(p, s, -0.07495445758104324f);
-  p = fmaf(p, s, 0.10636754333972931f);
-  p = fmaf(p, s, -0.14202570915222168f);
-  p = fmaf(p, s, 0.19992484152317047f);
-  p = fmaf(p, s, -0.3333306610584259f);
-  p = fmaf(p, s, 1.0f);
-  float r = p * t;
-  r = (ay > ax) ? 1.5707963267948966f - r : r;
-  r = (x < 0.0f) ? 3.141592653589793f - r : r;
-  return copysignf(r, y);
-}
+// (atan2 for the two interpolation angles: atan2_poly, cppf_common.h)
 
 // One neighbour's quadrilinear contribution (pcl::SHOTEstimation::interpolateSingleChannel, PCL 1.9.1
 // features/impl/shot.hpp), float arithmetic, written without divergent arms: every interpolation axis (cosine bin,
@@ -199,7 +178,7 @@ __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, fl
     if (has) atomicAdd(&shot[home + (outer ? -2 : 2) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(rd)) * fx_scale));
   }
   {  // elevation: two hemispheres, neighbour only towards the equator
-    const float inc = shot_atan2(__builtin_amdgcn_sqrtf(xf * xf + yf * yf), zf);      // [0, pi], exact at the poles
+    const float inc = atan2_poly(__builtin_amdgcn_sqrtf(xf * xf + yf * yf), zf);      // [0, pi], exact at the poles
     const float R45 = (float)RAD_45, R90 = (float)RAD_90, R135 = (float)RAD_135;
     const bool lower = inc > R90 || (inc == R90 && zf <= 0.0f);
     const float id = (inc - (lower ? R135 : R45)) * (float)(1.0 / RAD_90);
@@ -208,7 +187,7 @@ __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, fl
     if (has) atomicAdd(&shot[home + (lower ? 1 : -1) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(id)) * fx_scale));
   }
   if (yf != 0.0f || xf != 0.0f) {  // azimuth sectors wrap around
-    const float az = shot_atan2(yf, xf);
+    const float az = atan2_poly(yf, xf);
     float ad = (az - (-(float)RAD_PI_7_8 + (float)RAD_45 * (float)(desc >> 2))) * (float)(1.0 / RAD_45);
     ad = fminf(fmaxf(ad, -0.5f), 0.5f);
     w += 1.0f - fabsf(ad);

@@ -1402,7 +1402,9 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
       const float nn = fmaxf(norm3_fused(ux, uy, uz), 1e-7f);
       const float x = ux / nn, y = uy / nn, z = uz / nn;
       if (!(y == y) || !(x == x) || !(z == z)) continue;               // NaN candidate never passes the test
-      float phi = atan2f(z, x);
+      // the angle only selects the lookup cell, whose bin list carries 2e-3 rad of slack (ops.build_bin_lut): the
+      // polynomial atan2 (1.3e-7 rad) is as good as libm's here at a third of the instructions
+      float phi = atan2_poly(z, x);
       phi += (phi < 0.0f) ? 6.2831853071795865f : 0.0f;
       int ci = (int)((1.0f - y) * row_scale), cj = (int)(phi * col_scale);
       ci = min(max(ci, 0), lut_rows - 1);
