@@ -287,3 +287,45 @@ def test_vote_center_64_scene_full_size_batch():
         grid_o, cand = O.vote_center(scs[b]["pc"], outs[0][5][sl], 2e-3, idx_np[sl][:, :2], R, trig=trig)
         assert grid_o.size == ncell[b] and np.array_equal(grid_o.reshape(-1), g[b, :ncell[b]].astype(np.int64))
         assert int(np.argmax(grid_o)) == int(outs[0][0][b]) and np.array_equal(cand, outs[0][2][b])
+
+
+@pytest.mark.parametrize("B,bmm,R", [(20, 100000, 90),     # >= 16 scenes: ~160-pair row blocks, several chunks per scene
+                                     (20, 7001, 36),       # chunk boundaries inside pairs (7001 is not a multiple of 36)
+                                     (5, 4000, 72),        # small-batch plan (32-pair blocks), many chunks
+                                     (3, 100, 90)])        # chunks barely longer than one pair's rotations
+def test_rot_bins_chunk_aligned_blocks_equal_the_exhaustive_sweep(B, bmm, R):
+    """Both rotation votes from the lookup-table kernel (row blocks aligned to the float32 accumulation chunks, one
+    launch for both axes) against the exhaustive sweep and the single-axis entry point on ragged batches: counts are
+    float32 sums folded chunk by chunk (eval.py:41-45), so every chunk boundary must fall where the reference puts it."""
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    rng = np.random.RandomState(B * 1000 + R)
+    Ns = [int(x) for x in rng.randint(300, 1500, B)]
+    Ts = [int(x) for x in rng.randint(800, 9000, B)]
+    Ts[1] = 40                                           # a scene with almost nothing kept
+    scs = [synth.make_scene(4, b, n) for b, n in enumerate(Ns)]
+    pts = torch.from_numpy(np.concatenate([s["pc"] for s in scs])).to(dev)
+    idx = torch.cat([ops.sample_tuples(n, t, 5, 4, (b,)) for b, (n, t) in enumerate(zip(Ns, Ts))])
+    idx[sum(Ts[:2]) + 3, 1] = idx[sum(Ts[:2]) + 3, 0]    # a degenerate pair (|ab| = 0): dropped by vote_rotation
+    lg = torch.cat([torch.from_numpy(synth.teacher_logits(s["pc_canon"], idx[sum(Ts[:b]):sum(Ts[:b + 1])].cpu().numpy(), 32))
+                    for b, s in enumerate(scs)]).to(dev)
+    u = torch.cat([ops.philox_uniform(t, 6, 4, 1, (b,)) for b, t in enumerate(Ts)])
+    pipe = VotingPipeline(Ns, Ts, num_rots=R, bmm_size=bmm, backproj_ratio=0.3)
+    assert pipe.lut is not None
+    pipe.decode(pts, idx, lg, u)
+    pipe.vote_center(pts, idx)
+    pipe.backvote(pts, idx)
+    pipe.rot_bins(pts, idx, use_lut=False)
+    dense, dtop = pipe.counts.cpu().numpy().copy(), pipe.top_idx.cpu().numpy().copy()
+    pipe.counts.zero_()
+    pipe.rot_bins(pts, idx, use_lut=True)
+    fused, ftop = pipe.counts.cpu().numpy().copy(), pipe.top_idx.cpu().numpy().copy()
+    pipe.counts.zero_()
+    pipe.rot_bins_single(pts, idx, 0)
+    pipe.rot_bins_single(pts, idx, 1)
+    single = pipe.counts.cpu().numpy().copy()
+    assert np.array_equal(fused, dense) and np.array_equal(ftop, dtop)
+    assert np.array_equal(single, dense)
+    kept = pipe.kept_count.cpu().numpy()
+    assert kept.min() >= 0 and kept.max() * R > bmm       # at least one scene spans more than one chunk
+    assert dense[:, kept > 0].max() > 0
