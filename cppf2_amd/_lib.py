@@ -69,6 +69,7 @@ SIGNATURES = {
                            _p, _p, _p, _p, _i64, _p]),
     "cppf_rot_bins2": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
                             _p, _p, _p, _p, _i64, _p]),
+    "cppf_kept_rows": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),
     "cppf_refine_pose": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p]),

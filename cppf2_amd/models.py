@@ -199,12 +199,21 @@ class BeyondCPPFDino(nn.Module):
         coord = ops.encode_tuples_coord(points, idx)
         return torch.cat([coord, desc_part], -1)
 
-    def forward(self, points, point_descs, point_idxs_all):
-        inputs = self.prepare_tuple_inputs(points, point_descs, point_idxs_all)
+    def heads(self, inputs):
+        """(preds_cls [T,6,32], preds_scale [T,3]) from the tuple inputs (train_dino.py:130-132); inference on the GPU
+        runs the stacks with the elementwise work folded into GEMM epilogues (fused_stack), like the SHOT model."""
+        if not torch.is_grad_enabled() and inputs.is_cuda:
+            feat = fused_stack(self.tuple_encoder, inputs)
+            preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
+            preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
+            return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
         feat = self.tuple_encoder(inputs)
         preds_scale = self.scale_encoder(feat)
         preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
         return preds_cls, preds_scale
+
+    def forward(self, points, point_descs, point_idxs_all):
+        return self.heads(self.prepare_tuple_inputs(points, point_descs, point_idxs_all))
 
 
 def load_reference_checkpoint(model, path):

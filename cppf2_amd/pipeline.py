@@ -153,14 +153,10 @@ class VotingPipeline:
     def kept_rows(self):
         """Global tuple rows of the pairs that survived the back-vote filter, int64 [B * max_kept], without a host sync:
         scene b's list is padded to max_kept entries by repeating its first row (harmless for gather / scatter)."""
-        B, mk = self.B, self.max_kept
-        base = self.tup_off[:-1].long()
-        j = torch.arange(mk, device=self.dev)
-        src = (base[:, None] + j[None, :]).clamp_(max=self.Ttot - 1)                 # where scene b keeps entry j
-        local = self.kept_tuple[src.reshape(-1)].reshape(B, mk).long()
-        valid = j[None, :] < self.kept_count[:, None]
-        rows = base[:, None] + torch.where(valid, local, torch.zeros_like(local))
-        return rows.reshape(-1)
+        rows = torch.empty((self.B * self.max_kept,), dtype=torch.int64, device=self.dev)
+        _lib.check(_L.cppf_kept_rows(self.B, ops._p(self.tup_off), ops._p(self.kept_tuple), ops._p(self.kept_count),
+                                     self.max_kept, ops._p(rows), ops._stream()), "cppf_kept_rows")
+        return rows
 
     def scatter_kept(self, rows, values, out=None):
         """[T, C] buffer holding `values` at `rows` (what assemble() reads for the kept pairs); other rows are untouched."""

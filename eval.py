@@ -122,9 +122,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
         if model_idx == 0:
             # batched forward: indices are scene-local, tables are concatenated -> add the scene base
             x = dino_model.prepare_tuple_inputs(pts, desc, idx + base[:, None].to(torch.int32))
-            f = dino_model.tuple_encoder(x)
-            pred_scales = dino_model.scale_encoder(f)
-            pred_cls = dino_model.logit_encoder(f).reshape(f.shape[0], 6, -1)
+            pred_cls, pred_scales = dino_model.heads(x)
         else:
             x = ops.encode_tuples_shot(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off)
             pred_cls, pred_scales = shot_model.heads(x)

@@ -234,6 +234,12 @@ int cppf_rot_bins2(int B, const float* pts, const int32_t* pt_off, const int32_t
                    float* counts, int32_t* top_idx, float* top_count,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Global tuple rows of the kept pairs, int64[B, max_kept] (device): row = tup_off[b] + kept_tuple[tup_off[b] + j] for
+ * j < kept_count[b], the scene's first tuple row otherwise -- the fixed-shape index a caller gathers per-pair tensors with
+ * (e.g. the tuple features the scale head runs on, eval.py:272) without reading kept_count on the host. */
+int cppf_kept_rows(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count, int max_kept,
+                   int64_t* rows, void* stream);
+
 /* Stand-alone halves with the reference's own signatures (used by the drop-in wrappers):
  * vote_rotation -> up float32[n_valid, num_rots, 3] (valid pairs compacted in order), valid uint8[T];
  * get_topk_dir on explicit candidates float32[M,3] with weights float64[M] (NULL = ones). */
