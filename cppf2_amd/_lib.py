@@ -11,7 +11,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CppfError(RuntimeError):
@@ -48,6 +48,8 @@ SIGNATURES = {
     "cppf_shot352_workspace_bytes": (_i64, [_i, _i64]),
     "cppf_shot352": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i64, _p]),
     "cppf_shot352_from_normals": (_i, [_i, _p, _p, _i64, _p, _f, _p, _p, _p, _i64, _p]),
+    "cppf_shot1344_workspace_bytes": (_i64, [_i, _i64]),
+    "cppf_shot1344": (_i, [_i, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _i64, _p]),
     "cppf_shot_prepare": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _i64, _p]),
     "cppf_shot_describe": (_i, [_i, _p, _p, _i64, _p, _f, _i, _p, _p, _p, _i64, _p]),
     "cppf_estimate_normals": (_i, [_i, _p, _p, _i64, _f, _p, _p, _i64, _p]),

@@ -135,9 +135,16 @@ __device__ __forceinline__ float sqdist3(float px, float py, float pz, float qx,
 // radial shell, elevation, azimuth) yields one weight 1 - |d| for the home bin and one predicated atomic |d| for the
 // neighbouring bin; divisions by the constant bin widths are multiplications by their reciprocals and the two square
 // roots are the 1-ulp hardware ones.  The decisions (sector, shell, hemisphere, bin) are the reference's.
+#define NR_COLOR_BINS 30                                   // nr_color_bins_ of pcl::SHOTColorEstimation
+#define COLOR_OFF (MAX_SECTORS * (NR_BINS + 1))            // the colour channel follows the 352 shape entries
+#define SHOT_COLOR_LEN (COLOR_OFF + MAX_SECTORS * (NR_COLOR_BINS + 1))   // 1344
+
+// COLOR: second channel of SHOT1344 (interpolateDoubleChannel): `bdc` is the neighbour's colour bin coordinate; it
+// lands in the same sector with the same spatial interpolation terms, only the step along the bins is its own.
+template <bool COLOR>
 __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, float qx, float qy, float qz, float d2,
                                                 float nqx, float nqy, float nqz, const float* rf, float radius,
-                                                uint32_t* shot, float fx_scale) {
+                                                uint32_t* shot, float fx_scale, float bdc = 0.0f) {
   if (!isfinite(nqx) || !isfinite(nqy) || !isfinite(nqz)) return;
   float cosd = (nqx * rf[6] + nqy * rf[7]) + nqz * rf[8];
   cosd = fminf(fmaxf(cosd, -1.0f), 1.0f);
@@ -171,11 +178,26 @@ __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, fl
     nb -= (nb >= NR_BINS) ? NR_BINS : 0;
     atomicAdd(&shot[desc * (NR_BINS + 1) + nb], (uint32_t)__float2uint_rn((fabsf(bd)) * fx_scale));
   }
+  constexpr int CS = NR_COLOR_BINS + 1;
+  int chome = 0;
+  float wc = 0.0f;
+  if (COLOR) {
+    const float cstepf = floorf(bdc + 0.5f);
+    const int cstep = (int)cstepf;
+    chome = COLOR_OFF + desc * CS + cstep;
+    bdc -= cstepf;
+    wc = 1.0f - fabsf(bdc);
+    int nb = cstep + ((bdc > 0.0f) ? 1 : NR_COLOR_BINS - 1);
+    nb -= (nb >= NR_COLOR_BINS) ? NR_COLOR_BINS : 0;
+    atomicAdd(&shot[COLOR_OFF + desc * CS + nb], (uint32_t)__float2uint_rn((fabsf(bdc)) * fx_scale));
+  }
   {  // radial shells: the neighbour exists only towards the shell boundary at radius / 2
     const float rd = (distance - (outer ? r34 : r14)) * inv_r12;
     w += 1.0f - fabsf(rd);
+    wc += 1.0f - fabsf(rd);
     const bool has = outer ? !(distance > r34) : !(distance < r14);
     if (has) atomicAdd(&shot[home + (outer ? -2 : 2) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(rd)) * fx_scale));
+    if (COLOR && has) atomicAdd(&shot[chome + (outer ? -2 : 2) * CS], (uint32_t)__float2uint_rn((fabsf(rd)) * fx_scale));
   }
   {  // elevation: two hemispheres, neighbour only towards the equator
     const float inc = atan2_poly(__builtin_amdgcn_sqrtf(xf * xf + yf * yf), zf);      // [0, pi], exact at the poles
@@ -183,18 +205,23 @@ __device__ __forceinline__ void shot_accumulate(float px, float py, float pz, fl
     const bool lower = inc > R90 || (inc == R90 && zf <= 0.0f);
     const float id = (inc - (lower ? R135 : R45)) * (float)(1.0 / RAD_90);
     w += 1.0f - fabsf(id);
+    wc += 1.0f - fabsf(id);
     const bool has = lower ? !(inc > R135) : !(inc < R45);
     if (has) atomicAdd(&shot[home + (lower ? 1 : -1) * (NR_BINS + 1)], (uint32_t)__float2uint_rn((fabsf(id)) * fx_scale));
+    if (COLOR && has) atomicAdd(&shot[chome + (lower ? 1 : -1) * CS], (uint32_t)__float2uint_rn((fabsf(id)) * fx_scale));
   }
   if (yf != 0.0f || xf != 0.0f) {  // azimuth sectors wrap around
     const float az = atan2_poly(yf, xf);
     float ad = (az - (-(float)RAD_PI_7_8 + (float)RAD_45 * (float)(desc >> 2))) * (float)(1.0 / RAD_45);
     ad = fminf(fmaxf(ad, -0.5f), 0.5f);
     w += 1.0f - fabsf(ad);
+    wc += 1.0f - fabsf(ad);
     const int sec = (desc + ((ad > 0.0f) ? 4 : MAX_SECTORS - 4)) & (MAX_SECTORS - 1);
     atomicAdd(&shot[sec * (NR_BINS + 1) + step], (uint32_t)__float2uint_rn((fabsf(ad)) * fx_scale));
+    if (COLOR) atomicAdd(&shot[chome + (sec - desc) * CS], (uint32_t)__float2uint_rn((fabsf(ad)) * fx_scale));
   }
   atomicAdd(&shot[home], (uint32_t)__float2uint_rn((w) * fx_scale));
+  if (COLOR) atomicAdd(&shot[chome], (uint32_t)__float2uint_rn((wc) * fx_scale));
 }
 
 #define CELL_CAP 16384     // cells per scene held in LDS by shot_cells (64 KiB of counters)
@@ -503,6 +530,48 @@ __global__ __launch_bounds__(256) void shot_sort_normals_kernel(int64_t total, c
 // ---------------------------------------------------------------------------------------------
 // shot_hist: sign disambiguation + interpolated histogram
 // ---------------------------------------------------------------------------------------------
+// normalised CIELab of one point's colour the way pcl::SHOTColorEstimation::RGB2CIELAB computes it from PCL's two lookup
+// tables (sRGB gamma at 256 levels; cube root of XYZ quantised to 1/4000 with the exponent 0.3333f), evaluated in place
+// of the tables; components stored as uint8 = float * 255.f truncated like src_shot/shot.cpp:114-116.
+__device__ __forceinline__ float lab_srgb(float c) {
+  const float v = c * 255.f;
+  int i = (v == v) ? (int)v : 0;
+  i = min(max(i, 0), 255);
+  const float f = (float)i / 255.0f;
+  return (f > 0.04045f) ? powf((f + 0.055f) / 1.055f, 2.4f) : f / 12.92f;
+}
+__device__ __forceinline__ float lab_xyz(float v) {
+  const int i = min((int)(v * 4000), 3999);
+  const float f = (float)i / 4000.0f;
+  return (f > 0.008856f) ? powf(f, 0.3333f) : (float)((7.787 * (double)f) + (16.0 / 116.0));
+}
+__device__ __forceinline__ float4 lab_norm(const float* __restrict__ rgb) {
+  const float fr = lab_srgb(rgb[0]), fg = lab_srgb(rgb[1]), fb = lab_srgb(rgb[2]);
+  const float x = (fr * 0.412453f + fg * 0.357580f) + fb * 0.180423f;
+  const float y = (fr * 0.212671f + fg * 0.715160f) + fb * 0.072169f;
+  const float z = (fr * 0.019334f + fg * 0.119193f) + fb * 0.950227f;
+  const float vx = lab_xyz(x / 0.95047f), vy = lab_xyz(y), vz = lab_xyz(z / 1.08883f);
+  const float L = fminf(116.0f * vy - 16.0f, 100.0f);
+  const float A = fminf(fmaxf(500.0f * (vx - vy), -120.0f), 120.0f);
+  const float Bv = fminf(fmaxf(200.0f * (vy - vz), -120.0f), 120.0f);
+  return make_float4(L / 100.0f, A / 120.0f, Bv / 120.0f, 0.0f);
+}
+
+// Lab of every point, in the caller's order and in the cell-sorted order the histogram kernel walks
+__global__ __launch_bounds__(256) void shot_lab_kernel(int64_t total, const float* __restrict__ colors,
+                                                       const int32_t* __restrict__ pt_off,
+                                                       const int32_t* __restrict__ scene_of,
+                                                       const int32_t* __restrict__ sorted_idx,
+                                                       float4* __restrict__ lab, float4* __restrict__ sorted_lab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  lab[i] = lab_norm(colors + 3 * i);
+  // sorted position i of its scene holds original point sorted_idx[i] (scene-local)
+  const int b = scene_of[i];
+  sorted_lab[i] = lab_norm(colors + 3 * ((int64_t)pt_off[b] + sorted_idx[i]));
+}
+
+template <bool COLOR>
 __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __restrict__ pts,
                                                        const int32_t* __restrict__ pt_off,
                                                        const CellHdr* __restrict__ hdrs,
@@ -515,9 +584,13 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const int32_t* __restrict__ nbr_list,
                                                        const int32_t* __restrict__ nbr_cnt,
                                                        float* __restrict__ out_shot,
-                                                       float* __restrict__ out_rf) {
-  __shared__ uint32_t s_hist[SH_COPIES * SH_STRIDE];
-  uint32_t* hist = s_hist + (threadIdx.x & (SH_COPIES - 1)) * SH_STRIDE;
+                                                       float* __restrict__ out_rf,
+                                                       const float4* __restrict__ lab = nullptr,
+                                                       const float4* __restrict__ sorted_lab = nullptr) {
+  constexpr int LEN = COLOR ? SHOT_COLOR_LEN : SHOT_LEN;
+  constexpr int HWORDS = COLOR ? SHOT_COLOR_LEN + 1 : SH_COPIES * SH_STRIDE;
+  __shared__ uint32_t s_hist[HWORDS];
+  uint32_t* hist = COLOR ? s_hist : s_hist + (threadIdx.x & (SH_COPIES - 1)) * SH_STRIDE;
   __shared__ int s_list[SH_LCAP];       // positions in the cell-sorted order
   __shared__ float s_rf[9];
   const int lane = threadIdx.x;
@@ -530,12 +603,12 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   const float4* sn = sorted_nrm + (int64_t)p0;       // cell-sorted order, like sp
   const float px = pts[3 * (int64_t)qi], py = pts[3 * (int64_t)qi + 1], pz = pts[3 * (int64_t)qi + 2];
   const float r2 = radius * radius;
-  float* o = out_shot + (int64_t)SHOT_LEN * qi;
+  float* o = out_shot + (int64_t)LEN * qi;
   const LrfPre lp = pre[qi];
   const int valid = lp.valid;
   bool ok = valid >= 5;
   if (!ok || lp.nn < 5) {
-    for (int c = lane; c < SHOT_LEN; c += 64) o[c] = nan_to_zero ? 0.0f : NAN;
+    for (int c = lane; c < LEN; c += 64) o[c] = nan_to_zero ? 0.0f : NAN;
     if (out_rf && lane < 9) out_rf[9 * (int64_t)qi + lane] = NAN;
     if (!ok) return;
     // LRF exists but too few points for the descriptor: frame is still reported
@@ -684,7 +757,15 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
 #pragma unroll
     for (int c = 0; c < 9; ++c) s_rf[c] = rf[c];
   }
-  for (int c = lane; c < SH_COPIES * SH_STRIDE; c += 64) s_hist[c] = 0u;
+  for (int c = lane; c < HWORDS; c += 64) s_hist[c] = 0u;
+  float4 labq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (COLOR) labq = lab[qi];
+  // colour bin coordinate of a neighbour (SHOTColorEstimation::computePointSHOT): L1-type Lab distance in [0, 1] x 30 bins
+  auto color_bd = [&](const float4 lq) {
+    double cd = ((double)fabsf(labq.x - lq.x) + (((double)fabsf(labq.y - lq.y) + (double)fabsf(labq.z - lq.z)) / 2)) / 3;
+    cd = fmin(fmax(cd, 0.0), 1.0);
+    return (float)(cd * NR_COLOR_BINS);
+  };
   // Bins are summed in fixed point: a bin receives at most 4 per neighbour, so 2^(29 - ceil(log2(m + 1))) units per 1.0
   // cannot overflow 32 bits.  Integer LDS atomics run at full rate (float ones were measured ~50 cycles per
   // wavefront instruction), the sum does not depend on the order of the neighbours, and one unit (<= 2^-22 for the
@@ -694,45 +775,50 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   if (listed) {
     // the next 64 neighbours' positions and normals are requested before the current 64 are accumulated
     bool act = lane < m;
-    float4 qp, qn;
+    float4 qp, qn, ql = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     {
       const int j = act ? s_list[lane] : 0;
       qp = sp[j]; qn = sn[j];
+      if (COLOR) ql = sorted_lab[(int64_t)p0 + j];
     }
     for (int base = 0; base < m; base += 64) {
       const float qx = qp.x, qy = qp.y, qz = qp.z, nx = qn.x, ny = qn.y, nz = qn.z;
+      const float4 lq = ql;
       const bool cur = act;
       const int cn = base + 64 + lane;
       act = cn < m;
       if (base + 64 < m) {
         const int j = act ? s_list[cn] : 0;
         qp = sp[j]; qn = sn[j];
+        if (COLOR) ql = sorted_lab[(int64_t)p0 + j];
       }
-      if (cur) shot_accumulate(px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), nx, ny, nz, s_rf, radius, hist, fx_scale);
+      if (cur)
+        shot_accumulate<COLOR>(px, py, pz, qx, qy, qz, sqdist3(px, py, pz, qx, qy, qz), nx, ny, nz, s_rf, radius, hist,
+                               fx_scale, COLOR ? color_bd(lq) : 0.0f);
     }
   } else {
     FOR_EACH_NEIGHBOUR({
       if (act) {
         const float4 qv = sp[j], nv = sn[j];
-        shot_accumulate(px, py, pz, qv.x, qv.y, qv.z, sqdist3(px, py, pz, qv.x, qv.y, qv.z), nv.x, nv.y, nv.z, s_rf, radius,
-                        hist, fx_scale);
+        shot_accumulate<COLOR>(px, py, pz, qv.x, qv.y, qv.z, sqdist3(px, py, pz, qv.x, qv.y, qv.z), nv.x, nv.y, nv.z, s_rf,
+                               radius, hist, fx_scale, COLOR ? color_bd(sorted_lab[(int64_t)p0 + j]) : 0.0f);
       }
     })
   }
 #undef FOR_EACH_NEIGHBOUR
   __syncthreads();
   double acc = 0.0;
-  for (int c = lane; c < SHOT_LEN; c += 64) {
+  for (int c = lane; c < LEN; c += 64) {
     uint32_t u = s_hist[c];
 #pragma unroll
-    for (int k = 1; k < SH_COPIES; ++k) u += s_hist[k * SH_STRIDE + c];
+    for (int k = 1; k < (COLOR ? 1 : SH_COPIES); ++k) u += s_hist[k * SH_STRIDE + c];
     const float v = (float)u / fx_scale;               // power-of-two scale: exact
     s_hist[c] = __float_as_uint(v);                    // each bin is folded by the lane that normalises it below
     acc += (double)v * (double)v;
   }
   acc = sqrt(wave_sum(acc));
   const float facc = (float)acc;
-  for (int c = lane; c < SHOT_LEN; c += 64) {
+  for (int c = lane; c < LEN; c += 64) {
     float v = __uint_as_float(s_hist[c]) / facc;
     if (nan_to_zero && !(v == v)) v = 0.0f;            // an all-zero histogram normalises to 0/0
     __builtin_nontemporal_store(v, &o[c]);
@@ -794,7 +880,7 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
     hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
                        normals_in ? normals_in : out_normal, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
     CPPF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+    hipLaunchKernelGGL(shot_hist_kernel<false>, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
                        w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, 0, w.nbr_list, w.nbr_cnt,
                        out_shot, out_rf);
     CPPF_LAUNCH_CHECK();
@@ -869,9 +955,52 @@ extern "C" int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off
   hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((total_points + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, total_points, normals, pt_off, w.scene_of, w.sorted_idx, w.sorted_nrm);
   CPPF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shot_hist_kernel, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
+  hipLaunchKernelGGL(shot_hist_kernel<false>, dim3((unsigned)total_points), dim3(64), 0, (hipStream_t)stream, B, pts, pt_off,
                      w.hdr, w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, nan_to_zero,
                      w.nbr_list, w.nbr_cnt, out_shot, out_rf);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shot.compute_color (src_shot/shot.cpp:102-161): SHOT1344 = 352 shape + 992 colour entries per point.
+// Same pipeline as cppf_shot352 with the two-channel histogram kernel; the colour of a point enters through its
+// normalised CIELab triple (shot_lab_kernel).  Workspace = cppf_shot352's + two float4 tables of Lab values.
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t cppf_shot1344_workspace_bytes(int B, int64_t total_points) {
+  if (B <= 0 || total_points <= 0) return 0;
+  return cppf_shot352_workspace_bytes(B, total_points) + 2 * up256(total_points * 16);
+}
+
+extern "C" int cppf_shot1344(int B, const float* pts, const float* colors, const int32_t* pt_off, int64_t total_points,
+                             float normal_r, float shot_r, float* out_shot, float* out_normal, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && colors && pt_off && out_shot && out_normal && normal_r > 0.0f && shot_r > 0.0f);
+  CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
+  if (total_points <= 0) return CPPF_OK;
+  CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot1344_workspace_bytes(B, total_points));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = total_points;
+  const ShotWs w = carve(workspace, B, n);
+  float4* lab = (float4*)((char*)workspace + cppf_shot352_workspace_bytes(B, n));
+  float4* sorted_lab = (float4*)((char*)lab + up256(n * 16));
+  hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(normal_r, shot_r), w.hdr,
+                     w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
+                     w.pre);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, out_normal, pt_off,
+                     w.scene_of, w.sorted_idx, w.sorted_nrm);
+  hipLaunchKernelGGL(shot_lab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, colors, pt_off, w.scene_of,
+                     w.sorted_idx, lab, sorted_lab);
+  CPPF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shot_hist_kernel<true>, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
+                     w.sorted_idx, w.sorted_pts, w.scene_of, w.sorted_nrm, w.pre, shot_r, 0, w.nbr_list, w.nbr_cnt,
+                     out_shot, (float*)nullptr, (const float4*)lab, (const float4*)sorted_lab);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }

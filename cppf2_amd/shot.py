@@ -118,6 +118,31 @@ def compute(pc, normal_r=0.1, shot_r=0.17):
     return [s.reshape(-1).cpu().numpy(), n.reshape(-1).cpu().numpy()]
 
 
+def compute_color_device(pts, colors, pt_off, normal_r, shot_r):
+    """Batched device API of compute_color: pts / colors float32 [Ntot,3] (device).  Returns (shot1344 [Ntot,1344], normal)."""
+    dev = pts.device
+    n = pts.shape[0]
+    B = pt_off.numel() - 1
+    out = torch.empty((n, 1344), dtype=torch.float32, device=dev)
+    out_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    need = _L.cppf_shot1344_workspace_bytes(B, n)
+    ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=dev)
+    _lib.check(_L.cppf_shot1344(B, ops._p(pts), ops._p(colors), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
+                                ops._p(out), ops._p(out_normal), ops._p(ws), ws.numel(), ops._stream()), "cppf_shot1344")
+    return out, out_normal
+
+
+def compute_color(pc, pc_color, normal_r=0.1, shot_r=0.17):
+    """shot.compute_color (src_shot/shot.cpp:102-161): float32[N*1344] (SHOT1344: 352 shape + 992 colour entries)."""
+    dev = ops._dev()
+    pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
+    col = ops._t(np.asarray(pc_color, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
+    assert col.shape[0] == pts.shape[0]
+    pt_off = ops._offsets([pts.shape[0]], dev)
+    s, _ = compute_color_device(pts, col, pt_off, float(normal_r), float(shot_r))
+    return s.reshape(-1).cpu().numpy()
+
+
 def estimate_normal(pc, normal_r):
     """shot.estimate_normal (src_shot/shot.cpp:12-42): returns float32[N*3]."""
     dev = ops._dev()

@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 3
+#define CPPF_ABI_VERSION 4
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -94,6 +94,15 @@ int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_p
 int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
                               const float* normals, float shot_r, float* out_shot, float* out_rf,
                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* shot.compute_color (src_shot/shot.cpp:102-161 -> pcl::SHOTColorEstimation, SHOT1344): colors float32[total_points,3] in
+ * [0,1] (stored as uint8 = c * 255 truncated, like the wrapper), out_shot float32[total_points,1344] = 32 sectors x 11
+ * shape slots followed by 32 sectors x 31 colour slots, L2-normalised over all 1344 entries; NaN rows as cppf_shot352.
+ * Exported by the reference's module but called by none of its scripts; parity unpinned like cppf_shot352. */
+int64_t cppf_shot1344_workspace_bytes(int B, int64_t total_points);
+int cppf_shot1344(int B, const float* pts, const float* colors, const int32_t* pt_off, int64_t total_points,
+                  float normal_r, float shot_r, float* out_shot, float* out_normal,
+                  void* workspace, int64_t workspace_bytes, void* stream);
 /* Two-call form of cppf_shot352 sharing one workspace: prepare = cell sort + covariances + eigen-solves (normals out,
  * local-frame axes kept in the workspace); describe = the histogram kernel alone.  describe must follow a prepare
  * on the same inputs / stream / workspace.  `normals` are the ones the descriptor reads (eval.py zeroes NaNs only

@@ -205,8 +205,13 @@ static int shot_lrf(const float* pts, int n, int i, float radius, float rf[9]) {
 #define RAD_PI_7_8 2.7488935718910690836548129603691
 
 /* one neighbour's contribution (SHOTEstimation::interpolateSingleChannel body); returns nothing, adds into shot[] */
-static void shot_accumulate(const float* p, const float* q, float d2, const float* nq, const float rf[9], double radius,
-                            float* shot, double* margin) {
+#define NR_COLOR_BINS 30   /* nr_color_bins_ of SHOTColorEstimation */
+#define COLOR_OFF (MAX_SECTORS * (NR_BINS + 1))
+
+/* bdc < 0: shape channel only (SHOT352, interpolateSingleChannel); bdc >= 0: colour bin coordinate of this neighbour,
+ * SHOT1344's second channel (interpolateDoubleChannel): same sector, same spatial interpolation terms, its own step. */
+static void shot_accumulate2(const float* p, const float* q, float d2, const float* nq, const float rf[9], double radius,
+                             float* shot, double* margin, double bdc) {
   /* createBinDistanceShape */
   if (!isfinite(nq[0]) || !isfinite(nq[1]) || !isfinite(nq[2])) return;
   double cosd = (double)((nq[0] * rf[6] + nq[1] * rf[7]) + nq[2] * rf[8]);
@@ -263,15 +268,41 @@ static void shot_accumulate(const float* p, const float* q, float d2, const floa
     shot[volume_index + ((step_index + 1) % NR_BINS)] += (float)bin_distance;
   else
     shot[volume_index + ((step_index - 1 + NR_BINS) % NR_BINS)] += -(float)bin_distance;
+  const int has_c = bdc >= 0.0;
+  const int cstride = NR_COLOR_BINS + 1;
+  int step_c = 0;
+  double wc = 0.0;
+  if (has_c) {
+    if (margin) {
+      const double cm = fabs((bdc - floor(bdc)) - 0.5);
+      if (cm < *margin) *margin = cm;
+    }
+    step_c = (int)floor(bdc + 0.5);
+    const int vol_c = COLOR_OFF + desc_index * cstride;
+    bdc -= step_c;
+    wc = 1.0 - fabs(bdc);
+    if (bdc > 0)
+      shot[vol_c + ((step_c + 1) % NR_COLOR_BINS)] += (float)bdc;
+    else
+      shot[vol_c + ((step_c - 1 + NR_COLOR_BINS) % NR_COLOR_BINS)] -= (float)bdc;
+  }
 
   if (distance > r12) {
     const double rd = (distance - r34) / r12;
-    if (distance > r34) w += 1 - rd;
-    else { w += 1 + rd; shot[(desc_index - 2) * (NR_BINS + 1) + step_index] -= (float)rd; }
+    if (distance > r34) { w += 1 - rd; wc += 1 - rd; }
+    else {
+      w += 1 + rd; wc += 1 + rd;
+      shot[(desc_index - 2) * (NR_BINS + 1) + step_index] -= (float)rd;
+      if (has_c) shot[COLOR_OFF + (desc_index - 2) * cstride + step_c] -= (float)rd;
+    }
   } else {
     const double rd = (distance - r14) / r12;
-    if (distance < r14) w += 1 + rd;
-    else { w += 1 - rd; shot[(desc_index + 2) * (NR_BINS + 1) + step_index] += (float)rd; }
+    if (distance < r14) { w += 1 + rd; wc += 1 + rd; }
+    else {
+      w += 1 - rd; wc += 1 - rd;
+      shot[(desc_index + 2) * (NR_BINS + 1) + step_index] += (float)rd;
+      if (has_c) shot[COLOR_OFF + (desc_index + 2) * cstride + step_c] += (float)rd;
+    }
   }
 
   double inc_cos = zf / distance;
@@ -280,12 +311,20 @@ static void shot_accumulate(const float* p, const float* q, float d2, const floa
   const double inc = acos(inc_cos);
   if (inc > RAD_90 || (fabs(inc - RAD_90) < 1e-30 && zf <= 0)) {
     const double id = (inc - RAD_135) / RAD_90;
-    if (inc > RAD_135) w += 1 - id;
-    else { w += 1 + id; shot[(desc_index + 1) * (NR_BINS + 1) + step_index] -= (float)id; }
+    if (inc > RAD_135) { w += 1 - id; wc += 1 - id; }
+    else {
+      w += 1 + id; wc += 1 + id;
+      shot[(desc_index + 1) * (NR_BINS + 1) + step_index] -= (float)id;
+      if (has_c) shot[COLOR_OFF + (desc_index + 1) * cstride + step_c] -= (float)id;
+    }
   } else {
     const double id = (inc - RAD_45) / RAD_90;
-    if (inc < RAD_45) w += 1 + id;
-    else { w += 1 - id; shot[(desc_index - 1) * (NR_BINS + 1) + step_index] += (float)id; }
+    if (inc < RAD_45) { w += 1 + id; wc += 1 + id; }
+    else {
+      w += 1 - id; wc += 1 - id;
+      shot[(desc_index - 1) * (NR_BINS + 1) + step_index] += (float)id;
+      if (has_c) shot[COLOR_OFF + (desc_index - 1) * cstride + step_c] += (float)id;
+    }
   }
 
   if (yf != 0.0 || xf != 0.0) {
@@ -294,14 +333,22 @@ static void shot_accumulate(const float* p, const float* q, float d2, const floa
     double ad = (az - (-RAD_PI_7_8 + RAD_45 * sel)) / RAD_45;
     ad = fmax(-0.5, fmin(ad, 0.5));
     if (ad > 0) {
-      w += 1 - ad;
+      w += 1 - ad; wc += 1 - ad;
       shot[((desc_index + 4) % MAX_SECTORS) * (NR_BINS + 1) + step_index] += (float)ad;
+      if (has_c) shot[COLOR_OFF + ((desc_index + 4) % MAX_SECTORS) * cstride + step_c] += (float)ad;
     } else {
-      w += 1 + ad;
+      w += 1 + ad; wc += 1 + ad;
       shot[((desc_index - 4 + MAX_SECTORS) % MAX_SECTORS) * (NR_BINS + 1) + step_index] -= (float)ad;
+      if (has_c) shot[COLOR_OFF + ((desc_index - 4 + MAX_SECTORS) % MAX_SECTORS) * cstride + step_c] -= (float)ad;
     }
   }
   shot[volume_index + step_index] += (float)w;
+  if (has_c) shot[COLOR_OFF + desc_index * cstride + step_c] += (float)wc;
+}
+
+static void shot_accumulate(const float* p, const float* q, float d2, const float* nq, const float rf[9], double radius,
+                            float* shot, double* margin) {
+  shot_accumulate2(p, q, d2, nq, rf, radius, shot, margin, -1.0);
 }
 
 /* shot.compute(pc, normal_r, shot_r): out_shot [n,352], out_normal [n,3]; optional out_rf [n,9]. */
@@ -566,4 +613,109 @@ void shot_oracle_compute_ex(const float* pts, int n, float normal_r, float shot_
     for (int c = 0; c < SHOT_LEN; ++c) shot[c] /= (float)acc;
   }
   free(nb);
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SHOT1344 = shape + colour (shot.compute_color, src_shot/shot.cpp:102-161 -> pcl::SHOTColorEstimation<PointXYZRGB,
+ * Normal, SHOT1344>).  PARITY UNPINNED like SHOT352.  Restated from PCL 1.9.1's features/impl/shot.hpp:
+ * RGB2CIELAB through the two lookup tables (sRGB gamma at 256 levels; the cube root of XYZ quantised to 1/4000, with
+ * PCL's exponent 0.3333f), L / 100, a / 120, b / 120, colour distance (|dL| + (|da| + |db|) / 2) / 3 clamped to [0, 1],
+ * times 30 colour bins; interpolateDoubleChannel; L2 norm over all 1344 entries.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define SHOT_COLOR_LEN 1344
+static float g_srgb_lut[256], g_xyz_lut[4000];
+static int g_lut_ready = 0;
+
+static void lab_tables(void) {
+  if (g_lut_ready) return;
+  for (int i = 0; i < 256; ++i) {
+    const float f = (float)i / 255.0f;
+    g_srgb_lut[i] = (f > 0.04045) ? powf((f + 0.055f) / 1.055f, 2.4f) : f / 12.92f;
+  }
+  for (int i = 0; i < 4000; ++i) {
+    const float f = (float)i / 4000.0f;
+    g_xyz_lut[i] = (f > 0.008856) ? (float)powf(f, 0.3333f) : (float)((7.787 * f) + (16.0 / 116.0));
+  }
+  g_lut_ready = 1;
+}
+
+/* colour components as the wrapper stores them: uint8 = (float in [0,1]) * 255.f, truncated (shot.cpp:114-116) */
+static int color_u8(float c) {
+  const float v = c * 255.f;
+  int i = (int)v;
+  if (!(v == v)) i = 0;
+  if (i < 0) i = 0;
+  if (i > 255) i = 255;
+  return i;
+}
+
+static void rgb2lab_norm(const float* rgb, float lab[3]) {
+  lab_tables();
+  const float fr = g_srgb_lut[color_u8(rgb[0])], fg = g_srgb_lut[color_u8(rgb[1])], fb = g_srgb_lut[color_u8(rgb[2])];
+  const float x = fr * 0.412453f + fg * 0.357580f + fb * 0.180423f;
+  const float y = fr * 0.212671f + fg * 0.715160f + fb * 0.072169f;
+  const float z = fr * 0.019334f + fg * 0.119193f + fb * 0.950227f;
+  float vx = x / 0.95047f, vy = y, vz = z / 1.08883f;
+  int ix = (int)(vx * 4000), iy = (int)(vy * 4000), iz = (int)(vz * 4000);
+  if (ix > 3999) ix = 3999;
+  if (iy > 3999) iy = 3999;
+  if (iz > 3999) iz = 3999;
+  vx = g_xyz_lut[ix]; vy = g_xyz_lut[iy]; vz = g_xyz_lut[iz];
+  float L = 116.0f * vy - 16.0f;
+  if (L > 100) L = 100.0f;
+  float A = 500.0f * (vx - vy);
+  if (A > 120) A = 120.0f; else if (A < -120) A = -120.0f;
+  float B2 = 200.0f * (vy - vz);
+  if (B2 > 120) B2 = 120.0f; else if (B2 < -120) B2 = -120.0f;
+  lab[0] = L / 100.0f; lab[1] = A / 120.0f; lab[2] = B2 / 120.0f;
+}
+
+/* out_shot [n,1344], out_normal [n,3]; out_diag optional [n,DIAG_LEN] as in shot_oracle_compute_ex (mode 0 arithmetic) */
+void shot_oracle_compute_color(const float* pts, const float* colors, int n, float normal_r, float shot_r,
+                               float* out_shot, float* out_normal, double* out_diag) {
+  shot_oracle_normals(pts, n, normal_r, out_normal);
+  float* lab = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) rgb2lab_norm(colors + 3 * i, lab + 3 * i);
+  Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)(n > 0 ? n : 1));
+  const float r2 = shot_r * shot_r;
+  for (int i = 0; i < n; ++i) {
+    const float* p = pts + 3 * i;
+    float* shot = out_shot + (size_t)SHOT_COLOR_LEN * i;
+    float rf[9], tmp[9];
+    const int m = sorted_neighbours(pts, n, i, shot_r, nb);
+    shot_lrf_sorted(pts, i, nb, m, shot_r, tmp, out_diag ? out_diag + DIAG_LEN * i : NULL);      /* diagnostics only */
+    const int ok = shot_lrf(pts, n, i, shot_r, rf);
+    double mg = 1e300;
+    if (out_diag) {
+      const double r2d = (double)r2;
+      double edge = 1e300;
+      for (int j = 0; j < n; ++j) {
+        const double e = fabs((double)sqdist(p, pts + 3 * j) - r2d) / r2d;
+        if (e < edge) edge = e;
+      }
+      out_diag[DIAG_LEN * i + 5] = NAN; out_diag[DIAG_LEN * i + 6] = NAN; out_diag[DIAG_LEN * i + 7] = m;
+      out_diag[DIAG_LEN * i + 8] = edge;
+    }
+    if (!ok || m < 5) { for (int c = 0; c < SHOT_COLOR_LEN; ++c) shot[c] = NAN; continue; }
+    memset(shot, 0, sizeof(float) * SHOT_COLOR_LEN);
+    const float* lr = lab + 3 * i;
+    for (int j = 0; j < n; ++j) {
+      const float d2 = sqdist(p, pts + 3 * j);
+      if (!(d2 < r2)) continue;
+      const float* lq = lab + 3 * j;
+      double cd = (fabs(lr[0] - lq[0]) + ((fabs(lr[1] - lq[1]) + fabs(lr[2] - lq[2])) / 2)) / 3;
+      if (cd > 1.0) cd = 1.0;
+      if (cd < 0.0) cd = 0.0;
+      shot_accumulate2(p, pts + 3 * j, d2, out_normal + 3 * j, rf, (double)shot_r, shot, out_diag ? &mg : NULL,
+                       cd * NR_COLOR_BINS);
+    }
+    double acc = 0.0;
+    for (int c = 0; c < SHOT_COLOR_LEN; ++c) acc += (double)shot[c] * (double)shot[c];
+    acc = sqrt(acc);
+    if (out_diag) { out_diag[DIAG_LEN * i + 5] = mg; out_diag[DIAG_LEN * i + 6] = acc; }
+    for (int c = 0; c < SHOT_COLOR_LEN; ++c) shot[c] /= (float)acc;
+  }
+  free(nb);
+  free(lab);
 }

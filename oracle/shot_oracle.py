@@ -30,6 +30,9 @@ def _load():
         _lib.shot_oracle_compute_ex.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p]
         _lib.shot_oracle_compute_ex.restype = None
+        _lib.shot_oracle_compute_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]
+        _lib.shot_oracle_compute_color.restype = None
         _lib.shot_oracle_normals.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         _lib.shot_oracle_normals.restype = None
     return _lib
@@ -68,3 +71,18 @@ def compute_ex(pc, normal_r, shot_r, pcl_arithmetic=False):
     _load().shot_oracle_compute_ex(pc.ctypes.data, n, C.c_float(normal_r), C.c_float(shot_r), int(bool(pcl_arithmetic)),
                                    shot.ctypes.data, normal.ctypes.data, rf.ctypes.data, diag.ctypes.data)
     return shot, normal, rf, diag
+
+
+def compute_color(pc, pc_color, normal_r, shot_r):
+    """shot.compute_color (src_shot/shot.cpp:102-161; SHOT1344 = 352 shape + 992 colour entries).
+    Returns (shot f32[N,1344], normal f32[N,3], diag f64[N,9])."""
+    pc = np.ascontiguousarray(pc, dtype=np.float32).reshape(-1, 3)
+    col = np.ascontiguousarray(pc_color, dtype=np.float32).reshape(-1, 3)
+    n = pc.shape[0]
+    assert col.shape[0] == n
+    shot = np.empty((n, 1344), np.float32)
+    normal = np.empty((n, 3), np.float32)
+    diag = np.empty((n, 9), np.float64)
+    _load().shot_oracle_compute_color(pc.ctypes.data, col.ctypes.data, n, C.c_float(normal_r), C.c_float(shot_r),
+                                      shot.ctypes.data, normal.ctypes.data, diag.ctypes.data)
+    return shot, normal, diag

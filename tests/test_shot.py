@@ -109,6 +109,30 @@ def test_oracle_modes_agree_when_the_covariance_is_well_conditioned():
     assert np.allclose(rf0, rf1, atol=1e-6, equal_nan=True)
 
 
+def test_oracle_shot1344_invariants():
+    """shot.compute_color (src_shot/shot.cpp:102-161, SHOT1344; parity unpinned like SHOT352): unit norm over all 1344
+    entries; the shape channel is SHOT352 up to the common normalisation; both channels put the same mass into every
+    spatial sector (they share the interpolation weights); a cloud of one colour fills colour slot 0 only."""
+    sc = synth.make_scene(0, 0, 1500)
+    rng = np.random.RandomState(0)
+    col = rng.rand(1500, 3).astype(np.float32)
+    s352, n352, _ = S.compute(sc["pc"], 0.02, 0.02)
+    s, nrm, _ = S.compute_color(sc["pc"], col, 0.02, 0.02)
+    ok = ~np.isnan(s).any(1)
+    assert ok.mean() > 0.99 and np.array_equal(nrm, n352, equal_nan=True)
+    assert np.allclose(np.linalg.norm(s[ok], axis=1), 1.0, atol=1e-5)
+    shape = s[ok, :352]
+    assert np.abs(shape / np.linalg.norm(shape, axis=1, keepdims=True) - s352[ok]).max() < 1e-6
+    a, b = shape.reshape(-1, 32, 11).sum(2), s[ok, 352:].reshape(-1, 32, 31).sum(2)
+    assert np.abs(a - b).max() < 1e-6
+    one, _, _ = S.compute_color(sc["pc"], np.full((1500, 3), 0.3, np.float32), 0.02, 0.02)
+    cu = one[ok, 352:].reshape(-1, 32, 31)
+    assert np.all(cu[:, :, 1:] == 0) and cu[:, :, 0].sum() > 0
+    # colour is stored as uint8 = c * 255 truncated (shot.cpp:114-116): changes below one level do not matter
+    s2, _, _ = S.compute_color(sc["pc"], (np.floor(col * 255.0) / 255.0 + 1e-4).astype(np.float32), 0.02, 0.02)
+    assert np.array_equal(s2, s, equal_nan=True)
+
+
 @pytest.mark.gpu
 def test_hip_shot_vs_oracle():
     torch = pytest.importorskip("torch")
@@ -187,3 +211,33 @@ def test_hip_shot_bench_size_vs_oracle():
         assert np.all(err[~exempt] < 2e-5), float(err[~exempt].max())
         assert (err >= 2e-5).mean() < 5e-3
         assert np.allclose(np.linalg.norm(hs[sl][ok], axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_shot1344_vs_oracle():
+    """shot.compute_color on the GPU (cppf_shot1344) against the oracle: rows agree to 2e-5 except where the oracle
+    itself has a neighbour within 1e-6 of a decision boundary of PCL's interpolation (shape or colour step)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from cppf2_amd import shot
+    rng = np.random.RandomState(3)
+    for sid, n in ((0, 2000), (1, 777)):
+        sc = synth.make_scene(6, sid, n)
+        col = rng.rand(n, 3).astype(np.float32)
+        col[: n // 4] = col[0]                                    # a patch of one colour
+        got = shot.compute_color(sc["pc"], col, 0.02, 0.02)
+        assert got.shape == (n * 1344,) and got.dtype == np.float32
+        got = got.reshape(n, 1344)
+        want, _, d = S.compute_color(sc["pc"], col, 0.02, 0.02)
+        assert np.array_equal(np.isnan(want), np.isnan(got))
+        ok = ~np.isnan(want).any(1)
+        err = np.abs(got[ok] - want[ok]).max(1)
+        exempt = (d[ok, 5] < 1e-6) | (d[ok, 8] < 4e-7)
+        assert np.all(err[~exempt] < 2e-5), float(err[~exempt].max())
+        assert (err >= 2e-5).mean() < 1e-2
+        assert np.allclose(np.linalg.norm(got[ok], axis=1), 1.0, atol=1e-5)
+    # the shape channel is the SHOT352 kernel's
+    s352 = shot.compute(sc["pc"], 0.02, 0.02)[0].reshape(n, 352)
+    shape = got[ok, :352]
+    assert np.abs(shape / np.linalg.norm(shape, axis=1, keepdims=True) - s352[ok]).max() < 1e-5
