@@ -67,7 +67,9 @@ def fused_stack(seq, x, keep_input=False):
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
       out = x W0^T + (b0 + b2)           one GEMM, bias epilogue          (layers with a projection skip)
       out += h W2^T                      one GEMM, beta = 1, in place
-    Identity-skip layers accumulate h W2^T into x in place; their output bias b2 is not added to the activation
+    128-wide identity-skip layers (4 of the 6 layers of `tuple_encoder` and `shot_encoder`) run as one HIP kernel on the
+    f32 matrix cores (ops.reslayer128_: h never leaves the registers).  Other identity-skip layers accumulate h W2^T into
+    x in place; an identity layer's output bias b2 is not added to the activation
     but carried as a pending per-channel offset c (true activation = x + c) and folded into the biases of the
     next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
     models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`
@@ -75,6 +77,12 @@ def fused_stack(seq, x, keep_input=False):
     The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
     plan, c = _fused_plan(seq)
     for li, (w1t, b1, w0t, b0, w2t) in enumerate(plan):
+        if (w0t is None and w1t.shape == (128, 128) and x.dtype == torch.float32 and x.is_contiguous()
+                and not (li == 0 and keep_input)):
+            # 128-wide identity-skip layer: both GEMMs, the bias, the ReLU and the residual add in one matrix-core kernel
+            # that reads and writes the activation once (cppf_reslayer128); w1t / w2t are transposed views of the weights
+            x = ops.reslayer128_(x, w1t.t(), b1, w2t.t())
+            continue
         h = torch._addmm_activation(b1, x, w1t)
         if w0t is not None:
             x = torch.addmm(b0, x, w0t)

@@ -254,6 +254,17 @@ def encode_tuples_shot(points, point_idxs_all, shot_feat, normal, pt_off=None, t
     return out
 
 
+def reslayer128_(x, w1, b1, w2):
+    """In place x <- x + relu(x w1^T + b1) w2^T for x float32 [rows,128] (device, contiguous), w1 / w2 [128,128] as
+    nn.Linear stores them ([out,in]), b1 [128]: the 128-wide identity-skip ResLayer of the tuple / point encoders
+    (train_shot.py:19-45) as one matrix-core kernel (cppf_reslayer128).  Returns x."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
+    w1 = w1.contiguous(); w2 = w2.contiguous(); b1 = b1.contiguous()
+    assert w1.shape == (128, 128) and w2.shape == (128, 128) and b1.shape == (128,)
+    _lib.check(_L.cppf_reslayer128(_p(x), x.shape[0], _p(w1), _p(b1), _p(w2), _stream()), "cppf_reslayer128")
+    return x
+
+
 def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=None):
     """Coordinate part of the DINO model's prepare_tuple_inputs (train_dino.py:92): [T, C(k,2)*3]
     (written into the leading columns of `out` if given)."""

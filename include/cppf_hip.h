@@ -306,6 +306,14 @@ int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t st
                               int64_t stride_x, const float* pts, int n, float strides, int normalize, void* out,
                               int out_f16, void* stream);
 
+/* ---- 128-wide residual layer of the tuple / point encoders (train_shot.py:19-45 ResLayer with dim_in == dim_out == 128,
+ * bn = dropout = False; five of the six layers of `tuple_encoder` and `shot_encoder`):
+ *     x <- x + relu(x W1^T + b1) W2^T        in place on x float32[rows,128] (device, contiguous)
+ * w1, w2: float32[128,128] row-major [out,in] (the nn.Linear weights), b1 float32[128]; fc2's bias is left to the caller
+ * (it commutes with the residual stream).  One kernel on the f32 matrix cores: both products of a 32-row tile stay in
+ * registers.  float32 in, float32 accumulate: results differ from a library GEMM's only by summation order. */
+int cppf_reslayer128(float* x, int64_t rows, const float* w1, const float* b1, const float* w2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

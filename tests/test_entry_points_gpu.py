@@ -340,3 +340,33 @@ def test_encode_tuples_dino_gather_add_equals_linear_over_concatenation():
     out = torch.full((sum(Ts), 30 + D), 7.0, device=d.device)
     ops.encode_tuples_dino(tables, lin.bias, idx, out, 30, pt_off, tup_off)
     assert torch.allclose(out[:, 30:], want, atol=2e-5) and bool((out[:, :30] == 7.0).all())
+
+
+def test_reslayer128_kernel_matches_torch():
+    """cppf_reslayer128 (both GEMMs of a 128-wide identity-skip ResLayer on the f32 matrix cores, in place) against
+    x + relu(x W1^T + b1) W2^T in float64; float32 in / float32 accumulate: only the summation order differs from a
+    library GEMM (1e-5 relative to the row scale); ragged row counts; the fused stack still reproduces the module."""
+    from cppf2_amd import ops
+    from cppf2_amd.models import BeyondCPPFShot, fused_stack
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w1 = (torch.randn((128, 128), generator=g) * 0.1).cuda()
+    w2 = (torch.randn((128, 128), generator=g) * 0.1).cuda()
+    b1 = torch.randn((128,), generator=g).cuda()
+    for rows in (1, 31, 32, 33, 4096, 100003):
+        x = torch.randn((rows, 128), generator=g).cuda()
+        want = x.double() + torch.relu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t()
+        got = ops.reslayer128_(x.clone(), w1, b1, w2)
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() < 2e-5 * scale, rows
+    # zero weights: identity; the kernel must not touch rows beyond `rows`
+    buf = torch.randn((70, 128), generator=g).cuda()
+    keep = buf.clone()
+    ops.reslayer128_(buf[:33], torch.zeros_like(w1), b1, torch.zeros_like(w2))
+    assert torch.equal(buf, keep)
+    torch.manual_seed(1)
+    m = BeyondCPPFShot(Cfg()).cuda().eval()
+    xin = torch.randn((5000, 360), generator=g).cuda()
+    with torch.no_grad():
+        a = fused_stack(m.tuple_encoder, xin.clone())
+        ref = m.tuple_encoder(xin)
+    assert torch.allclose(a, ref, atol=2e-4, rtol=1e-4)
