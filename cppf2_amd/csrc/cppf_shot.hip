@@ -405,8 +405,6 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
                                                       int32_t* __restrict__ nbr_list /* [Ntot][NBR_CAP] */,
                                                       int32_t* __restrict__ nbr_cnt /* [Ntot] */) {
   __shared__ double s_part[NSUM][64];
-  int* s_list = reinterpret_cast<int*>(&s_part[0][0]);          // SH_LCAP ints, dead before the partial sums land
-  static_assert(SH_LCAP * sizeof(int) <= sizeof(double) * NSUM * 64, "list must fit under the partial sums");
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const int b = scene_of[qi];
@@ -421,45 +419,60 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
   double a[NSUM];
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
+  // The 9 runs are walked as ONE flat candidate range (no partly filled wavefront per run), the next 64 candidates are
+  // requested before the current 64 are processed, and the covariance sums are accumulated in the same sweep (the
+  // in-radius tests live in cov_accumulate); the compacted list only serves shot_hist.
+  int base[10];
+  base[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) base[k + 1] = base[k] + (runs.end[k] - runs.beg[k]);
+  const int C = base[9];
+  auto cand = [&](int f) {
+    int j = runs.beg[0] + f;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) j = (f >= base[k]) ? runs.beg[k] + (f - base[k]) : j;
+    return j;
+  };
   int m = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
-      const int j = jb + lane;
-      bool in = false;
-      if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2; }
-      const unsigned long long mask = __ballot(in);
-      if (in) {
-        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < SH_LCAP) s_list[pos] = j;
-      }
-      m += __popcll(mask);
+  int jn = (lane < C) ? cand(lane) : 0;
+  float4 qn = sp[jn];
+  for (int fb = 0; fb < C; fb += 64) {
+    const float4 qv = qn;
+    const int j = jn;
+    const bool valid = fb + lane < C;
+    const int fnext = fb + 64 + lane;
+    if (fb + 64 < C) {
+      jn = (fnext < C) ? cand(fnext) : 0;
+      qn = sp[jn];
     }
-  }
-  __syncthreads();
-  if (m <= SH_LCAP) {
-    for (int c = lane; c < m; c += 64) {
-      const int j = s_list[c];
-      if (nbr_list && c < NBR_CAP) nbr_list[(int64_t)qi * NBR_CAP + c] = j;
-      cov_accumulate(sp[j], px, py, pz, rn2, rs2, rs, a);
+    bool in = false;
+    if (valid) {
+      in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
+      cov_accumulate(qv, px, py, pz, rn2, rs2, rs, a);
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-      for (int j = runs.beg[k] + lane; j < runs.end[k]; j += 64) cov_accumulate(sp[j], px, py, pz, rn2, rs2, rs, a);
+    const unsigned long long mask = __ballot(in);
+    if (in) {
+      const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
+    }
+    m += __popcll(mask);
   }
   if (nbr_cnt && lane == 0) {
     nbr_cnt[qi] = m;
     if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
   }
-  __syncthreads();                                               // the list is dead: its storage becomes s_part
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) s_part[c][lane] = a[c];
   __syncthreads();
-  if (lane < NSUM) {
+  // column sums in a fixed order (run-to-run reproducible): three lanes per column add a third of the 64 partials each,
+  // the first of them adds the three thirds
+  {
+    const int c = min(lane / 3, NSUM - 1), part = lane - 3 * (lane / 3);
+    const int lo = part * 22, hi = min(64, lo + 22);
     double t = 0.0;
-    for (int l = 0; l < 64; ++l) t += s_part[lane][l];            // fixed order: run-to-run reproducible
-    sums[(int64_t)qi * NSUM + lane] = t;
+    for (int l = lo; l < hi; ++l) t += s_part[c][l];
+    const double t1 = __shfl_down(t, 1), t2 = __shfl_down(t, 2);
+    if (lane < 3 * NSUM && part == 0) sums[(int64_t)qi * NSUM + c] = (t + t1) + t2;
   }
 }
 
