@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RL_THREADS, 1) void reslayer128_kernel(float* __res
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) h[t][e] = fmaxf(h[t][e], 0.0f);
+      for (int e = 0; e < 16; ++e) h[t][e] = (h[t][e] < 0.0f) ? 0.0f : h[t][e];     // relu; NaN stays NaN like torch.relu
     }
     // y^T = x^T + W2 h^T: the x registers are the accumulators
     rl_product(w2_lds, h, xr);

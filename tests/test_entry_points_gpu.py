@@ -358,6 +358,11 @@ def test_reslayer128_kernel_matches_torch():
         got = ops.reslayer128_(x.clone(), w1, b1, w2)
         scale = want.abs().max().item()
         assert (got.double() - want).abs().max().item() < 2e-5 * scale, rows
+    # a NaN in a row poisons that row only (torch.relu keeps NaN; so does the kernel's)
+    x = torch.randn((64, 128), generator=g).cuda()
+    x[5, 17] = float("nan")
+    got = ops.reslayer128_(x.clone(), w1, b1, w2)
+    assert torch.isnan(got[5]).all() and not torch.isnan(got[torch.arange(64) != 5]).any()
     # zero weights: identity; the kernel must not touch rows beyond `rows`
     buf = torch.randn((70, 128), generator=g).cuda()
     keep = buf.clone()
