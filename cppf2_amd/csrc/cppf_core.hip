@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void encode_shot_kernel(const float* __restric
   // (tried: mapping all workgroups of a scene onto one XCD so its feature table stays in one L2 -- 10 % slower,
   //  the kernel is bound by the 1.8 GB of streaming writes, not by the gathers.  Round 2: fewer, longer-running
   //  workgroups (grid capped at 256 ... 16 per scene: 0.59 ... 0.86 ms against 0.56) and items in output order so that
-  //  every wavefront stores 1 KiB of consecutive addresses with its head lanes diverging (1.38 ms) are both slower.)
+  //  every wavefront stores 1 KiB of consecutive addresses with its head lanes diverging (1.38 ms) are both slower; so is
+  //  one contiguous span per workgroup with four gather-copies in flight per thread (0.57 ms at best).)
   const unsigned b = blockIdx.y, bx = blockIdx.x, bps = gridDim.x;
   const int p0 = pt_off[b];
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
