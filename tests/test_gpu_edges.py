@@ -329,3 +329,27 @@ def test_rot_bins_chunk_aligned_blocks_equal_the_exhaustive_sweep(B, bmm, R):
     kept = pipe.kept_count.cpu().numpy()
     assert kept.min() >= 0 and kept.max() * R > bmm       # at least one scene spans more than one chunk
     assert dense[:, kept > 0].max() > 0
+
+
+@pytest.mark.parametrize("R", [8, 37, 512, 600])
+def test_vote_center_rotation_counts_at_the_table_limits(R):
+    """num_rots at and around the LDS rotation-table capacity (512: arcs path with the doubled table; 600: the exhaustive
+    path) and odd counts: the grid equals the oracle's int64 grid cell for cell."""
+    from oracle import cppf_oracle as O
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda")
+    N, T = 1500, 3000
+    sc = synth.make_scene(12, 0, N)
+    idx = ops.sample_tuples(N, T, 5, 12, (0,))
+    lg = torch.from_numpy(synth.teacher_logits(sc["pc_canon"], idx.cpu().numpy(), 32)).to(dev)
+    u = ops.philox_uniform(T, 6, 12, 1, (0,))
+    pts = torch.from_numpy(sc["pc"]).to(dev)
+    pipe = VotingPipeline([N], [T], num_rots=R, vote_mode=1)
+    pipe.decode(pts, idx, lg, u)
+    grid = torch.zeros(pipe.cells_cap, dtype=torch.int32, device=dev)
+    pipe.vote_center(pts, idx, grid=grid, grid_off=torch.zeros(1, dtype=torch.int64, device=dev))
+    trig = (pipe.cs.cpu().numpy(), pipe.sn.cpu().numpy())
+    want, cand = O.vote_center(sc["pc"], pipe.tr.cpu().numpy(), 2e-3, idx.cpu().numpy()[:, :2], R, trig=trig)
+    got = grid.cpu().numpy()[:want.size].astype(np.int64)
+    assert np.array_equal(got, want.reshape(-1))
+    assert int(pipe.argmax.item()) == int(np.argmax(want)) and np.array_equal(pipe.world.cpu().numpy()[0], cand)
