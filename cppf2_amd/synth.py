@@ -87,7 +87,8 @@ def scene_pose(seed, scene_id, max_tilt_deg=25.0):
 
 
 def make_scene(seed, scene_id, n_points=4096, max_tilt_deg=25.0):
-    """Returns dict(pc f32[N,3], pc_canon f32[N,3] in [-0.5,0.5]^3, R f64[3,3], t f64[3], diag)."""
+    """Returns dict(pc f32[N,3], pc_canon f32[N,3] in [-0.5,0.5]^3, R f64[3,3], t f64[3], diag, extent f64[3] =
+    the box extents in metres)."""
     u = uniforms(seed, scene_id, 1, n_points, 4)
     side_frac = (2 * np.pi * RADIUS * HEIGHT) / (2 * np.pi * RADIUS * HEIGHT + 2 * np.pi * RADIUS ** 2)
     on_side = u[:, 0] < side_frac
@@ -100,7 +101,7 @@ def make_scene(seed, scene_id, n_points=4096, max_tilt_deg=25.0):
     pc = (obj @ R.T + t).astype(np.float32)
     # canonical coordinates exactly as eval.py:358 maps them back: (pc - t) @ R / diag
     pc_canon = ((pc.astype(np.float64) - t) @ R / DIAG).astype(np.float32)
-    return dict(pc=pc, pc_canon=pc_canon, R=R, t=t, diag=DIAG)
+    return dict(pc=pc, pc_canon=pc_canon, R=R, t=t, diag=DIAG, extent=np.array([2 * RADIUS, HEIGHT, 2 * RADIUS]))
 
 
 def teacher_logits(pc_canon, idx, num_bins=32, sigma_bins=0.6, noise=None):

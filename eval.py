@@ -85,11 +85,12 @@ def needed_cells(pc, res):
 @torch.no_grad()
 def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_pairs, num_rots, angle_tol=1.,
                  imp_wt_margin=0.01, backproj_ratio=.1, opt=False, geo_branch=True, visual_branch=True, up_sym=False,
-                 priors=None, keep=False):
+                 priors=None, keep=False, scale_priors=None):
     """eval.py:207-372 for a batch of instances of one category.  pcs: list of float32 [N_b,3]; descs: list of float32
     [N_b,1024] (DINOv2 features at the points: inputs to the path); priors: optional callable(idx_global, base) -> logit
-    prior [T,6,nb] added to both models' logits.  Returns dict(records=[2 x structured array], losses float64 [2,B],
-    pick int [B], scale, scale_norm, idx, pipe, ...)."""
+    prior [T,6,nb] added to both models' logits; scale_priors: optional float32 [B,3] teacher box extents that stand in for
+    the scale head of random-init weights (the head's output stays in the sum at 1e-3).  Returns dict(records=[2 x
+    structured array], losses float64 [2,B], pick int [B], scale, scale_norm, idx, pipe, ...)."""
     dev = ops._dev()
     B = len(pcs)
     Ns = [int(p.shape[0]) for p in pcs]
@@ -114,6 +115,9 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     desc = torch.from_numpy(np.concatenate(descs)).to(dev)
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
     prior = priors(idx, base) if priors is not None else None
+    scale_prior = None
+    if scale_priors is not None:
+        scale_prior = torch.from_numpy(np.asarray(scale_priors, dtype=np.float32)).to(dev).repeat_interleave(num_pairs, 0)
 
     feat_shot = shot_model.encode_points(shot_feat)
     records, losses, kept = [], [], []
@@ -129,6 +133,8 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
         raw_cls = pred_cls
         if prior is not None:
             pred_cls = pred_cls + prior
+        if scale_prior is not None:
+            pred_scales = scale_prior + 1e-3 * pred_scales
         u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
         pipe.vote(pts, idx, pred_cls.contiguous(), u, pred_scales.contiguous())
         if opt:
@@ -196,7 +202,7 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
     setups = {c: load_category(c, ckpt_dir, ckpt_shot, ckpt_dino, device=dev) for c in categories}
 
     from cppf2_amd import metrics
-    summary, all_cls, all_RT, all_scale, all_gt = [], [], [], [], []
+    summary, all_cls, all_RT, all_scale, all_gt, all_gt_scale = [], [], [], [], [], []
     inst = 0
     for ci, cat in enumerate(categories):
         cfg, dino_model, shot_model = setups[cat]
@@ -225,12 +231,13 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         g = torch.Generator(device="cpu").manual_seed(seed + 1 + ci)
         descs = [torch.nn.functional.normalize(torch.randn((s["pc"].shape[0], 1024), generator=g), dim=-1).numpy()
                  for s in scenes]
-        priors = None
+        priors = scale_priors = None
         if scenes[0]["pc_canon"] is not None:
             priors = _teacher_prior(np.concatenate([s["pc_canon"] for s in scenes]), dev)
+            scale_priors = np.stack([s["extent"] for s in scenes])
         r = run_ensemble(cfg, dino_model, shot_model, [s["pc"] for s in scenes], descs, seed, scene_ids, num_pairs,
                          num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch, visual_branch,
-                         up_sym, priors)
+                         up_sym, priors, scale_priors=scale_priors)
         cls_id = category2id[cat]
         for b in range(B):
             RT, sc = np.eye(4), np.ones(3)                                      # eval.py:143-144 defaults
@@ -249,10 +256,13 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
                     item["rot_err_deg"] = geometry.rot_err_deg(rec["R"], scenes[b]["R"], up_sym)
             summary.append(item)
             all_cls.append(cls_id); all_RT.append(RT); all_scale.append(sc)
-            if scenes[b]["R"] is not None:                  # synthetic instances carry their pose: unit-scale ground truth
+            if scenes[b]["R"] is not None:
+                # synthetic instances carry their pose and box: NOCS convention, rotation scaled by the box diagonal and
+                # the extents normalised by it (what eval.py:370-372 builds from the prediction)
                 gt = np.eye(4)
-                gt[:3, :3], gt[:3, 3] = scenes[b]["R"], scenes[b]["t"]
+                gt[:3, :3], gt[:3, 3] = scenes[b]["R"] * scenes[b]["diag"], scenes[b]["t"]
                 all_gt.append(gt)
+                all_gt_scale.append(scenes[b]["extent"] / scenes[b]["diag"])
         inst += B
 
     report = dict(categories=categories, instances=len(summary),
@@ -270,7 +280,7 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
     n = len(summary)
     gt = {}
     if n and len(all_gt) == n:
-        gt = dict(gt_class_ids=np.array(all_cls), gt_RTs=np.stack(all_gt), gt_scales=np.ones((n, 3)))
+        gt = dict(gt_class_ids=np.array(all_cls), gt_RTs=np.stack(all_gt), gt_scales=np.stack(all_gt_scale))
     record = metrics.make_result_record(np.array(all_cls, dtype=np.int64), np.stack(all_RT) if n else np.zeros((0, 4, 4)),
                                         np.stack(all_scale) if n else np.zeros((0, 3)), None, **gt)
     if gt:

@@ -129,6 +129,17 @@ def test_eval_main_all_six_categories(ev, tmp_path):
     rep2 = ev.main(num_pairs=3000, num_rots=36, num_scenes=1, num_points=512, opt=False, categories="mug,can",
                    visual_branch=False, debug=True)
     assert rep2["categories"] == ["mug", "can"] and [r_["model"] for r_ in rep2["results"]] == ["dino", "dino"]
+    # with the online refinement (eval.py:319-355, `opt`; one kernel per batch): poses stay finite and do not get worse
+    rep3 = ev.main(num_pairs=6000, num_rots=72, num_scenes=2, num_points=1024, opt=True, debug=True)
+    assert rep3["instances"] == 12 and "Adam" in rep3["opt_refinement"]
+    for a, b in zip(rep["results"], rep3["results"]):
+        assert np.all(np.isfinite(np.array(b["pred_RT"]))) and b["category"] == a["category"]
+        # (the y-only objective of an up-symmetric category leaves the translation along the axis free: within 2 cm)
+        assert b["tr_err_cm"] < 2.0 and b["rot_err_deg"] < a["rot_err_deg"] + 2.0
+    assert rep3["acc_5deg_5cm"] >= rep["acc_5deg_5cm"]
+    # teacher box extents stand in for the scale head -> the 3-D IoU matching of the scorer sees real boxes
+    assert rep["iou_AP"]["IoU50"] >= 0.9 and rep3["iou_AP"]["IoU50"] >= 0.9
+    assert rep["pose_AP"]["10deg_5cm"] >= 0.9 and rep3["pose_AP"]["5deg_5cm"] >= rep["pose_AP"]["5deg_5cm"]
 
 
 def test_checkpoint_directory_layout(ev, tmp_path):
