@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcppf_hip.so")
-SOURCES = ["cppf_core.hip", "cppf_vote.hip", "cppf_shot.hip", "cppf_prep.hip", "cppf_refine.hip", "cppf_mlp.hip"]
+SOURCES = ["cppf_core.hip", "cppf_vote.hip", "cppf_shot.hip", "cppf_prep.hip", "cppf_refine.hip", "cppf_mlp.hip", "cppf_mlp_split.hip"]
 # -ffp-contract=off: every float op rounds where it is written (bit-exact vote grid); fused ops are explicit fmaf().
 # -munsafe-fp-atomics: native ds/global float64 atomic add for the rotation-bin partial sums.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -8,6 +8,7 @@ load_reference_checkpoint().
 """
 from __future__ import annotations
 
+import os
 from itertools import combinations
 
 import torch
@@ -35,6 +36,60 @@ def _stack(dims):
     return nn.Sequential(*[ResLayer(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
 
 
+# Arithmetic of the inference MLPs on the GPU: "split" = every ResLayer as one kernel on the bf16 matrix cores with each
+# float32 operand split exactly into three bf16 values (cppf_reslayer_split: float32-equivalent accuracy, 2-3x the rate of
+# the f32-input matrix instruction); "native" = f32-input matrix cores (library GEMMs + cppf_reslayer128).
+MLP_ARITH = os.environ.get("CPPF_MLP_ARITH", "split")
+
+
+def split_bf16(w):
+    """float32 tensor -> bfloat16 [3, ...]: w == hi + mid + lo exactly (round-to-nearest-even each, exact remainders)."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo])
+
+
+def pack_split(w1, w0, w2, k_in):
+    """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
+    nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights).
+    One operand fragment = 64 lanes x 8 bf16; lane = 32 g + i multiplies output feature 32 u + i of tile u; a tile is its
+    (hi, mid, lo) fragments; a chunk is one K step (16 input features) of all tiles of a phase:
+      phase 1 (W1, all N/32 tiles), step s: lane half g holds input features 16 s + 8 g + j, j < 8;
+      then per output half (one half for N <= 128, two otherwise):
+        [W0 of the half's tiles, same K order as phase 1]  (projection skip only)
+        W2 of the half's tiles, step (t, s') over the hidden features in the accumulator order of the first product:
+        lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2)."""
+    n = w1.shape[0]
+    nt = n // 32
+    nh = 2 if nt > 4 else 1
+    nth = nt // nh
+    ks1 = (k_in + 15) // 16
+    dev = w1.device
+
+    def pack_x(w, first, tiles):
+        s = split_bf16(F.pad(w.detach().float(), (0, ks1 * 16 - w.shape[1])))[:, 32 * first:32 * (first + tiles)]
+        return s.reshape(3, tiles, 32, ks1, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)      # [s, u, slice, g, i, j]
+
+    def pack_h(w, first, tiles):
+        t = torch.arange(nt, device=dev).view(nt, 1, 1, 1)
+        sp = torch.arange(2, device=dev).view(1, 2, 1, 1)
+        g = torch.arange(2, device=dev).view(1, 1, 2, 1)
+        j = torch.arange(8, device=dev).view(1, 1, 1, 8)
+        col = (32 * t + 16 * sp + 4 * g + (j & 3) + 8 * (j >> 2)).reshape(-1)
+        s = split_bf16(w)[:, 32 * first:32 * (first + tiles)][:, :, col]
+        return s.reshape(3, tiles, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)  # [t, s', u, slice, g, i, j]
+
+    parts = [pack_x(w1, 0, nt)]
+    for hf in range(nh):
+        if w0 is not None:
+            parts.append(pack_x(w0, hf * nth, nth))
+        parts.append(pack_h(w2, hf * nth, nth))
+    return torch.cat(parts).contiguous()
+
+
 def _fused_plan(seq):
     """Per-layer (W1^T, b1', W0^T | None, b0', W2^T) with the pending-offset algebra of fused_stack applied once; cached
     on the module and rebuilt when any parameter changed (version counters) or moved."""
@@ -52,10 +107,10 @@ def _fused_plan(seq):
                 b0 = layer.fc0.bias + b2
                 if c is not None:
                     b0 = torch.addmv(b0, layer.fc0.weight, c)
-                plan.append((w1.t(), b1.clone(), layer.fc0.weight.t(), b0, w2.t()))
+                plan.append([w1.t(), b1.clone(), layer.fc0.weight.t(), b0, w2.t(), None])
                 c = None
             else:
-                plan.append((w1.t(), b1.clone(), None, None, w2.t()))
+                plan.append([w1.t(), b1.clone(), None, None, w2.t(), None])
                 c = b2.clone() if c is None else c + b2
     seq._fused_plan_cache = (stamp, (plan, c))
     return plan, c
@@ -76,7 +131,19 @@ def fused_stack(seq, x, keep_input=False):
     unless keep_input is set.
     The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
     plan, c = _fused_plan(seq)
-    for li, (w1t, b1, w0t, b0, w2t) in enumerate(plan):
+    for li, entry in enumerate(plan):
+        w1t, b1, w0t, b0, w2t = entry[:5]
+        n_out = w1t.shape[1]
+        if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.shape[1] >= w1t.shape[0] and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
+            # the whole layer as one kernel on the bf16 matrix cores, float32-equivalent split arithmetic
+            if entry[5] is None or entry[5][0] != x.shape[1]:
+                entry[5] = (x.shape[1], pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1]))
+            out = None
+            if w0t is None and li == 0 and keep_input:
+                out = torch.empty_like(x)
+            x = ops.reslayer_split(x, entry[5][1], b1, b0, n_out, out=out)
+            continue
         if (w0t is None and w1t.shape == (128, 128) and x.dtype == torch.float32 and x.is_contiguous()
                 and not (li == 0 and keep_input)):
             # 128-wide identity-skip layer: both GEMMs, the bias, the ReLU and the residual add in one matrix-core kernel

@@ -1,0 +1,182 @@
+"""cppf_reslayer_split: the ResLayers of the tuple / point MLPs (train_shot.py:19-45) on the bf16 matrix cores in
+float32-equivalent split arithmetic.  CPU part: the exact three-way split and the documented weight-stream order;
+GPU part: the kernel against a float64 evaluation, next to the library float32 path's error against the same."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+SHAPES = [(128, 128, False), (360, 128, True), (128, 256, True), (256, 256, False), (256, 192, True), (352, 128, True),
+          (128, 64, True), (256, 128, True), (64, 64, False), (288, 128, True), (192, 192, False)]
+
+
+def _layer(k, n, proj, dev, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w1 = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    w2 = (torch.randn(n, n, generator=g) / n ** 0.5).to(dev)
+    w0 = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev) if proj else None
+    b1 = (torch.randn(n, generator=g) * 0.1).to(dev)
+    b0 = (torch.randn(n, generator=g) * 0.1).to(dev) if proj else None
+    return w1, b1, w0, b0, w2
+
+
+def _ref64(x, w1, b1, w0, b0, w2):
+    x = x.double()
+    h = torch.relu(x @ w1.double().t() + b1.double())
+    skip = x if w0 is None else x @ w0.double().t() + b0.double()
+    return skip + h @ w2.double().t()
+
+
+def test_split_is_exact_and_stream_order_is_the_documented_one():
+    from cppf2_amd import models, ops
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(64, 40, generator=g) * torch.logspace(-6, 6, 40)[None]
+    s = models.split_bf16(w)
+    assert s.dtype == torch.bfloat16 and s.shape == (3, 64, 40)
+    assert torch.equal((s[0].float() + s[1].float()) + s[2].float(), w)             # exact: 8 + 8 + 8 significand bits
+    assert torch.equal(s[0], w.to(torch.bfloat16))
+    for k, n, proj in SHAPES:
+        w1, b1, w0, b0, w2 = _layer(k, n, proj, "cpu", seed=k + n)
+        k_in = k + (8 if k == 288 else 0)                                           # x wider than dim_in: zero weights
+        q = models.pack_split(w1, w0, w2, k_in)
+        assert q.dtype == torch.bfloat16
+        assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(k_in, n, int(proj))
+        # walk the stream the way the header describes it and rebuild the three matrices
+        nt = n // 32
+        nh = 2 if nt > 4 else 1
+        nth = nt // nh
+        ks1 = (k_in + 15) // 16
+        f = q.float().numpy()
+        pos = 0
+
+        def take(tiles, steps):
+            nonlocal pos
+            c = f[pos:pos + steps * tiles * 3 * 512].reshape(steps, tiles, 3, 2, 32, 8)   # [step, tile, slice, g, i, j]
+            pos += c.size
+            return c.sum(2)                                                                # hi + mid + lo
+        c1 = take(nt, ks1)
+        got1 = np.zeros((n, ks1 * 16), np.float32)
+        for s_ in range(ks1):
+            for g_ in range(2):
+                got1[:, 16 * s_ + 8 * g_:16 * s_ + 8 * g_ + 8] = c1[s_, :, g_].reshape(n, 8)
+        assert np.array_equal(got1[:, :k], w1.numpy()) and not got1[:, k:].any()
+        got2 = np.zeros((n, n), np.float32)
+        for hf in range(nh):
+            if proj:
+                c0 = take(nth, ks1)
+                for s_ in range(ks1):
+                    for g_ in range(2):
+                        blk = c0[s_, :, g_].reshape(nth * 32, 8)
+                        cols = slice(16 * s_ + 8 * g_, 16 * s_ + 8 * g_ + 8)
+                        want = np.zeros((nth * 32, 8), np.float32)
+                        src = w0.numpy()[32 * hf * nth:32 * (hf + 1) * nth, cols]
+                        want[:, :src.shape[1]] = src
+                        assert np.array_equal(blk, want)
+            c2 = take(nth, 2 * nt)
+            for t in range(nt):
+                for sp in range(2):
+                    for g_ in range(2):
+                        for j in range(8):
+                            col = 32 * t + 16 * sp + 4 * g_ + (j & 3) + 8 * (j >> 2)
+                            got2[32 * hf * nth:32 * (hf + 1) * nth, col] = c2[2 * t + sp, :, g_, :, j].reshape(-1)
+        assert pos == f.size and np.array_equal(got2, w2.numpy())
+    assert ops._L.cppf_reslayer_split_stream_bytes(128, 96 + 1, 0) == -1 and ops._L.cppf_reslayer_split_stream_bytes(128, 320, 0) == -1
+
+
+@pytest.mark.gpu
+def test_reslayer_split_matches_float64_like_a_float32_gemm():
+    from cppf2_amd import models, ops
+    dev = torch.device("cuda:0")
+    worst = 0.0
+    for k, n, proj in SHAPES:
+        w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=k * 7 + n)
+        wq = models.pack_split(w1, w0, w2, k)
+        for rows in (1, 31, 257, 3001):
+            x = torch.randn(rows, k, device=dev, generator=torch.Generator(device=dev).manual_seed(rows))
+            want = _ref64(x, w1, b1, w0, b0, w2)
+            got = ops.reslayer_split(x.clone(), wq, b1, b0, n)
+            h = torch._addmm_activation(b1, x, w1.t())
+            nat = torch.addmm(x if w0 is None else torch.addmm(b0, x, w0.t()), h, w2.t())
+            scale = want.abs().max().item()
+            e_split = (got.double() - want).abs().max().item() / scale
+            e_nat = (nat.double() - want).abs().max().item() / scale
+            # float32-equivalent: a few units of 2^-24 of the largest output, and no worse than 3x what the library's
+            # float32 GEMMs (f32-input matrix cores) leave against the same float64 evaluation
+            assert e_split < 2e-6, (k, n, proj, rows, e_split)
+            assert e_split < 3.0 * e_nat + 2e-7, (k, n, proj, rows, e_split, e_nat)
+            worst = max(worst, e_split / max(e_nat, 1e-9))
+    # in place on a strided view (row stride > k), rows of the parent beyond the view untouched; NaN stays NaN through relu
+    k = n = 128
+    w1, b1, w0, b0, w2 = _layer(k, n, False, dev)
+    wq = models.pack_split(w1, None, w2, k)
+    buf = torch.randn(300, 160, device=dev)
+    keep = buf.clone()
+    view = buf[:290, 16:144]
+    want = _ref64(view, w1, b1, None, None, w2)
+    ops.reslayer_split(view, wq, b1, None, n)
+    assert (view.double() - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    assert torch.equal(buf[290:], keep[290:]) and torch.equal(buf[:, :16], keep[:, :16]) and torch.equal(buf[:, 144:], keep[:, 144:])
+    x = torch.randn(64, 128, device=dev)
+    x[3, 5] = float("nan")
+    got = ops.reslayer_split(x.clone(), wq, b1, None, n)
+    assert torch.isnan(got[3]).all() and not torch.isnan(got[[0, 1, 2, 4]]).any()
+    # out of place for an identity layer (fused_stack's keep_input) leaves x alone
+    x = torch.randn(100, 128, device=dev)
+    x0 = x.clone()
+    out = ops.reslayer_split(x, wq, b1, None, n, out=torch.empty_like(x))
+    assert torch.equal(x, x0) and torch.equal(out, ops.reslayer_split(x.clone(), wq, b1, None, n))
+    # rows are independent of the batch they sit in (no split-K, no M-dependent tiling): bit-identical
+    assert torch.equal(out[:37], ops.reslayer_split(x[:37].clone(), wq, b1, None, n))
+
+
+@pytest.mark.gpu
+def test_reslayer_split_rejects_bad_arguments():
+    from cppf2_amd import models, ops, _lib
+    dev = torch.device("cuda:0")
+    w1, b1, w0, b0, w2 = _layer(128, 128, False, dev)
+    wq = models.pack_split(w1, None, w2, 128)
+    x = torch.randn(8, 128, device=dev)
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split(x, wq[:-8], b1, None, 128)                       # stream size mismatch
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split(x, wq, b1, None, 96, out=torch.empty(8, 96, device=dev))   # unsupported width
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split(torch.randn(8, 132, device=dev), wq, b1, None, 128, out=torch.empty(8, 128, device=dev))   # k_in % 8
+    assert not ops.reslayer_split_supported(132, 128, False) and ops.reslayer_split_supported(360, 128, True)
+
+
+@pytest.mark.gpu
+def test_models_split_arithmetic_matches_native_and_module_forward():
+    """The inference stacks in split arithmetic against the f32-input path and the plain nn.Module forward
+    (train_shot.py:100-122, train_dino.py:118-133): same network, float32-level differences only."""
+    from cppf2_amd import models
+    from cppf2_amd.config import load_config
+    dev = torch.device("cuda:0")
+    cfg = load_config("config", "config", ["category=bottle"])
+    torch.manual_seed(3)
+    shot = models.BeyondCPPFShot(cfg).to(dev).eval()
+    dino = models.BeyondCPPFDino(cfg).to(dev).eval()
+    x = torch.randn(5000, 360, device=dev)
+    sf = torch.randn(3000, 352, device=dev)
+    xd = torch.randn(5000, dino.ncoord + 256, device=dev)
+    prev = models.MLP_ARITH
+    try:
+        outs = {}
+        for mode in ("split", "native"):
+            models.MLP_ARITH = mode
+            with torch.no_grad():
+                outs[mode] = (shot.heads(x.clone()), shot.heads(x.clone(), lazy_scale=True), shot.encode_points(sf.clone()),
+                              dino.heads(xd.clone()))
+        with torch.no_grad():
+            feat = shot.tuple_encoder(x)
+            ref = (shot.logit_encoder(feat).reshape(-1, 6, 32), shot.scale_encoder(feat), shot.shot_encoder(sf))
+            featd = dino.tuple_encoder(xd)
+            refd = (dino.logit_encoder(featd).reshape(-1, 6, 32), dino.scale_encoder(featd))
+    finally:
+        models.MLP_ARITH = prev
+    for mode in ("split", "native"):
+        (cls, sc), (cls_l, feat_l), pts, (dcls, dsc) = outs[mode]
+        for got, want in ((cls, ref[0]), (sc, ref[1]), (cls_l, ref[0]), (pts, ref[2]), (dcls, refd[0]), (dsc, refd[1])):
+            assert got.shape == want.shape
+            assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), mode
+        assert (shot.scale_head(feat_l) - ref[1]).abs().max().item() < 2e-5
