@@ -33,133 +33,199 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef RS_DMA
-#define RS_DMA 1
+#ifndef RS_PREFETCH_MAX_NT
+#define RS_PREFETCH_MAX_NT 8
 #endif
 #define RS_THREADS 512
 #define RS_WAVES 8
 #define RS_BLOCK_ROWS 256
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
 #define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
-#define RS_STAGE_BYTES (8 * RS_TILE_BYTES)      // one K step of up to 8 output tiles
+#define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-struct RsFrag {
-  bf16x8 h, m, l;
+// K steps per staged chunk (one barrier per chunk): as many as fit a stage
+__host__ __device__ constexpr int rs_spc(int tiles) { return tiles >= 5 ? 2 : 4; }
+
+struct RsFrag {                                  // one operand fragment per slice, as raw dwords (2 bf16 each)
+  unsigned h[4], m[4], l[4];
 };
 
-// exact three-way split of 8 floats (each step rounds to nearest even; the remainders are exact in float32)
+// exact three-way split of two floats into packed bf16 pairs (each step rounds to nearest even; the remainders are
+// exact in float32): dword p of a fragment's (hi, mid, lo)
+template <bool PIN = false>
+__device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+  // PIN: an opaque copy of the inputs keeps the arithmetic where it is written (between two tiles' MFMAs); without it the
+  // compiler gathers the splits of a whole chunk in front of the chunk's first MFMA (12 registers per K step, no overlap)
+  if (PIN) asm volatile("" : "+v"(v0), "+v"(v1));
+  const f32x2 v = {v0, v1};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
 __device__ __forceinline__ RsFrag rs_split(const float (&v)[8]) {
   RsFrag f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    const float r1 = v[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    f.h[i] = h;
-    f.m[i] = m;
-    f.l[i] = (__bf16)r2;
-  }
+  for (int p = 0; p < 4; ++p) rs_split_pair(v[2 * p], v[2 * p + 1], f.h[p], f.m[p], f.l[p]);
   return f;
+}
+
+__device__ __forceinline__ f32x16 rs_mfma(const unsigned (&a)[4], const unsigned (&b)[4], const f32x16& c) {
+  const u32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 
 // acc += A B over one K step of 16 with both operands split: six exact-product MFMAs, smallest terms first
 __device__ __forceinline__ void rs_mma6(f32x16& acc, const RsFrag& a, const RsFrag& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+  acc = rs_mfma(a.l, b.h, acc);
+  acc = rs_mfma(a.h, b.l, acc);
+  acc = rs_mfma(a.m, b.m, acc);
+  acc = rs_mfma(a.m, b.h, acc);
+  acc = rs_mfma(a.h, b.m, acc);
+  acc = rs_mfma(a.h, b.h, acc);
 }
 
-// the weight stream of one layer, consumed in order by every wavefront of the workgroup (see pack_split):
-//   KS1 chunks of NT tiles (W1), then per output half: [KS1 chunks of NTH tiles (W0)] + 2 NT chunks of NTH tiles (W2)
-template <int NT, int NTH>
+// The weight stream of one layer, consumed in order by every wavefront of the workgroup (cppf2_amd.models.pack_split):
+// segment 0 = ks1 K steps of T0 tiles (W1; for a narrow projection layer W1 and W0 side by side), then per output half
+// [XH: W0 of the half, ks1 steps of NTH tiles] + W2 of the half (2 NT steps of NTH tiles).  It moves through a two-stage
+// LDS ring in chunks of up to rs_spc(tiles) K steps of one segment.
+template <int NT, int T0, int NTH, bool XH>
 struct RsStream {
+  static constexpr int NSEG = 1 + (NT / NTH) * (XH ? 2 : 1);
   const char* base;            // packed stream in global memory
   char* ring;                  // LDS, two stages
-  int ks1, chunks;             // chunks per row block
-  int next;                    // chunk (within the layer) the next DMA fetches
+  int ks1;
+  int seg, pos;                // segment / K step within it the next DMA starts at
+  int64_t off;                 // its byte offset
   int64_t left;                // chunks still to fetch over the remaining row blocks of this workgroup
   int stage;                   // stage the next acquire() returns
   int wave, lane;
 
+  __device__ __forceinline__ int chunks_per_block() const {
+    const int cx = (ks1 + rs_spc(T0) - 1) / rs_spc(T0), cxh = (ks1 + rs_spc(NTH) - 1) / rs_spc(NTH);
+    return cx + (NT / NTH) * ((XH ? cxh : 0) + 2 * NT / rs_spc(NTH));
+  }
   __device__ __forceinline__ void issue(int st) {
     if (left <= 0) return;
-    const int tiles = next < ks1 ? NT : NTH;
-    const int64_t off = next < ks1 ? (int64_t)next * (NT * RS_TILE_BYTES)
-                                   : (int64_t)ks1 * (NT * RS_TILE_BYTES) + (int64_t)(next - ks1) * (NTH * RS_TILE_BYTES);
+    const bool first = seg == 0;
+    const int tiles = first ? T0 : NTH;
+    const int spc = first ? rs_spc(T0) : rs_spc(NTH);
+    const int steps = (first || (XH && (seg & 1))) ? ks1 : 2 * NT;
+    const int ns = steps - pos < spc ? steps - pos : spc;
+    const int pieces = ns * tiles * 3;
     const char* src = base + off + lane * 16;
     char* dst = ring + st * RS_STAGE_BYTES;
-    for (int j = wave; j < tiles * 3; j += RS_WAVES) {
-#if RS_DMA
+    for (int j = wave; j < pieces; j += RS_WAVES) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * RS_FRAG_BYTES),
                                        (__attribute__((address_space(3))) void*)(dst + j * RS_FRAG_BYTES), 16, 0, 0);
-#else
-      *reinterpret_cast<uint4*>(dst + j * RS_FRAG_BYTES + lane * 16) = *reinterpret_cast<const uint4*>(src + j * RS_FRAG_BYTES);
-#endif
     }
-    next = (next + 1 == chunks) ? 0 : next + 1;
+    off += (int64_t)pieces * RS_FRAG_BYTES;
+    pos += ns;
+    if (pos == steps) {
+      pos = 0;
+      if (++seg == NSEG) {
+        seg = 0;
+        off = 0;
+      }
+    }
     --left;
   }
   // the stage holding the next chunk in stream order; its DMA was issued one chunk earlier.  Every wavefront waits for
   // its own pieces (vmcnt) before the barrier, so after it the whole chunk is in LDS and the other stage is free.
-  __device__ __forceinline__ const bf16x8* acquire() {
+  __device__ __forceinline__ const u32x4* acquire() {
     __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) lgkmcnt(0) expcnt(0)
     __syncthreads();
     const int cur = stage;
     stage ^= 1;
     issue(stage);
-    return reinterpret_cast<const bf16x8*>(ring + cur * RS_STAGE_BYTES) + lane;
+    return reinterpret_cast<const u32x4*>(ring + cur * RS_STAGE_BYTES) + lane;
   }
 };
 
-__device__ __forceinline__ RsFrag rs_read(const bf16x8* w, int tile) {
+__device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
   RsFrag a;
-  a.h = w[(tile * 3 + 0) * 64];
-  a.m = w[(tile * 3 + 1) * 64];
-  a.l = w[(tile * 3 + 2) * 64];
+  const u32x4 h = w[(tile * 3 + 0) * 64], m = w[(tile * 3 + 1) * 64], l = w[(tile * 3 + 2) * 64];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    a.h[p] = h[p];
+    a.m[p] = m[p];
+    a.l[p] = l[p];
+  }
   return a;
 }
 
-// one K step: acc[u] += W[tile u] b for the NTILES tiles of the staged chunk.  The fragments of tile u + 1 are requested from
-// LDS before the six MFMAs of tile u issue (their 192 cycles cover the read); the scheduling barrier per tile keeps the
-// compiler from hoisting all the reads of a step to its front (12 registers per tile in flight).
-template <int NTILES>
-__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const bf16x8* w, const RsFrag& b) {
-  RsFrag a = rs_read(w, 0);
+// one K step: acc[u] += W[tile u] b for the NTILES tiles at w.  The fragments of tile u + 1 are requested from LDS before
+// the six MFMAs of tile u issue (their 192 cycles cover the read); `filler(u)` is independent vector work (the split of
+// the NEXT step's B operand, a quarter per call) placed in front of tile u's MFMAs so that it issues in their shadow;
+// the scheduling barrier per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
+template <int NTILES, bool PREFETCH, class F>
+__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler) {
+  if (PREFETCH) {
+    RsFrag a = rs_read(w, 0);
 #pragma unroll
-  for (int u = 0; u < NTILES; ++u) {
-    RsFrag an = a;
-    if (u + 1 < NTILES) an = rs_read(w, u + 1);
-    rs_mma6(acc[u], a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    a = an;
+    for (int u = 0; u < NTILES; ++u) {
+      RsFrag an = a;
+      if (u + 1 < NTILES) an = rs_read(w, u + 1);
+#pragma unroll
+      for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
+      rs_mma6(acc[u], a, b);
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+    }
+  } else {
+    // no read-ahead (12 registers less): the partner wavefront on the SIMD covers the LDS latency
+#pragma unroll
+    for (int u = 0; u < NTILES; ++u) {
+      const RsFrag a = rs_read(w, u);
+#pragma unroll
+      for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
+      rs_mma6(acc[u], a, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-// acc[u] (u < NTILES) += W[tile u] x^T over all K steps: x is this lane's row, features 16 s + 8 g + (0..7) at step s
-template <int NTILES, int NT, int NTH>
-__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const float* __restrict__ xrow, int k_in, int ks1, int g,
-                                             RsStream<NT, NTH>& ws) {
-  float xn[8];
-  auto fetch = [&](int s) {
-    const int f = 16 * s + 8 * g;
-    f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (f + 8 <= k_in) {
-      v0 = *reinterpret_cast<const f32x4*>(xrow + f);
-      v1 = *reinterpret_cast<const f32x4*>(xrow + f + 4);
+// this lane's 8 values of K step s of its row: features 16 s + 8 g + (0..7), zeros past k_in
+__device__ __forceinline__ void rs_fetch(float (&dst)[8], const float* __restrict__ xrow, int k_in, int s, int g) {
+  const int f = 16 * s + 8 * g;
+  f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (f + 8 <= k_in) {
+    v0 = *reinterpret_cast<const f32x4*>(xrow + f);
+    v1 = *reinterpret_cast<const f32x4*>(xrow + f + 4);
+  }
+  dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+}
+
+// acc[u] (u < NTILES) += W[tile u] x^T over all K steps.  xv holds the row's values of steps 0 and 1 on entry (the caller
+// fetched them, possibly a whole row block earlier); the values of step s + 1 are split while step s multiplies, those
+// of step s + 2 are in flight.
+template <int NTILES, bool PREFETCH, class Stream>
+__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], float (&xv)[2][8], const float* __restrict__ xrow, int k_in,
+                                             int ks1, int g, Stream& ws) {
+  constexpr int SPC = rs_spc(NTILES);
+  RsFrag b = rs_split(xv[0]);
+  for (int s0 = 0; s0 < ks1; s0 += SPC) {
+    const u32x4* w = ws.acquire();
+#pragma unroll
+    for (int i = 0; i < SPC; ++i) {                    // SPC is even: step s0 + i splits xv[(i + 1) & 1], refills xv[i & 1]
+      if (s0 + i < ks1) {
+        rs_fetch(xv[i & 1], xrow, k_in, s0 + i + 2, g);
+        RsFrag bn;
+        rs_step<NTILES, PREFETCH>(acc, w + i * NTILES * 3 * 64, b, [&](int p) {
+          rs_split_pair<true>(xv[(i + 1) & 1][2 * p], xv[(i + 1) & 1][2 * p + 1], bn.h[p], bn.m[p], bn.l[p]);
+        });
+        b = bn;
+      }
     }
-    xn[0] = v0.x; xn[1] = v0.y; xn[2] = v0.z; xn[3] = v0.w; xn[4] = v1.x; xn[5] = v1.y; xn[6] = v1.z; xn[7] = v1.w;
-  };
-  fetch(0);
-  for (int s = 0; s < ks1; ++s) {
-    const RsFrag b = rs_split(xn);
-    if (s + 1 < ks1) fetch(s + 1);
-    const bf16x8* w = ws.acquire();
-    rs_step<NTILES>(acc, w, b);
   }
 }
 
@@ -179,6 +245,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
                                                                        const float* __restrict__ b0) {
   constexpr int NH = NT > 4 ? 2 : 1;            // output halves
   constexpr int NTH = NT / NH;
+  constexpr bool FUSE0 = PROJ && NH == 1;       // narrow projection layer: x W0^T rides along with x W1^T (one pass over x)
+  constexpr bool XH = PROJ && !FUSE0;           // wide projection layer: x W0^T per output half
+  constexpr int T0 = FUSE0 ? 2 * NT : NT;       // tiles of the first product
+  constexpr int SPC2 = rs_spc(NTH);
+  constexpr bool PF = RS_PREFETCH_MAX_NT >= NT; // LDS read-ahead of the next tile's fragments
+  constexpr bool AHEAD = NH == 1;               // the next row block's first x values are fetched during the second product
+  static_assert((2 * NT) % SPC2 == 0, "second product: whole chunks");
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, g = lane >> 5;
@@ -186,36 +259,58 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
   const int64_t nblocks = (rows + RS_BLOCK_ROWS - 1) / RS_BLOCK_ROWS;
   const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
 
-  RsStream<NT, NTH> ws;
+  RsStream<NT, T0, NTH, XH> ws;
   ws.base = wq;
   ws.ring = s_ring;
   ws.ks1 = ks1;
-  ws.chunks = ks1 + NH * ((PROJ ? ks1 : 0) + 2 * NT);
-  ws.next = 0;
-  ws.left = mine * ws.chunks;
+  ws.seg = 0;
+  ws.pos = 0;
+  ws.off = 0;
+  ws.left = mine * ws.chunks_per_block();
   ws.stage = 0;
   ws.wave = wave;
   ws.lane = lane;
   ws.issue(0);
   // the biases live in LDS: as kernel-lifetime registers (where the compiler would hoist them) they cost 16 per tile
   float* s_b1 = reinterpret_cast<float*>(s_ring + 2 * RS_STAGE_BYTES);
-  float* s_b0 = s_b1 + 32 * NT;
+  float* s_b0 = s_b1 + 32 * NT;                 // directly behind b1: the fused first product initialises both in one sweep
   for (int i = threadIdx.x; i < 32 * NT; i += RS_THREADS) {
     s_b1[i] = b1[i];
     if (PROJ) s_b0[i] = b0[i];
   }
   __syncthreads();
 
+  auto row_ptr = [&](int64_t blk) {
+    const int64_t row = blk * RS_BLOCK_ROWS + wave * 32 + r;
+    return x + (row < rows ? row : rows - 1) * ldx;
+  };
+  float xv[2][8];
+  if (AHEAD && blockIdx.x < nblocks) {
+    rs_fetch(xv[0], row_ptr(blockIdx.x), k_in, 0, g);
+    rs_fetch(xv[1], row_ptr(blockIdx.x), k_in, 1, g);
+  }
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * RS_BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
-    const int64_t row_c = in ? row : rows - 1;
-    const float* xrow = x + row_c * ldx;
-    // ---- h^T = relu(W1 x^T + b1) ----------------------------------------------------------------------
-    f32x16 h[NT];
+    const float* xrow = row_ptr(blk);
+    // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a narrow projection layer] ---------------------
+    f32x16 acc[T0 + (FUSE0 ? 0 : NTH)];         // h tiles, then the output tiles (of one half)
+    f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
+    f32x16 (&o)[NTH] = *reinterpret_cast<f32x16 (*)[NTH]>(&acc[NT]);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) rs_load_tile(h[u], s_b1 + 32 * u, g);
-    rs_product_x<NT, NT, NTH>(h, xrow, k_in, ks1, g, ws);
+    for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
+    if (!PROJ && AHEAD) {                       // residual of a narrow identity layer: requested before the first product
+#pragma unroll
+      for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
+    }
+    if (!AHEAD) {
+      rs_fetch(xv[0], xrow, k_in, 0, g);
+      rs_fetch(xv[1], xrow, k_in, 1, g);
+    }
+    {
+      f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
+      rs_product_x<T0, PF>(first, xv, xrow, k_in, ks1, g, ws);
+    }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
 #pragma unroll
@@ -224,29 +319,39 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
     // ---- out^T = skip^T + W2 h^T, one half of the output features at a time ------------------------------
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      f32x16 o[NTH];
-      if (PROJ) {
+      if (XH) {
 #pragma unroll
         for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], s_b0 + 32 * (hf * NTH + u), g);
-        rs_product_x<NTH, NT, NTH>(o, xrow, k_in, ks1, g, ws);
-      } else {
+        rs_fetch(xv[0], xrow, k_in, 0, g);
+        rs_fetch(xv[1], xrow, k_in, 1, g);
+        rs_product_x<NTH, PF>(o, xv, xrow, k_in, ks1, g, ws);
+      } else if (!PROJ && !AHEAD) {
 #pragma unroll
         for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * (hf * NTH + u), g);
       }
+      if (AHEAD && blk + gridDim.x < nblocks) {
+        rs_fetch(xv[0], row_ptr(blk + gridDim.x), k_in, 0, g);
+        rs_fetch(xv[1], row_ptr(blk + gridDim.x), k_in, 1, g);
+      }
+      // step (t, sp) contracts over this lane's registers 8 sp .. 8 sp + 7 of h tile t; the split of step + 1 runs in
+      // the shadow of step's MFMAs (pinned there, which also keeps CSE from carrying the split h of the first half over
+      // to the second at 24 registers per tile).
+      RsFrag b;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int p = 0; p < 4; ++p) rs_split_pair(h[0][2 * p], h[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          float hv[8];
+      for (int c = 0; c < 2 * NT / SPC2; ++c) {
+        const u32x4* w = ws.acquire();
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            hv[j] = h[t][8 * sp + j];
-            // the split is recomputed per output half: kept across halves (what CSE would do) it costs 24 registers per h tile
-            if (NH > 1) asm volatile("" : "+v"(hv[j]));
-          }
-          const RsFrag b = rs_split(hv);
-          const bf16x8* w = ws.acquire();
-          rs_step<NTH>(o, w, b);
+        for (int i = 0; i < SPC2; ++i) {
+          const int step = c * SPC2 + i, nx = (step + 1 < 2 * NT) ? step + 1 : step;
+          RsFrag bn = b;
+          rs_step<NTH, PF>(o, w + i * NTH * 3 * 64, b, [&](int p) {
+            if (step + 1 < 2 * NT)
+              rs_split_pair<true>(h[nx >> 1][8 * (nx & 1) + 2 * p], h[nx >> 1][8 * (nx & 1) + 2 * p + 1], bn.h[p], bn.m[p],
+                                  bn.l[p]);
+          });
+          b = bn;
         }
       }
       if (in) {

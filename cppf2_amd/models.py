@@ -56,10 +56,11 @@ def pack_split(w1, w0, w2, k_in):
     """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
     nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights).
     One operand fragment = 64 lanes x 8 bf16; lane = 32 g + i multiplies output feature 32 u + i of tile u; a tile is its
-    (hi, mid, lo) fragments; a chunk is one K step (16 input features) of all tiles of a phase:
-      phase 1 (W1, all N/32 tiles), step s: lane half g holds input features 16 s + 8 g + j, j < 8;
+    (hi, mid, lo) fragments; a K step (16 input features) of a phase is its tiles one after the other:
+      first product, step s: lane half g holds input features 16 s + 8 g + j, j < 8; tiles = all N/32 tiles of W1, and
+        for a projection layer with N <= 128 the N/32 tiles of W0 behind them (one pass over x computes both);
       then per output half (one half for N <= 128, two otherwise):
-        [W0 of the half's tiles, same K order as phase 1]  (projection skip only)
+        [W0 of the half's tiles, same K order]  (projection layers with N > 128 only)
         W2 of the half's tiles, step (t, s') over the hidden features in the accumulator order of the first product:
         lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2)."""
     n = w1.shape[0]
@@ -82,9 +83,10 @@ def pack_split(w1, w0, w2, k_in):
         s = split_bf16(w)[:, 32 * first:32 * (first + tiles)][:, :, col]
         return s.reshape(3, tiles, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)  # [t, s', u, slice, g, i, j]
 
-    parts = [pack_x(w1, 0, nt)]
+    fuse0 = w0 is not None and nh == 1
+    parts = [pack_x(torch.cat([w1, w0]), 0, 2 * nt) if fuse0 else pack_x(w1, 0, nt)]
     for hf in range(nh):
-        if w0 is not None:
+        if w0 is not None and not fuse0:
             parts.append(pack_x(w0, hf * nth, nth))
         parts.append(pack_h(w2, hf * nth, nth))
     return torch.cat(parts).contiguous()

@@ -54,15 +54,19 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
             c = f[pos:pos + steps * tiles * 3 * 512].reshape(steps, tiles, 3, 2, 32, 8)   # [step, tile, slice, g, i, j]
             pos += c.size
             return c.sum(2)                                                                # hi + mid + lo
-        c1 = take(nt, ks1)
-        got1 = np.zeros((n, ks1 * 16), np.float32)
+        fuse0 = proj and nh == 1                      # narrow projection layer: W0's tiles ride behind W1's
+        t0 = 2 * nt if fuse0 else nt
+        c1 = take(t0, ks1)
+        got1 = np.zeros((32 * t0, ks1 * 16), np.float32)
         for s_ in range(ks1):
             for g_ in range(2):
-                got1[:, 16 * s_ + 8 * g_:16 * s_ + 8 * g_ + 8] = c1[s_, :, g_].reshape(n, 8)
-        assert np.array_equal(got1[:, :k], w1.numpy()) and not got1[:, k:].any()
+                got1[:, 16 * s_ + 8 * g_:16 * s_ + 8 * g_ + 8] = c1[s_, :, g_].reshape(32 * t0, 8)
+        assert np.array_equal(got1[:n, :k], w1.numpy()) and not got1[:, k:].any()
+        if fuse0:
+            assert np.array_equal(got1[n:, :k], w0.numpy())
         got2 = np.zeros((n, n), np.float32)
         for hf in range(nh):
-            if proj:
+            if proj and not fuse0:
                 c0 = take(nth, ks1)
                 for s_ in range(ks1):
                     for g_ in range(2):
