@@ -100,7 +100,8 @@ __device__ __forceinline__ void rs_mma6(f32x16& acc, const RsFrag& a, const RsFr
 // LDS ring in chunks of up to rs_spc(tiles) K steps of one segment.
 template <int NT, int T0, int NTH, bool XH>
 struct RsStream {
-  static constexpr int NSEG = 1 + (NT / NTH) * (XH ? 2 : 1);
+  int nseg;                    // 1 + per half (W0?, W2) + per chained identity layer (W1, W2)
+  int chunks;                  // chunks per row block
   const char* base;            // packed stream in global memory
   char* ring;                  // LDS, two stages
   int ks1;
@@ -110,9 +111,10 @@ struct RsStream {
   int stage;                   // stage the next acquire() returns
   int wave, lane;
 
-  __device__ __forceinline__ int chunks_per_block() const {
+  __device__ __forceinline__ void shape(int chain) {
     const int cx = (ks1 + rs_spc(T0) - 1) / rs_spc(T0), cxh = (ks1 + rs_spc(NTH) - 1) / rs_spc(NTH);
-    return cx + (NT / NTH) * ((XH ? cxh : 0) + 2 * NT / rs_spc(NTH));
+    nseg = 1 + (NT / NTH) * (XH ? 2 : 1) + 2 * chain;
+    chunks = cx + (NT / NTH) * ((XH ? cxh : 0) + 2 * NT / rs_spc(NTH)) + chain * 2 * (2 * NT / rs_spc(NTH));
   }
   __device__ __forceinline__ void issue(int st) {
     if (left <= 0) return;
@@ -132,7 +134,7 @@ struct RsStream {
     pos += ns;
     if (pos == steps) {
       pos = 0;
-      if (++seg == NSEG) {
+      if (++seg == nseg) {
         seg = 0;
         off = 0;
       }
@@ -229,6 +231,34 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], float (&xv)[
   }
 }
 
+// dst[u] (u < NTILES) += W[tile u] src^T where src is NS accumulator tiles of this lane's row (the output of a previous
+// product): step (t, sp) contracts over the lane's registers 8 sp .. 8 sp + 7 of src tile t -- the weights are packed in
+// that feature order.  The split of step + 1 runs in the shadow of step's MFMAs (pinned there, which also keeps CSE from
+// carrying the split of one output half over to the next at 24 registers per tile).
+template <int NS, int NTILES, bool PREFETCH, class Stream>
+__device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16 (&src)[NS], Stream& ws) {
+  constexpr int SPC = rs_spc(NTILES);
+  static_assert((2 * NS) % SPC == 0, "whole chunks");
+  RsFrag b;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) rs_split_pair(src[0][2 * p], src[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
+#pragma unroll
+  for (int c = 0; c < 2 * NS / SPC; ++c) {
+    const u32x4* w = ws.acquire();
+#pragma unroll
+    for (int i = 0; i < SPC; ++i) {
+      const int step = c * SPC + i, nx = (step + 1 < 2 * NS) ? step + 1 : step;
+      RsFrag bn = b;
+      rs_step<NTILES, PREFETCH>(dst, w + i * NTILES * 3 * 64, b, [&](int p) {
+        if (step + 1 < 2 * NS)
+          rs_split_pair<true>(src[nx >> 1][8 * (nx & 1) + 2 * p], src[nx >> 1][8 * (nx & 1) + 2 * p + 1], bn.h[p], bn.m[p],
+                              bn.l[p]);
+      });
+      b = bn;
+    }
+  }
+}
+
 // accumulator tile registers <- per-feature values v[32 tile + 8 q + 4 g + c] (bias vectors, rows of x)
 __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g) {
 #pragma unroll
@@ -242,7 +272,7 @@ template <int NT, bool PROJ>
 __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                        int64_t ldo, int64_t rows, const char* __restrict__ wq,
                                                                        const float* __restrict__ b1,
-                                                                       const float* __restrict__ b0) {
+                                                                       const float* __restrict__ b0, int chain) {
   constexpr int NH = NT > 4 ? 2 : 1;            // output halves
   constexpr int NTH = NT / NH;
   constexpr bool FUSE0 = PROJ && NH == 1;       // narrow projection layer: x W0^T rides along with x W1^T (one pass over x)
@@ -266,7 +296,8 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
   ws.seg = 0;
   ws.pos = 0;
   ws.off = 0;
-  ws.left = mine * ws.chunks_per_block();
+  ws.shape(chain);
+  ws.left = mine * ws.chunks;
   ws.stage = 0;
   ws.wave = wave;
   ws.lane = lane;
@@ -278,6 +309,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
     s_b1[i] = b1[i];
     if (PROJ) s_b0[i] = b0[i];
   }
+  for (int i = threadIdx.x; i < 32 * NT * chain; i += RS_THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
   __syncthreads();
 
   auto row_ptr = [&](int64_t blk) {
@@ -333,25 +365,23 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
         rs_fetch(xv[0], row_ptr(blk + gridDim.x), k_in, 0, g);
         rs_fetch(xv[1], row_ptr(blk + gridDim.x), k_in, 1, g);
       }
-      // step (t, sp) contracts over this lane's registers 8 sp .. 8 sp + 7 of h tile t; the split of step + 1 runs in
-      // the shadow of step's MFMAs (pinned there, which also keeps CSE from carrying the split h of the first half over
-      // to the second at 24 registers per tile).
-      RsFrag b;
+      rs_product_h<NT, NTH, PF>(o, h, ws);
+      if (NH == 1) {
+        // ---- the identity layers chained behind (same width): x <- x + relu(x W1^T + b1) W2^T with x = the output tiles,
+        // never leaving the registers; their W1 is packed in accumulator feature order like every W2
+#pragma unroll 1
+        for (int l = 0; l < chain; ++l) {
+          const float* bl = s_b1 + 32 * NT * (2 + l);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rs_split_pair(h[0][2 * p], h[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
+          for (int u = 0; u < NT; ++u) rs_load_tile(h[u], bl + 32 * u, g);
+          f32x16 (&xo)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
+          rs_product_h<NT, NT, PF>(h, xo, ws);
 #pragma unroll
-      for (int c = 0; c < 2 * NT / SPC2; ++c) {
-        const u32x4* w = ws.acquire();
+          for (int u = 0; u < NT; ++u) {
 #pragma unroll
-        for (int i = 0; i < SPC2; ++i) {
-          const int step = c * SPC2 + i, nx = (step + 1 < 2 * NT) ? step + 1 : step;
-          RsFrag bn = b;
-          rs_step<NTH, PF>(o, w + i * NTH * 3 * 64, b, [&](int p) {
-            if (step + 1 < 2 * NT)
-              rs_split_pair<true>(h[nx >> 1][8 * (nx & 1) + 2 * p], h[nx >> 1][8 * (nx & 1) + 2 * p + 1], bn.h[p], bn.m[p],
-                                  bn.l[p]);
-          });
-          b = bn;
+            for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];
+          }
+          rs_product_h<NT, NT, PF>(xo, h, ws);
         }
       }
       if (in) {
@@ -370,40 +400,44 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
   }
 }
 
-extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj) {
-  if (k_in <= 0 || n_out <= 0 || (n_out & 31) || n_out > 256) return -1;
+extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
+  if (k_in <= 0 || n_out <= 0 || (n_out & 31) || n_out > 256 || chain < 0 || chain > 15) return -1;
   const int nt = n_out / 32, nh = nt > 4 ? 2 : 1, nth = nt / nh;
-  if (nt != nth * nh) return -1;
+  if (nt != nth * nh || (chain > 0 && nh != 1)) return -1;
   const int64_t ks1 = (k_in + 15) / 16;
-  return ks1 * nt * RS_TILE_BYTES + (int64_t)nh * ((proj ? ks1 : 0) + 2 * nt) * nth * RS_TILE_BYTES;
+  return ks1 * nt * RS_TILE_BYTES + (int64_t)nh * ((proj ? ks1 : 0) + 2 * nt) * nth * RS_TILE_BYTES +
+         (int64_t)chain * 2 * (2 * nt) * nt * RS_TILE_BYTES;
 }
 
 template <int NT, bool PROJ>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
-                     const float* b1, const float* b0, int cus, hipStream_t stream) {
-  const int lds_bytes = 2 * RS_STAGE_BYTES + 2 * 32 * NT * 4;
+                     const float* b1, const float* b0, int chain, int cus, hipStream_t stream) {
+  const int lds_bytes = 2 * RS_STAGE_BYTES + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + RS_BLOCK_ROWS - 1) / RS_BLOCK_ROWS;
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
   hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ>), dim3(grid), dim3(RS_THREADS), lds_bytes, stream, x, ldx, k_in, out, ldo,
-                     rows, wq, b1, b0);
+                     rows, wq, b1, b0, chain);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
 
-// out[rows, n_out] = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T with skip = x (b0 == NULL; then k_in == n_out and out may
-// be x itself) or x W0^T + b0.  x float32 [rows, >= k_in] with row stride ldx, out float32 with row stride ldo (device;
-// 16-byte aligned rows: ldx, ldo multiples of 4); k_in a multiple of 8; n_out in {64, 128, 192, 256}.  wq = the layer's
-// weights as the packed split stream (cppf_reslayer_split_stream_bytes bytes; cppf2_amd.models.pack_split documents the
-// order).  The second layer's bias is the caller's (carried as a pending offset by cppf2_amd.models.fused_stack).
+// out[rows, n_out] = L_chain(...L_1(L_0(x))): L_0(x) = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T with skip = x (b0 == NULL;
+// then k_in == n_out and out may be x itself) or x W0^T + b0, followed by `chain` identity-skip layers of the same width
+// (n_out <= 128) evaluated on the output tiles in registers.  x float32 [rows, >= k_in] with row stride ldx, out float32
+// with row stride ldo (device; 16-byte aligned rows: ldx, ldo multiples of 4); k_in a multiple of 8; n_out in {64, 128,
+// 192, 256}.  wq = the layers' weights as the packed split stream (cppf_reslayer_split_stream_bytes bytes;
+// cppf2_amd.models.pack_split documents the order); b1 = float32[(1 + chain) * n_out], the first-layer biases of L_0,
+// L_1, ...  The second-layer biases are the caller's (carried as a pending offset by cppf2_amd.models.fused_stack).
 extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out,
                                    int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
-                                   void* stream) {
+                                   int32_t chain, void* stream) {
   CPPF_CHECK_ARG(x && out && wq && b1 && rows >= 0);
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out);
   CPPF_CHECK_ARG(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256);
   CPPF_CHECK_ARG(b0 != nullptr || k_in == n_out);
+  CPPF_CHECK_ARG(chain >= 0 && chain <= 15 && (chain == 0 || n_out <= 128));
   CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
-  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr));
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr, chain));
   if (rows == 0) return CPPF_OK;
   static std::mutex mu;
   static int cus[64] = {0};
@@ -422,13 +456,13 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
   hipStream_t st = (hipStream_t)stream;
   const bool proj = b0 != nullptr;
   switch (n_out / 32) {
-    case 2: return proj ? rs_launch<2, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st)
-                        : rs_launch<2, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st);
-    case 4: return proj ? rs_launch<4, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st)
-                        : rs_launch<4, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st);
-    case 6: return proj ? rs_launch<6, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st)
-                        : rs_launch<6, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st);
-    default: return proj ? rs_launch<8, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st)
-                         : rs_launch<8, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, n_cu, st);
+    case 2: return proj ? rs_launch<2, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
+                        : rs_launch<2, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
+    case 4: return proj ? rs_launch<4, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
+                        : rs_launch<4, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
+    case 6: return proj ? rs_launch<6, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
+                        : rs_launch<6, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
+    default: return proj ? rs_launch<8, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
+                         : rs_launch<8, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
   }
 }

@@ -52,9 +52,10 @@ def split_bf16(w):
     return torch.stack([hi, mid, lo])
 
 
-def pack_split(w1, w0, w2, k_in):
+def pack_split(w1, w0, w2, k_in, chain=()):
     """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
-    nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights).
+    nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights), optionally
+    followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width N <= 128.
     One operand fragment = 64 lanes x 8 bf16; lane = 32 g + i multiplies output feature 32 u + i of tile u; a tile is its
     (hi, mid, lo) fragments; a K step (16 input features) of a phase is its tiles one after the other:
       first product, step s: lane half g holds input features 16 s + 8 g + j, j < 8; tiles = all N/32 tiles of W1, and
@@ -62,7 +63,9 @@ def pack_split(w1, w0, w2, k_in):
       then per output half (one half for N <= 128, two otherwise):
         [W0 of the half's tiles, same K order]  (projection layers with N > 128 only)
         W2 of the half's tiles, step (t, s') over the hidden features in the accumulator order of the first product:
-        lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2)."""
+        lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2);
+      then per chained layer W1_l and W2_l, both in that accumulator feature order (their input is the previous layer's
+      output tiles in registers)."""
     n = w1.shape[0]
     nt = n // 32
     nh = 2 if nt > 4 else 1
@@ -89,6 +92,9 @@ def pack_split(w1, w0, w2, k_in):
         if w0 is not None and not fuse0:
             parts.append(pack_x(w0, hf * nth, nth))
         parts.append(pack_h(w2, hf * nth, nth))
+    for w1_l, w2_l in chain:
+        assert nh == 1 and w1_l.shape == (n, n) and w2_l.shape == (n, n)
+        parts += [pack_h(w1_l, 0, nt), pack_h(w2_l, 0, nt)]
     return torch.cat(parts).contiguous()
 
 
@@ -133,21 +139,34 @@ def fused_stack(seq, x, keep_input=False):
     unless keep_input is set.
     The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
     plan, c = _fused_plan(seq)
-    for li, entry in enumerate(plan):
+    li = 0
+    while li < len(plan):
+        entry = plan[li]
         w1t, b1, w0t, b0, w2t = entry[:5]
         n_out = w1t.shape[1]
         if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.shape[1] >= w1t.shape[0] and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
-            # the whole layer as one kernel on the bf16 matrix cores, float32-equivalent split arithmetic
-            if entry[5] is None or entry[5][0] != x.shape[1]:
-                entry[5] = (x.shape[1], pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1]))
+            # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
+            # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
+            chain = 0
+            while (n_out <= 128 and li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None
+                   and plan[li + 1 + chain][0].shape == (n_out, n_out) and chain < 15):
+                chain += 1
+            key = (x.shape[1], chain)
+            if entry[5] is None or entry[5][0] != key:
+                rest = plan[li + 1:li + 1 + chain]
+                wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1],
+                                chain=[(e[0].t(), e[4].t()) for e in rest])
+                entry[5] = (key, wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
             out = None
             if w0t is None and li == 0 and keep_input:
                 out = torch.empty_like(x)
-            x = ops.reslayer_split(x, entry[5][1], b1, b0, n_out, out=out)
+            x = ops.reslayer_split(x, entry[5][1], entry[5][2], b0, n_out, out=out, chain=chain)
+            li += 1 + chain
             continue
+        li += 1
         if (w0t is None and w1t.shape == (128, 128) and x.dtype == torch.float32 and x.is_contiguous()
-                and not (li == 0 and keep_input)):
+                and not (li == 1 and keep_input)):
             # 128-wide identity-skip layer: both GEMMs, the bias, the ReLU and the residual add in one matrix-core kernel
             # that reads and writes the activation once (cppf_reslayer128); w1t / w2t are transposed views of the weights
             x = ops.reslayer128_(x, w1t.t(), b1, w2t.t())
@@ -155,7 +174,7 @@ def fused_stack(seq, x, keep_input=False):
         h = torch._addmm_activation(b1, x, w1t)
         if w0t is not None:
             x = torch.addmm(b0, x, w0t)
-        elif li == 0 and keep_input:
+        elif li == 1 and keep_input:
             x = torch.addmm(x, h, w2t)              # same GEMM, written to a new tensor: the caller's x survives
             continue
         x = x.addmm_(h, w2t)

@@ -265,25 +265,27 @@ def reslayer128_(x, w1, b1, w2):
     return x
 
 
-def reslayer_split_supported(k_in, n_out, proj):
-    """True when cppf_reslayer_split has a kernel for a ResLayer of these dims (k_in = columns of x it reads)."""
-    return k_in % 8 == 0 and _L.cppf_reslayer_split_stream_bytes(int(k_in), int(n_out), int(bool(proj))) > 0
+def reslayer_split_supported(k_in, n_out, proj, chain=0):
+    """True when cppf_reslayer_split has a kernel for a ResLayer of these dims (k_in = columns of x it reads) followed by
+    `chain` identity layers of the same width."""
+    return k_in % 8 == 0 and _L.cppf_reslayer_split_stream_bytes(int(k_in), int(n_out), int(bool(proj)), int(chain)) > 0
 
 
-def reslayer_split(x, wq, b1, b0, n_out, out=None):
-    """out = skip(x) + relu(x W1^T + b1) W2^T on the bf16 matrix cores in float32-equivalent split arithmetic
-    (cppf_reslayer_split).  x float32 [rows, k_in] (device; row stride a multiple of 4 elements), wq the layer's packed
-    split weight stream (models.pack_split), b1 [n_out], b0 [n_out] or None for an identity skip (then out defaults to x:
-    in place).  Returns out."""
+def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0):
+    """out = skip(x) + relu(x W1^T + b1) W2^T, then `chain` identity ResLayers of the same width on the result, on the
+    bf16 matrix cores in float32-equivalent split arithmetic (cppf_reslayer_split).  x float32 [rows, k_in] (device; row
+    stride a multiple of 4 elements), wq the packed split weight stream (models.pack_split), b1 [(1 + chain) * n_out] (the
+    layers' first biases), b0 [n_out] or None for an identity skip (then out defaults to x: in place).  Returns out."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     rows, k_in = x.shape
     if out is None:
         out = x if b0 is None else torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     assert out.dtype == torch.float32 and out.shape == (rows, n_out) and out.stride(1) == 1
     b1 = b1.contiguous()
+    assert b1.numel() == (1 + chain) * n_out
     b0 = None if b0 is None else b0.contiguous()
     _lib.check(_L.cppf_reslayer_split(_p(x), x.stride(0), k_in, _p(out), out.stride(0), n_out, rows, _p(wq),
-                                      wq.numel() * wq.element_size(), _p(b1), _p(b0), _stream()),
+                                      wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
                "cppf_reslayer_split")
     return out
 

@@ -314,19 +314,21 @@ int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t st
  * registers.  float32 in, float32 accumulate: results differ from a library GEMM's only by summation order. */
 int cppf_reslayer128(float* x, int64_t rows, const float* w1, const float* b1, const float* w2, void* stream);
 
-/* ---- any ResLayer of the models (train_shot.py:19-45; bn = dropout = False) as one kernel on the bf16 matrix cores in
- * float32-equivalent arithmetic (every float32 operand is the exact sum of three bf16 values; six exact-product MFMAs per
- * K step, float32 accumulate; error against float64 = a float32 GEMM's, see cppf_mlp_split.hip):
- *     out[rows, n_out] = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T
- * skip(x) = x when b0 == NULL (then k_in == n_out; out may be x itself: in place) or x W0^T + b0 otherwise.
+/* ---- the ResLayers of the models (train_shot.py:19-45; bn = dropout = False), one or several per kernel, on the bf16
+ * matrix cores in float32-equivalent arithmetic (every float32 operand is the exact sum of three bf16 values; six
+ * exact-product MFMAs per K step, float32 accumulate; error against float64 = a float32 GEMM's, see cppf_mlp_split.hip):
+ *     y = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T          skip(x) = x when b0 == NULL (then k_in == n_out; out may be
+ *                                                              x itself: in place), x W0^T + b0 otherwise
+ *     then `chain` times (n_out <= 128 only)  y <- y + relu(y W1_l^T + b1_l) W2_l^T   without leaving the registers
  * x float32 with row stride ldx >= k_in, out float32 with row stride ldo >= n_out (elements; both multiples of 4, base
  * pointers 16-byte aligned); k_in a multiple of 8 (columns of x beyond the layer's true dim_in must hold finite values;
- * their weights are zero in the stream); n_out in {64, 128, 192, 256}.  wq = W1, W0, W2 pre-split into bf16 triples in the
- * per-lane operand order the kernel streams (cppf2_amd.models.pack_split writes it; cppf_reslayer_split_stream_bytes gives
- * its size, -1 for unsupported shapes).  fc2's bias is the caller's, as for cppf_reslayer128. */
-int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj);
+ * their weights are zero in the stream); n_out in {64, 128, 192, 256}; b1 float32[(1 + chain) * n_out].  wq = the weights
+ * pre-split into bf16 triples in the per-lane operand order the kernel streams (cppf2_amd.models.pack_split writes it;
+ * cppf_reslayer_split_stream_bytes gives its size, -1 for unsupported shapes).  Each layer's fc2 bias is the caller's, as
+ * for cppf_reslayer128. */
+int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
-                        const void* wq, int64_t wq_bytes, const float* b1, const float* b0, void* stream);
+                        const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, void* stream);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,21 @@ for k, n, proj in shapes:
         native(x, w1, b1, w0, b0, w2)
     torch.cuda.synchronize()
     t_nat = (time.perf_counter() - t0) / reps * 1e3
+    if (k, n, proj) == (360, 128, True):        # + the four identity layers of the tuple encoder chained in the same kernel
+        rest = [(torch.randn(n, n, device=dev) / n ** 0.5, torch.randn(n, device=dev) * 0.1, torch.randn(n, n, device=dev) / n ** 0.5) for _ in range(4)]
+        wqc = models.pack_split(w1, w0, w2, k, chain=[(e[0], e[2]) for e in rest])
+        bias = torch.cat([b1] + [e[1] for e in rest])
+        x = torch.randn(rows, k, device=dev)
+        for _ in range(2):
+            ops.reslayer_split(x, wqc, bias, b0, n, out=out, chain=4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ops.reslayer_split(x, wqc, bias, b0, n, out=out, chain=4)
+        torch.cuda.synchronize()
+        tc = (time.perf_counter() - t0) / reps * 1e3
+        fl = 2.0 * rows * (k * n * 2 + n * n + 4 * 2 * n * n)
+        print("K=360 N=128 proj + 4 chained identity layers: %.3f ms (%.0f TF/s eq)" % (tc, fl / tc / 1e9), flush=True)
     flops = 2.0 * rows * (k * n * (2 if proj else 1) + n * n)
     print("K=%3d N=%3d proj=%d  max err split %.2e native %.2e | rms split %.2e native %.2e | split %.3f ms (%.0f TF/s eq) native %.3f ms (%.0f TF/s)"
           % (k, n, proj, e_split, e_nat, r_split, r_nat, t_split, flops / t_split / 1e9, t_nat, flops / t_nat / 1e9), flush=True)

@@ -40,7 +40,7 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
         k_in = k + (8 if k == 288 else 0)                                           # x wider than dim_in: zero weights
         q = models.pack_split(w1, w0, w2, k_in)
         assert q.dtype == torch.bfloat16
-        assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(k_in, n, int(proj))
+        assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(k_in, n, int(proj), 0)
         # walk the stream the way the header describes it and rebuild the three matrices
         nt = n // 32
         nh = 2 if nt > 4 else 1
@@ -84,7 +84,23 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
                             col = 32 * t + 16 * sp + 4 * g_ + (j & 3) + 8 * (j >> 2)
                             got2[32 * hf * nth:32 * (hf + 1) * nth, col] = c2[2 * t + sp, :, g_, :, j].reshape(-1)
         assert pos == f.size and np.array_equal(got2, w2.numpy())
-    assert ops._L.cppf_reslayer_split_stream_bytes(128, 96 + 1, 0) == -1 and ops._L.cppf_reslayer_split_stream_bytes(128, 320, 0) == -1
+    assert ops._L.cppf_reslayer_split_stream_bytes(128, 96 + 1, 0, 0) == -1
+    assert ops._L.cppf_reslayer_split_stream_bytes(128, 320, 0, 0) == -1
+    assert ops._L.cppf_reslayer_split_stream_bytes(256, 256, 0, 1) == -1            # chains: widths <= 128 only
+    # chained identity layers: their W1 and W2 follow, both in accumulator feature order
+    w1, b1, w0, b0, w2 = _layer(72, 64, True, "cpu", seed=5)
+    wa, _, _, _, wb = _layer(64, 64, False, "cpu", seed=6)
+    q0 = models.pack_split(w1, w0, w2, 72)
+    q = models.pack_split(w1, w0, w2, 72, chain=[(wa, wb)])
+    assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(72, 64, 1, 1) and torch.equal(q[:q0.numel()], q0)
+    tail = q[q0.numel():].float().numpy().reshape(2, 4, 2, 3, 2, 32, 8).sum(3)      # [matrix, step, tile, g, i, j]
+    for m, want in enumerate((wa.numpy(), wb.numpy())):
+        got = np.zeros((64, 64), np.float32)
+        for st in range(4):
+            for g_ in range(2):
+                for j in range(8):
+                    got[:, 32 * (st >> 1) + 16 * (st & 1) + 4 * g_ + (j & 3) + 8 * (j >> 2)] = tail[m, st, :, g_, :, j].reshape(-1)
+        assert np.array_equal(got, want)
 
 
 @pytest.mark.gpu
@@ -109,6 +125,24 @@ def test_reslayer_split_matches_float64_like_a_float32_gemm():
             assert e_split < 2e-6, (k, n, proj, rows, e_split)
             assert e_split < 3.0 * e_nat + 2e-7, (k, n, proj, rows, e_split, e_nat)
             worst = max(worst, e_split / max(e_nat, 1e-9))
+    # a projection layer with identity layers chained behind it in the same kernel (the tuple / point encoders' shape)
+    for k, n, proj, chain in ((360, 128, True, 4), (352, 128, True, 4), (128, 128, False, 3), (64, 64, False, 1), (128, 64, True, 2)):
+        w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=11)
+        rest = [_layer(n, n, False, dev, seed=20 + l) for l in range(chain)]
+        wq = models.pack_split(w1, w0, w2, k, chain=[(e[0], e[4]) for e in rest])
+        bias = torch.cat([b1] + [e[1] for e in rest])
+        for rows in (5, 700):
+            x = torch.randn(rows, k, device=dev)
+            want = _ref64(x, w1, b1, w0, b0, w2)
+            nat = torch.addmm(x if w0 is None else torch.addmm(b0, x, w0.t()), torch._addmm_activation(b1, x, w1.t()), w2.t())
+            for e in rest:
+                want = _ref64(want, e[0], e[1], None, None, e[4])
+                nat = torch.addmm(nat, torch._addmm_activation(e[1], nat, e[0].t()), e[4].t())
+            got = ops.reslayer_split(x.clone(), wq, bias, b0, n, chain=chain)
+            scale = want.abs().max().item()
+            e_split = (got.double() - want.double()).abs().max().item() / scale
+            e_nat = (nat.double() - want.double()).abs().max().item() / scale
+            assert e_split < 3e-6 and e_split < 3.0 * e_nat + 2e-7, (k, n, chain, rows, e_split, e_nat)
     # in place on a strided view (row stride > k), rows of the parent beyond the view untouched; NaN stays NaN through relu
     k = n = 128
     w1, b1, w0, b0, w2 = _layer(k, n, False, dev)
@@ -143,10 +177,13 @@ def test_reslayer_split_rejects_bad_arguments():
     with pytest.raises(_lib.CppfError):
         ops.reslayer_split(x, wq[:-8], b1, None, 128)                       # stream size mismatch
     with pytest.raises(_lib.CppfError):
-        ops.reslayer_split(x, wq, b1, None, 96, out=torch.empty(8, 96, device=dev))   # unsupported width
+        ops.reslayer_split(x, wq, b1[:96], None, 96, out=torch.empty(8, 96, device=dev))   # unsupported width
     with pytest.raises(_lib.CppfError):
         ops.reslayer_split(torch.randn(8, 132, device=dev), wq, b1, None, 128, out=torch.empty(8, 128, device=dev))   # k_in % 8
-    assert not ops.reslayer_split_supported(132, 128, False) and ops.reslayer_split_supported(360, 128, True)
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split(torch.randn(8, 256, device=dev), wq, torch.zeros(512, device=dev), None, 256, chain=1)     # chain on a wide layer
+    assert not ops.reslayer_split_supported(132, 128, False) and ops.reslayer_split_supported(360, 128, True, 4)
+    assert not ops.reslayer_split_supported(256, 256, False, 1)
 
 
 @pytest.mark.gpu
