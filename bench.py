@@ -81,6 +81,11 @@ def parse():
                          "that survive the back-vote filter, the only rows eval.py:272 ever reads)")
     ap.add_argument("--no-reference-order", action="store_true",
                     help="skip the second timed loop that measures the other scale-head placement (value_reference_order)")
+    ap.add_argument("--mlp-arith", choices=("split", "native"), default=None,
+                    help="arithmetic of the tuple MLP: split = float32 as 3 x bf16 on the bf16 matrix cores (default, "
+                         "cppf_reslayer_split), native = f32-input matrix cores (library GEMMs + cppf_reslayer128)")
+    ap.add_argument("--no-native-arith", action="store_true",
+                    help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -270,6 +275,9 @@ def main():
             torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
+    from cppf2_amd import models as _models
+    if args.mlp_arith:
+        _models.MLP_ARITH = args.mlp_arith
     step = Step(args, rank, world, dev)
     step.run()                      # part of the untimed setup: allocator pools of both streams, GEMM solution table,
     torch.cuda.synchronize()        # kernel attributes -- so that even --warmup 0 times steady-state steps
@@ -307,6 +315,14 @@ def main():
         step.run()
         dt_other, _ = timed_loop(args.steps)
         step.eager = not step.eager
+
+    # the same step with the tuple MLP on the f32-input matrix cores (the arithmetic of rounds 1-2), same loop protocol
+    dt_native = None
+    if _models.MLP_ARITH == "split" and not args.no_native_arith:
+        _models.MLP_ARITH = "native"
+        step.run()
+        dt_native, _ = timed_loop(args.steps)
+        _models.MLP_ARITH = "split"
 
     # per-stage HIP-event times (ms per launch, averaged over the timed steps) on the stream the kernels ran on
     stage_ms = {}
@@ -392,12 +408,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SHOT model, %d scenes/GPU x %d pts x %d tuples x %d rots, "
-                                   "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s"
-                                   % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only"),
+                                   "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s; "
+                                   "MLP arithmetic: %s"
+                                   % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only",
+                                      "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
+                                      "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
+                                      if _models.MLP_ARITH == "split" else "f32-input matrix cores"),
                        "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
             # the same run with the scale head on every tuple (the reference's forward order), same loop protocol
             "value_reference_order" if not args.eager_scale_head else "value_kept_pairs_order":
                 (total_scenes / dt_other) if dt_other else None,
+            # the same run with the MLP on the f32-input matrix instruction (no operand splitting)
+            "value_f32_input_mfma": (total_scenes / dt_native) if dt_native else None,
             "records_gathered": int(all_rec.shape[0]),
             "roofline": roofline, "cpu_baseline": cpu,
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,

@@ -165,12 +165,14 @@ def fused_stack(seq, x, keep_input=False):
             li += 1 + chain
             continue
         li += 1
-        if (w0t is None and w1t.shape == (128, 128) and x.dtype == torch.float32 and x.is_contiguous()
+        if (w0t is None and w1t.shape == (128, 128) and x.shape[1] == 128 and x.dtype == torch.float32 and x.is_contiguous()
                 and not (li == 1 and keep_input)):
             # 128-wide identity-skip layer: both GEMMs, the bias, the ReLU and the residual add in one matrix-core kernel
             # that reads and writes the activation once (cppf_reslayer128); w1t / w2t are transposed views of the weights
             x = ops.reslayer128_(x, w1t.t(), b1, w2t.t())
             continue
+        if x.shape[1] > w1t.shape[0]:               # zero-padded input columns (see BeyondCPPFDino.prepare_tuple_inputs)
+            x = x[:, :w1t.shape[0]]
         h = torch._addmm_activation(b1, x, w1t)
         if w0t is not None:
             x = torch.addmm(b0, x, w0t)
@@ -286,7 +288,12 @@ class BeyondCPPFDino(nn.Module):
             # instead of a [T, k*256] gather and a K = k*256 GEMM over T rows (T/N = 5x the FLOPs, 6.5 GB at bench size)
             w = self.desc_pair_transform.weight                                        # [256, k*256]
             tables = torch.stack([per_point @ w[:, i * d:(i + 1) * d].t() for i in range(k)], 1).contiguous()
-            out = torch.empty((T, self.ncoord + d), dtype=torch.float32, device=per_point.device)
+            # rows padded with zero columns to a multiple of 8 floats (286 -> 288): 16-byte aligned rows for the MLP kernels,
+            # which give the extra columns zero weights (fused_stack)
+            width = (self.ncoord + d + 7) // 8 * 8
+            out = torch.empty((T, width), dtype=torch.float32, device=per_point.device)
+            if width > self.ncoord + d:
+                out[:, self.ncoord + d:] = 0
             ops.encode_tuples_coord(points, idx, out=out)
             ops.encode_tuples_dino(tables, self.desc_pair_transform.bias, idx, out, self.ncoord)
             return out

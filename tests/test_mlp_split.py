@@ -207,7 +207,7 @@ def test_models_split_arithmetic_matches_native_and_module_forward():
             models.MLP_ARITH = mode
             with torch.no_grad():
                 outs[mode] = (shot.heads(x.clone()), shot.heads(x.clone(), lazy_scale=True), shot.encode_points(sf.clone()),
-                              dino.heads(xd.clone()))
+                              dino.heads(xd.clone()), dino.heads(torch.nn.functional.pad(xd, (0, 2))))   # 286 -> 288 zero columns
         with torch.no_grad():
             feat = shot.tuple_encoder(x)
             ref = (shot.logit_encoder(feat).reshape(-1, 6, 32), shot.scale_encoder(feat), shot.shot_encoder(sf))
@@ -216,8 +216,9 @@ def test_models_split_arithmetic_matches_native_and_module_forward():
     finally:
         models.MLP_ARITH = prev
     for mode in ("split", "native"):
-        (cls, sc), (cls_l, feat_l), pts, (dcls, dsc) = outs[mode]
-        for got, want in ((cls, ref[0]), (sc, ref[1]), (cls_l, ref[0]), (pts, ref[2]), (dcls, refd[0]), (dsc, refd[1])):
+        (cls, sc), (cls_l, feat_l), pts, (dcls, dsc), (pcls, psc) = outs[mode]
+        for got, want in ((cls, ref[0]), (sc, ref[1]), (cls_l, ref[0]), (pts, ref[2]), (dcls, refd[0]), (dsc, refd[1]),
+                          (pcls, refd[0]), (psc, refd[1])):
             assert got.shape == want.shape
             assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), mode
         assert (shot.scale_head(feat_l) - ref[1]).abs().max().item() < 2e-5
