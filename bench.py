@@ -56,6 +56,8 @@ import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
+F32_MFMA_PEAK_TFLOPS = 157.0    # f32-input MFMA: 256 CUs x 4 SIMDs x 64 flops/cycle x 2.4 GHz
 
 
 class Cfg:
@@ -93,8 +95,8 @@ def parse():
 class Step:
     """Holds the resident inputs and runs one pass of the path."""
 
-    STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder_torch", "encode_tuples", "tuple_mlp_torch",
-              "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "scale_head_torch", "assemble_pose", "gather"]
+    STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder", "encode_tuples", "tuple_mlp",
+              "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "scale_head", "assemble_pose", "gather"]
 
     def __init__(self, args, rank, world, dev):
         from cppf2_amd import dist as cdist
@@ -152,12 +154,12 @@ class Step:
         self._mark("shot352")
         normal = torch.nan_to_num_(self.normal, nan=0.0)
         feat = self.model.encode_points(shot)
-        self._mark("shot_encoder_torch")
+        self._mark("shot_encoder")
         x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
         self._mark("encode_tuples")
         eager = self.eager
         logits, feat = self.model.heads(x, lazy_scale=not eager)
-        self._mark("tuple_mlp_torch")
+        self._mark("tuple_mlp")
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
         self._mark("decode_bins")
@@ -181,7 +183,7 @@ class Step:
         self._mark("rot_bins")
         if not eager:
             torch.cuda.current_stream().wait_stream(self.side)
-        self._mark("scale_head_torch")
+        self._mark("scale_head")
         pipe.assemble(scales)
         self._mark("assemble_pose")
         # the one collective of the path: 160-byte records of every rank's scenes, global scene order
@@ -227,6 +229,21 @@ def pmc_traffic(stage):
         if not d:
             return None
         return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
+def pmc_traffic_mlp():
+    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 5, point encoder 2, scale head 2) from the same
+    committed passes; None if absent."""
+    try:
+        cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
+        with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
+            d = json.load(f)
+        passes = d["vote_worklist_kernel"]["launches"]
+        tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
+                  for k_, v in d.items() if k_.startswith("reslayer_split_kernel"))
+        return tot / passes if tot > 0 else None
     except Exception:
         return None
 
@@ -336,7 +353,8 @@ def main():
         all_rec = step.pipe.results_to_numpy(step.all_records)
         assert all_rec.shape[0] == B * world and np.array_equal(all_rec[:B].tobytes(), res.tobytes())
         G = int(np.mean(res["ncell"]))
-        hip_stages = [s for s in Step.STAGES if "torch" not in s and s != "gather"]
+        mlp_stages = ("shot_encoder", "tuple_mlp", "scale_head")
+        hip_stages = [s for s in Step.STAGES if s not in mlp_stages and s != "gather"]
         # the rotation-vote stage shares the chip with the PyTorch scale head running on a side stream, so its event time
         # is not the kernel's own (0.26 ms alone, profiles/): the dominant kernel is picked among the stages that run alone
         shared = set() if args.eager_scale_head else {"rot_bins"}
@@ -372,10 +390,33 @@ def main():
                         hip_only_ms=hip_only_ms,
                         hip_only_frac=(path_bytes / 1e9) / (hip_only_ms / 1e3) / HBM_PEAK_GBS if hip_only_ms > 0 else None,
                         hip_only_scenes_per_s=B * world / (hip_only_ms / 1e3) if hip_only_ms > 0 else None,
-                        torch_mlp_ms=sum(stage_ms.get(s, 0.0) for s in Step.STAGES if "torch" in s),
+                        mlp_ms=sum(stage_ms.get(s, 0.0) for s in mlp_stages),
                         stages_sharing_the_chip_with_torch=sorted(shared),
                         per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
+        if _models.MLP_ARITH == "split":
+            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 5 launches back to back: the stage
+            # time is their sum): matrix-core bound.  `achieved` = the bf16 MFMA work it executes (6 exact-product MFMAs per
+            # float32 product, K padded to 16) over the stage's HIP-event time, against the dense bf16 peak; the
+            # float32-equivalent rate (2 M K N of the layers) is next to it.  The HBM-bound kernel's roofline stays under "hbm".
+            def layer_flops(k, n, proj):
+                return 2.0 * n * ((k + 15) // 16 * 16) * (2 if proj else 1) + 2.0 * n * n, 2.0 * n * k * (2 if proj else 1) + 2.0 * n * n
+            layers = [(360, 128, True)] + [(128, 128, False)] * 4 + [(128, 256, True), (256, 256, False), (256, 256, False), (256, 192, True)]
+            executed = 6.0 * sum(layer_flops(*l)[0] for l in layers) * B * T
+            algorithmic = sum(layer_flops(*l)[1] for l in layers) * B * T
+            mlp_ms_ = stage_ms["tuple_mlp"]
+            hbm = {k_: roofline[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
+                                               "kernel_name", "algorithmic_bytes_per_launch", "algorithmic_model")}
+            roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
+                            achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
+                            launch_ms=mlp_ms_, launches=5,
+                            executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
+                            algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
+                            algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = 6 bf16 "
+                                              "MFMA products per float32 product (3-way exact operand split)" % (B * T),
+                            hbm=hbm)
+            roofline.pop("algorithmic_bytes_per_launch", None)
         # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
         ok = 0
         for b in range(B):

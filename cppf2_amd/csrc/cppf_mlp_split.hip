@@ -33,6 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef RS_NH8
+#define RS_NH8 2
+#endif
 #ifndef RS_PREFETCH_MAX_NT
 #define RS_PREFETCH_MAX_NT 8
 #endif
@@ -220,7 +223,9 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], float (&xv)[
 #pragma unroll
     for (int i = 0; i < SPC; ++i) {                    // SPC is even: step s0 + i splits xv[(i + 1) & 1], refills xv[i & 1]
       if (s0 + i < ks1) {
+#ifndef RS_NOFETCH
         rs_fetch(xv[i & 1], xrow, k_in, s0 + i + 2, g);
+#endif
         RsFrag bn;
         rs_step<NTILES, PREFETCH>(acc, w + i * NTILES * 3 * 64, b, [&](int p) {
           rs_split_pair<true>(xv[(i + 1) & 1][2 * p], xv[(i + 1) & 1][2 * p + 1], bn.h[p], bn.m[p], bn.l[p]);
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
                                                                        int64_t ldo, int64_t rows, const char* __restrict__ wq,
                                                                        const float* __restrict__ b1,
                                                                        const float* __restrict__ b0, int chain) {
-  constexpr int NH = NT > 4 ? 2 : 1;            // output halves
+  constexpr int NH = NT > 4 ? (NT == 8 ? RS_NH8 : 2) : 1;            // output halves
   constexpr int NTH = NT / NH;
   constexpr bool FUSE0 = PROJ && NH == 1;       // narrow projection layer: x W0^T rides along with x W1^T (one pass over x)
   constexpr bool XH = PROJ && !FUSE0;           // wide projection layer: x W0^T per output half

@@ -68,7 +68,7 @@ def pack_split(w1, w0, w2, k_in, chain=()):
       output tiles in registers)."""
     n = w1.shape[0]
     nt = n // 32
-    nh = 2 if nt > 4 else 1
+    nh = (int(os.environ.get("CPPF_RS_NH8", "2")) if nt == 8 else 2) if nt > 4 else 1
     nth = nt // nh
     ks1 = (k_in + 15) // 16
     dev = w1.device
