@@ -234,7 +234,7 @@ def pmc_traffic(stage):
 
 
 def pmc_traffic_mlp():
-    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 5, point encoder 2, scale head 2) from the same
+    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 3, point encoder 2, scale head 2) from the same
     committed passes; None if absent."""
     try:
         cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
@@ -395,7 +395,7 @@ def main():
                         per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         if _models.MLP_ARITH == "split":
-            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 5 launches back to back: the stage
+            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 3 launches back to back: the stage
             # time is their sum): matrix-core bound.  `achieved` = the bf16 MFMA work it executes (6 exact-product MFMAs per
             # float32 product, K padded to 16) over the stage's HIP-event time, against the dense bf16 peak; the
             # float32-equivalent rate (2 M K N of the layers) is next to it.  The HBM-bound kernel's roofline stays under "hbm".
@@ -410,7 +410,7 @@ def main():
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
-                            launch_ms=mlp_ms_, launches=5,
+                            launch_ms=mlp_ms_, launches=3,
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = 6 bf16 "

@@ -33,15 +33,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef RS_NH8
-#define RS_NH8 2
-#endif
 #ifndef RS_PREFETCH_MAX_NT
 #define RS_PREFETCH_MAX_NT 8
 #endif
-#define RS_THREADS 512
-#define RS_WAVES 8
-#define RS_BLOCK_ROWS 256
+// wavefronts per workgroup: 8 (two per SIMD, 256 registers each) for layers up to 192 wide, 4 (one per SIMD, 512 registers:
+// both accumulator sets of a 256-wide layer at once) for 256
+__host__ __device__ constexpr int rs_waves(int nt) { return nt >= 8 ? 4 : 8; }
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
 #define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
@@ -51,7 +48,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // K steps per staged chunk (one barrier per chunk): as many as fit a stage
-__host__ __device__ constexpr int rs_spc(int tiles) { return tiles >= 5 ? 2 : 4; }
+__host__ __device__ constexpr int rs_spc(int tiles) { return tiles >= 9 ? 1 : tiles >= 5 ? 2 : 4; }
 
 struct RsFrag {                                  // one operand fragment per slice, as raw dwords (2 bf16 each)
   unsigned h[4], m[4], l[4];
@@ -97,29 +94,43 @@ __device__ __forceinline__ void rs_mma6(f32x16& acc, const RsFrag& a, const RsFr
   acc = rs_mfma(a.h, b.h, acc);
 }
 
+// s_waitcnt immediate (gfx9 encoding): vmcnt (6 bits, split 4 + 2), lgkmcnt (4 bits); expcnt not waited on
+__host__ __device__ constexpr int rs_waitcnt(int vm, int lgkm) {
+  return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8);
+}
+#define RS_WAIT(vm, lgkm) __builtin_amdgcn_s_waitcnt(rs_waitcnt(vm, lgkm))
+
 // The weight stream of one layer, consumed in order by every wavefront of the workgroup (cppf2_amd.models.pack_split):
 // segment 0 = ks1 K steps of T0 tiles (W1; for a narrow projection layer W1 and W0 side by side), then per output half
-// [XH: W0 of the half, ks1 steps of NTH tiles] + W2 of the half (2 NT steps of NTH tiles).  It moves through a two-stage
-// LDS ring in chunks of up to rs_spc(tiles) K steps of one segment.
-template <int NT, int T0, int NTH, bool XH>
+// [XH: W0 of the half, ks1 steps of NTH tiles] + W2 of the half (2 NT steps of NTH tiles), then W1, W2 of each chained
+// layer.  It moves through a two-stage LDS ring by LDS-DMA in chunks of up to rs_spc(tiles) K steps of one segment: the
+// pieces of chunk c + 1 (1 KiB per wavefront instruction) are issued between the MFMAs of the first K step of chunk c.
+// All memory waits of the kernel's main loops are COUNTED (the vector-memory queue completes in order): see acquire().
+template <int NT, int T0, int NTH, bool XH, int WAVES>
 struct RsStream {
+  static constexpr int PMAX = 48 / WAVES;      // pieces of a chunk per wavefront, at most
   int nseg;                    // 1 + per half (W0?, W2) + per chained identity layer (W1, W2)
   int chunks;                  // chunks per row block
   const char* base;            // packed stream in global memory
   char* ring;                  // LDS, two stages
   int ks1;
-  int seg, pos;                // segment / K step within it the next DMA starts at
+  int seg, pos;                // segment / K step within it the next chunk starts at
   int64_t off;                 // its byte offset
   int64_t left;                // chunks still to fetch over the remaining row blocks of this workgroup
   int stage;                   // stage the next acquire() returns
   int wave, lane;
+  const char* p_src;           // this wavefront's first piece of the chunk being fetched, and how many pieces it has
+  char* p_dst;
+  int p_n;
 
   __device__ __forceinline__ void shape(int chain) {
     const int cx = (ks1 + rs_spc(T0) - 1) / rs_spc(T0), cxh = (ks1 + rs_spc(NTH) - 1) / rs_spc(NTH);
     nseg = 1 + (NT / NTH) * (XH ? 2 : 1) + 2 * chain;
     chunks = cx + (NT / NTH) * ((XH ? cxh : 0) + 2 * NT / rs_spc(NTH)) + chain * 2 * (2 * NT / rs_spc(NTH));
   }
-  __device__ __forceinline__ void issue(int st) {
+  // selects the next chunk of the stream (destination: stage st); its pieces are then issued one by one with piece()
+  __device__ __forceinline__ void plan(int st) {
+    p_n = 0;
     if (left <= 0) return;
     const bool first = seg == 0;
     const int tiles = first ? T0 : NTH;
@@ -127,12 +138,10 @@ struct RsStream {
     const int steps = (first || (XH && (seg & 1))) ? ks1 : 2 * NT;
     const int ns = steps - pos < spc ? steps - pos : spc;
     const int pieces = ns * tiles * 3;
-    const char* src = base + off + lane * 16;
-    char* dst = ring + st * RS_STAGE_BYTES;
-    for (int j = wave; j < pieces; j += RS_WAVES) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * RS_FRAG_BYTES),
-                                       (__attribute__((address_space(3))) void*)(dst + j * RS_FRAG_BYTES), 16, 0, 0);
-    }
+    p_src = base + off + wave * RS_FRAG_BYTES + lane * 16;
+    p_dst = ring + st * RS_STAGE_BYTES + wave * RS_FRAG_BYTES;
+    p_n = (pieces - wave + WAVES - 1) / WAVES;
+    if (p_n < 0) p_n = 0;
     off += (int64_t)pieces * RS_FRAG_BYTES;
     pos += ns;
     if (pos == steps) {
@@ -144,14 +153,31 @@ struct RsStream {
     }
     --left;
   }
-  // the stage holding the next chunk in stream order; its DMA was issued one chunk earlier.  Every wavefront waits for
-  // its own pieces (vmcnt) before the barrier, so after it the whole chunk is in LDS and the other stage is free.
+  // the q-th piece of this wavefront (pieces wave, wave + WAVES, ...): at most PMAX per chunk
+  __device__ __forceinline__ void piece(int q) {
+    if (q < p_n) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + q * (WAVES * RS_FRAG_BYTES)),
+                                       (__attribute__((address_space(3))) void*)(p_dst + q * (WAVES * RS_FRAG_BYTES)), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void prime() {                // the very first chunk: all pieces at once
+    plan(0);
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) piece(q);
+  }
+  // The stage holding the next chunk in stream order.  Its pieces were issued during the first K step of the previous
+  // chunk; `younger` = the vector-memory operations this wavefront has issued since (the x tiles of the K steps after
+  // that one): the queue completes in order, so vmcnt(younger) means "my pieces have landed".  After the barrier every
+  // wavefront's pieces have, and every wavefront is done reading the other stage, which plan() then hands to the next
+  // chunk.  (A raw barrier: __syncthreads() would drain the whole queue, the x tiles in flight included.)
+  template <int YOUNGER>
   __device__ __forceinline__ const u32x4* acquire() {
-    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) lgkmcnt(0) expcnt(0)
-    __syncthreads();
+    RS_WAIT(YOUNGER, 0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     const int cur = stage;
     stage ^= 1;
-    issue(stage);
+    plan(stage);
     return reinterpret_cast<const u32x4*>(ring + cur * RS_STAGE_BYTES) + lane;
   }
 };
@@ -169,67 +195,87 @@ __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
 }
 
 // one K step: acc[u] += W[tile u] b for the NTILES tiles at w.  The fragments of tile u + 1 are requested from LDS before
-// the six MFMAs of tile u issue (their 192 cycles cover the read); `filler(u)` is independent vector work (the split of
-// the NEXT step's B operand, a quarter per call) placed in front of tile u's MFMAs so that it issues in their shadow;
-// the scheduling barrier per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
-template <int NTILES, bool PREFETCH, class F>
-__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler) {
-  if (PREFETCH) {
-    RsFrag a = rs_read(w, 0);
+// the six MFMAs of tile u issue (their 192 cycles cover the read); `filler(p)`, p < 4, is independent vector work (the split
+// of the NEXT step's B operand, a quarter per call) and `dma(q)`, q < PMAX, the LDS-DMA issue of one piece of the next
+// weight chunk: both are placed in front of a tile's MFMAs so that they issue in their shadow; the scheduling barrier
+// per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
+template <int NTILES, bool PREFETCH, int PMAX, class F, class D>
+__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler, D&& dma) {
+  RsFrag a = rs_read(w, 0);
 #pragma unroll
-    for (int u = 0; u < NTILES; ++u) {
-      RsFrag an = a;
-      if (u + 1 < NTILES) an = rs_read(w, u + 1);
+  for (int u = 0; u < NTILES; ++u) {
+    RsFrag an = a;
+    if (PREFETCH && u + 1 < NTILES) an = rs_read(w, u + 1);
+    if (!PREFETCH && u > 0) a = rs_read(w, u);
 #pragma unroll
-      for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
-      rs_mma6(acc[u], a, b);
-      __builtin_amdgcn_sched_barrier(0);
-      a = an;
-    }
-  } else {
-    // no read-ahead (12 registers less): the partner wavefront on the SIMD covers the LDS latency
+    for (int q = (u * PMAX + NTILES - 1) / NTILES; q < ((u + 1) * PMAX + NTILES - 1) / NTILES; ++q) dma(q);
 #pragma unroll
-    for (int u = 0; u < NTILES; ++u) {
-      const RsFrag a = rs_read(w, u);
-#pragma unroll
-      for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
-      rs_mma6(acc[u], a, b);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
+    rs_mma6(acc[u], a, b);
+    __builtin_amdgcn_sched_barrier(0);
+    if (PREFETCH) a = an;
   }
 }
 
-// this lane's 8 values of K step s of its row: features 16 s + 8 g + (0..7), zeros past k_in
-__device__ __forceinline__ void rs_fetch(float (&dst)[8], const float* __restrict__ xrow, int k_in, int s, int g) {
-  const int f = 16 * s + 8 * g;
-  f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (f + 8 <= k_in) {
-    v0 = *reinterpret_cast<const f32x4*>(xrow + f);
-    v1 = *reinterpret_cast<const f32x4*>(xrow + f + 4);
-  }
-  dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
-}
+// The x tile of one K step of a wavefront's 32 rows -- lane (r, g): features 16 s + 8 g + (0..7) of row r, 32 bytes --
+// travels global -> LDS by two LDS-DMA instructions (16 bytes per lane each) into one of three 2 KiB slots of the
+// wavefront, three K steps ahead of its use; nothing of it is tracked by the compiler, the waits are counted by hand.
+struct RsX {
+  const float* xrow;           // this lane's row
+  char* slots;                 // the wavefront's three slots in LDS
+  int k_in, g, lane;
 
-// acc[u] (u < NTILES) += W[tile u] x^T over all K steps.  xv holds the row's values of steps 0 and 1 on entry (the caller
-// fetched them, possibly a whole row block earlier); the values of step s + 1 are split while step s multiplies, those
-// of step s + 2 are in flight.
+  __device__ __forceinline__ void issue(int s, int slot) const {        // always exactly two vector-memory operations
+    int f = 16 * s + 8 * g;
+    if (f + 8 > k_in) f = 0;                     // past the end (or the zero tail): any valid address, the value is masked
+    const float* src = xrow + f;
+    char* dst = slots + slot * 2048;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4),
+                                     (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void read(float (&v)[8], int s, int slot) const {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(slots + slot * 2048 + lane * 16);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(slots + slot * 2048 + 1024 + lane * 16);
+    const bool ok = 16 * s + 8 * g + 8 <= k_in;
+    v[0] = ok ? v0.x : 0.0f; v[1] = ok ? v0.y : 0.0f; v[2] = ok ? v0.z : 0.0f; v[3] = ok ? v0.w : 0.0f;
+    v[4] = ok ? v1.x : 0.0f; v[5] = ok ? v1.y : 0.0f; v[6] = ok ? v1.z : 0.0f; v[7] = ok ? v1.w : 0.0f;
+  }
+};
+
+// acc[u] (u < NTILES) += W[tile u] x^T over all K steps.  On entry the x tiles of steps 0, 1, 2 have been issued into
+// slots 0, 1, 2 (by the caller, possibly a whole row block earlier) and nothing younger than them is in flight except
+// weight pieces.  Step s: wait for tile s + 1 (two tiles younger: vmcnt(4) before, vmcnt(2) after the issue of tile
+// s + 3 -- the wait comes first), read it, issue tile s + 3 into the slot tile s left, split tile s + 1 in the shadow of
+// step s's MFMAs.
 template <int NTILES, bool PREFETCH, class Stream>
-__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], float (&xv)[2][8], const float* __restrict__ xrow, int k_in,
-                                             int ks1, int g, Stream& ws) {
+__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const RsX& xs, int ks1, Stream& ws) {
   constexpr int SPC = rs_spc(NTILES);
-  RsFrag b = rs_split(xv[0]);
+  float xv[8];
+  RS_WAIT(4, 15);                                    // tile 0 has landed (tiles 1, 2 may be in flight)
+  __builtin_amdgcn_sched_barrier(0);
+  xs.read(xv, 0, 0);
+  RsFrag b = rs_split(xv);
+  int slot = 1;                                      // slot of tile s + 1
+  bool whole = true;                                 // the previous chunk had SPC steps (counted wait) or this is the first
   for (int s0 = 0; s0 < ks1; s0 += SPC) {
-    const u32x4* w = ws.acquire();
+    // weight pieces of this chunk: issued in the first step of the previous chunk, 2 (SPC - 1) x-tile operations ago --
+    // unless that chunk was not this loop's (first iteration: other phases issue no x tiles after their pieces)
+    const u32x4* w = (s0 > 0 && whole) ? ws.template acquire<2 * (SPC - 1)>() : ws.template acquire<0>();
+    whole = s0 + SPC <= ks1;
 #pragma unroll
-    for (int i = 0; i < SPC; ++i) {                    // SPC is even: step s0 + i splits xv[(i + 1) & 1], refills xv[i & 1]
+    for (int i = 0; i < SPC; ++i) {
       if (s0 + i < ks1) {
-#ifndef RS_NOFETCH
-        rs_fetch(xv[i & 1], xrow, k_in, s0 + i + 2, g);
-#endif
+        RS_WAIT(2, 15);                              // x tile s + 1 has landed (tile s + 2 may be in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        xs.read(xv, s0 + i + 1, slot);
+        xs.issue(s0 + i + 3, slot == 0 ? 2 : slot - 1);
+        slot = slot == 2 ? 0 : slot + 1;
         RsFrag bn;
-        rs_step<NTILES, PREFETCH>(acc, w + i * NTILES * 3 * 64, b, [&](int p) {
-          rs_split_pair<true>(xv[(i + 1) & 1][2 * p], xv[(i + 1) & 1][2 * p + 1], bn.h[p], bn.m[p], bn.l[p]);
-        });
+        rs_step<NTILES, PREFETCH, Stream::PMAX>(acc, w + i * NTILES * 3 * 64, b,
+                                  [&](int p) { rs_split_pair<true>(xv[2 * p], xv[2 * p + 1], bn.h[p], bn.m[p], bn.l[p]); },
+                                  [&](int q) { if (i == 0) ws.piece(q); });
         b = bn;
       }
     }
@@ -249,16 +295,18 @@ __device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16
   for (int p = 0; p < 4; ++p) rs_split_pair(src[0][2 * p], src[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
 #pragma unroll
   for (int c = 0; c < 2 * NS / SPC; ++c) {
-    const u32x4* w = ws.acquire();
+    const u32x4* w = ws.template acquire<0>();        // no x tiles in flight here (or old ones: harmless)
 #pragma unroll
     for (int i = 0; i < SPC; ++i) {
       const int step = c * SPC + i, nx = (step + 1 < 2 * NS) ? step + 1 : step;
       RsFrag bn = b;
-      rs_step<NTILES, PREFETCH>(dst, w + i * NTILES * 3 * 64, b, [&](int p) {
-        if (step + 1 < 2 * NS)
-          rs_split_pair<true>(src[nx >> 1][8 * (nx & 1) + 2 * p], src[nx >> 1][8 * (nx & 1) + 2 * p + 1], bn.h[p], bn.m[p],
-                              bn.l[p]);
-      });
+      rs_step<NTILES, PREFETCH, Stream::PMAX>(dst, w + i * NTILES * 3 * 64, b,
+                                [&](int p) {
+                                  if (step + 1 < 2 * NS)
+                                    rs_split_pair<true>(src[nx >> 1][8 * (nx & 1) + 2 * p], src[nx >> 1][8 * (nx & 1) + 2 * p + 1],
+                                                        bn.h[p], bn.m[p], bn.l[p]);
+                                },
+                                [&](int q) { if (i == 0) ws.piece(q); });
       b = bn;
     }
   }
@@ -274,11 +322,12 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
 }
 
 template <int NT, bool PROJ>
-__global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
+__global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                        int64_t ldo, int64_t rows, const char* __restrict__ wq,
                                                                        const float* __restrict__ b1,
                                                                        const float* __restrict__ b0, int chain) {
-  constexpr int NH = NT > 4 ? (NT == 8 ? RS_NH8 : 2) : 1;            // output halves
+  constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
+  constexpr int NH = (NT > 4 && WAVES == 8) ? 2 : 1;            // output halves
   constexpr int NTH = NT / NH;
   constexpr bool FUSE0 = PROJ && NH == 1;       // narrow projection layer: x W0^T rides along with x W1^T (one pass over x)
   constexpr bool XH = PROJ && !FUSE0;           // wide projection layer: x W0^T per output half
@@ -288,13 +337,14 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
   constexpr bool AHEAD = NH == 1;               // the next row block's first x values are fetched during the second product
   static_assert((2 * NT) % SPC2 == 0, "second product: whole chunks");
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: keeps its derived addresses scalar
   const int r = lane & 31, g = lane >> 5;
   const int ks1 = (k_in + 15) >> 4;
-  const int64_t nblocks = (rows + RS_BLOCK_ROWS - 1) / RS_BLOCK_ROWS;
+  const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
 
-  RsStream<NT, T0, NTH, XH> ws;
+  RsStream<NT, T0, NTH, XH, WAVES> ws;
   ws.base = wq;
   ws.ring = s_ring;
   ws.ks1 = ks1;
@@ -306,28 +356,35 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
   ws.stage = 0;
   ws.wave = wave;
   ws.lane = lane;
-  ws.issue(0);
+  ws.prime();
   // the biases live in LDS: as kernel-lifetime registers (where the compiler would hoist them) they cost 16 per tile
-  float* s_b1 = reinterpret_cast<float*>(s_ring + 2 * RS_STAGE_BYTES);
+  float* s_b1 = reinterpret_cast<float*>(s_ring + 2 * RS_STAGE_BYTES + WAVES * 3 * 2048);
   float* s_b0 = s_b1 + 32 * NT;                 // directly behind b1: the fused first product initialises both in one sweep
-  for (int i = threadIdx.x; i < 32 * NT; i += RS_THREADS) {
+  for (int i = threadIdx.x; i < 32 * NT; i += THREADS) {
     s_b1[i] = b1[i];
     if (PROJ) s_b0[i] = b0[i];
   }
-  for (int i = threadIdx.x; i < 32 * NT * chain; i += RS_THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
+  for (int i = threadIdx.x; i < 32 * NT * chain; i += THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
   __syncthreads();
 
   auto row_ptr = [&](int64_t blk) {
-    const int64_t row = blk * RS_BLOCK_ROWS + wave * 32 + r;
+    const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     return x + (row < rows ? row : rows - 1) * ldx;
   };
-  float xv[2][8];
-  if (AHEAD && blockIdx.x < nblocks) {
-    rs_fetch(xv[0], row_ptr(blockIdx.x), k_in, 0, g);
-    rs_fetch(xv[1], row_ptr(blockIdx.x), k_in, 1, g);
-  }
+  RsX xs;
+  xs.slots = s_ring + 2 * RS_STAGE_BYTES + wave * (3 * 2048);
+  xs.k_in = k_in;
+  xs.g = g;
+  xs.lane = lane;
+  auto first_tiles = [&](const float* rowp) {     // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
+    xs.xrow = rowp;
+    xs.issue(0, 0);
+    xs.issue(1, 1);
+    xs.issue(2, 2);
+  };
+  if (AHEAD && blockIdx.x < nblocks) first_tiles(row_ptr(blockIdx.x));
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int64_t row = blk * RS_BLOCK_ROWS + wave * 32 + r;
+    const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
     const float* xrow = row_ptr(blk);
     // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a narrow projection layer] ---------------------
@@ -340,13 +397,11 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
 #pragma unroll
       for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
-    if (!AHEAD) {
-      rs_fetch(xv[0], xrow, k_in, 0, g);
-      rs_fetch(xv[1], xrow, k_in, 1, g);
-    }
+    if (!AHEAD) first_tiles(xrow);
+    xs.xrow = xrow;
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
-      rs_product_x<T0, PF>(first, xv, xrow, k_in, ks1, g, ws);
+      rs_product_x<T0, PF>(first, xs, ks1, ws);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -359,17 +414,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
       if (XH) {
 #pragma unroll
         for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], s_b0 + 32 * (hf * NTH + u), g);
-        rs_fetch(xv[0], xrow, k_in, 0, g);
-        rs_fetch(xv[1], xrow, k_in, 1, g);
-        rs_product_x<NTH, PF>(o, xv, xrow, k_in, ks1, g, ws);
+        first_tiles(xrow);
+        rs_product_x<NTH, PF>(o, xs, ks1, ws);
       } else if (!PROJ && !AHEAD) {
 #pragma unroll
         for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * (hf * NTH + u), g);
       }
-      if (AHEAD && blk + gridDim.x < nblocks) {
-        rs_fetch(xv[0], row_ptr(blk + gridDim.x), k_in, 0, g);
-        rs_fetch(xv[1], row_ptr(blk + gridDim.x), k_in, 1, g);
-      }
+      if (AHEAD && blk + gridDim.x < nblocks) first_tiles(row_ptr(blk + gridDim.x));
       rs_product_h<NT, NTH, PF>(o, h, ws);
       if (NH == 1) {
         // ---- the identity layers chained behind (same width): x <- x + relu(x W1^T + b1) W2^T with x = the output tiles,
@@ -407,7 +458,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void reslayer_split_kernel(const flo
 
 extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
   if (k_in <= 0 || n_out <= 0 || (n_out & 31) || n_out > 256 || chain < 0 || chain > 15) return -1;
-  const int nt = n_out / 32, nh = nt > 4 ? 2 : 1, nth = nt / nh;
+  const int nt = n_out / 32, nh = (nt > 4 && rs_waves(nt) == 8) ? 2 : 1, nth = nt / nh;
   if (nt != nth * nh || (chain > 0 && nh != 1)) return -1;
   const int64_t ks1 = (k_in + 15) / 16;
   return ks1 * nt * RS_TILE_BYTES + (int64_t)nh * ((proj ? ks1 : 0) + 2 * nt) * nth * RS_TILE_BYTES +
@@ -417,10 +468,11 @@ extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out,
 template <int NT, bool PROJ>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream) {
-  const int lds_bytes = 2 * RS_STAGE_BYTES + (2 + chain) * 32 * NT * 4;
-  const int64_t nblocks = (rows + RS_BLOCK_ROWS - 1) / RS_BLOCK_ROWS;
+  constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
+  const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
+  const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
-  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ>), dim3(grid), dim3(RS_THREADS), lds_bytes, stream, x, ldx, k_in, out, ldo,
+  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx, k_in, out, ldo,
                      rows, wq, b1, b0, chain);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
@@ -428,7 +480,7 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
 
 // out[rows, n_out] = L_chain(...L_1(L_0(x))): L_0(x) = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T with skip = x (b0 == NULL;
 // then k_in == n_out and out may be x itself) or x W0^T + b0, followed by `chain` identity-skip layers of the same width
-// (n_out <= 128) evaluated on the output tiles in registers.  x float32 [rows, >= k_in] with row stride ldx, out float32
+// (any width but 192) evaluated on the output tiles in registers.  x float32 [rows, >= k_in] with row stride ldx, out float32
 // with row stride ldo (device; 16-byte aligned rows: ldx, ldo multiples of 4); k_in a multiple of 8; n_out in {64, 128,
 // 192, 256}.  wq = the layers' weights as the packed split stream (cppf_reslayer_split_stream_bytes bytes;
 // cppf2_amd.models.pack_split documents the order); b1 = float32[(1 + chain) * n_out], the first-layer biases of L_0,
@@ -440,7 +492,7 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out);
   CPPF_CHECK_ARG(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256);
   CPPF_CHECK_ARG(b0 != nullptr || k_in == n_out);
-  CPPF_CHECK_ARG(chain >= 0 && chain <= 15 && (chain == 0 || n_out <= 128));
+  CPPF_CHECK_ARG(chain >= 0 && chain <= 15 && (chain == 0 || n_out != 192));
   CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
   CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr, chain));
   if (rows == 0) return CPPF_OK;

@@ -55,7 +55,7 @@ def split_bf16(w):
 def pack_split(w1, w0, w2, k_in, chain=()):
     """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
     nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights), optionally
-    followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width N <= 128.
+    followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width (N != 192).
     One operand fragment = 64 lanes x 8 bf16; lane = 32 g + i multiplies output feature 32 u + i of tile u; a tile is its
     (hi, mid, lo) fragments; a K step (16 input features) of a phase is its tiles one after the other:
       first product, step s: lane half g holds input features 16 s + 8 g + j, j < 8; tiles = all N/32 tiles of W1, and
@@ -68,7 +68,7 @@ def pack_split(w1, w0, w2, k_in, chain=()):
       output tiles in registers)."""
     n = w1.shape[0]
     nt = n // 32
-    nh = (int(os.environ.get("CPPF_RS_NH8", "2")) if nt == 8 else 2) if nt > 4 else 1
+    nh = 2 if 4 < nt < 8 else 1            # output halves of the kernel (192-wide layers only)
     nth = nt // nh
     ks1 = (k_in + 15) // 16
     dev = w1.device
@@ -149,8 +149,9 @@ def fused_stack(seq, x, keep_input=False):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
             # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
             chain = 0
-            while (n_out <= 128 and li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None
-                   and plan[li + 1 + chain][0].shape == (n_out, n_out) and chain < 15):
+            while (li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None and chain < 15
+                   and plan[li + 1 + chain][0].shape == (n_out, n_out)
+                   and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, chain + 1)):
                 chain += 1
             key = (x.shape[1], chain)
             if entry[5] is None or entry[5][0] != key:

@@ -43,7 +43,7 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
         assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(k_in, n, int(proj), 0)
         # walk the stream the way the header describes it and rebuild the three matrices
         nt = n // 32
-        nh = 2 if nt > 4 else 1
+        nh = 2 if 4 < nt < 8 else 1
         nth = nt // nh
         ks1 = (k_in + 15) // 16
         f = q.float().numpy()
@@ -86,7 +86,7 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
         assert pos == f.size and np.array_equal(got2, w2.numpy())
     assert ops._L.cppf_reslayer_split_stream_bytes(128, 96 + 1, 0, 0) == -1
     assert ops._L.cppf_reslayer_split_stream_bytes(128, 320, 0, 0) == -1
-    assert ops._L.cppf_reslayer_split_stream_bytes(256, 256, 0, 1) == -1            # chains: widths <= 128 only
+    assert ops._L.cppf_reslayer_split_stream_bytes(256, 192, 1, 1) == -1            # chains: not behind 192-wide layers
     # chained identity layers: their W1 and W2 follow, both in accumulator feature order
     w1, b1, w0, b0, w2 = _layer(72, 64, True, "cpu", seed=5)
     wa, _, _, _, wb = _layer(64, 64, False, "cpu", seed=6)
@@ -126,7 +126,8 @@ def test_reslayer_split_matches_float64_like_a_float32_gemm():
             assert e_split < 3.0 * e_nat + 2e-7, (k, n, proj, rows, e_split, e_nat)
             worst = max(worst, e_split / max(e_nat, 1e-9))
     # a projection layer with identity layers chained behind it in the same kernel (the tuple / point encoders' shape)
-    for k, n, proj, chain in ((360, 128, True, 4), (352, 128, True, 4), (128, 128, False, 3), (64, 64, False, 1), (128, 64, True, 2)):
+    for k, n, proj, chain in ((360, 128, True, 4), (352, 128, True, 4), (128, 128, False, 3), (64, 64, False, 1), (128, 64, True, 2),
+                              (128, 256, True, 2), (256, 256, False, 1)):
         w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=11)
         rest = [_layer(n, n, False, dev, seed=20 + l) for l in range(chain)]
         wq = models.pack_split(w1, w0, w2, k, chain=[(e[0], e[4]) for e in rest])
@@ -181,9 +182,9 @@ def test_reslayer_split_rejects_bad_arguments():
     with pytest.raises(_lib.CppfError):
         ops.reslayer_split(torch.randn(8, 132, device=dev), wq, b1, None, 128, out=torch.empty(8, 128, device=dev))   # k_in % 8
     with pytest.raises(_lib.CppfError):
-        ops.reslayer_split(torch.randn(8, 256, device=dev), wq, torch.zeros(512, device=dev), None, 256, chain=1)     # chain on a wide layer
+        ops.reslayer_split(torch.randn(8, 192, device=dev), wq, torch.zeros(384, device=dev), None, 192, chain=1)     # chain behind 192
     assert not ops.reslayer_split_supported(132, 128, False) and ops.reslayer_split_supported(360, 128, True, 4)
-    assert not ops.reslayer_split_supported(256, 256, False, 1)
+    assert ops.reslayer_split_supported(128, 256, True, 2) and not ops.reslayer_split_supported(192, 192, False, 1)
 
 
 @pytest.mark.gpu
