@@ -1,7 +1,8 @@
-// cppf_mlp_split.hip -- a whole ResLayer of the tuple / point MLPs (train_shot.py:19-45) as ONE kernel on the bf16 matrix
-// cores, computing in float32-equivalent arithmetic by operand splitting.
+// cppf_mlp_split.hip -- the ResLayers of the tuple / point MLPs (train_shot.py:19-45), one or several per kernel, on the
+// bf16 matrix cores, computing in float32-equivalent arithmetic by operand splitting.
 //
-//   out = skip(x) + relu(x W1^T + b1) W2^T,     skip(x) = x  (dim_in == dim_out)   or   x W0^T + b0
+//   y = skip(x) + relu(x W1^T + b1) W2^T,     skip(x) = x  (dim_in == dim_out)   or   x W0^T + b0
+//   [then identity layers of the same width chained behind it:  y <- y + relu(y W1_l^T + b1_l) W2_l^T]
 //
 // gfx950 has no xf32 / tf32 path; its f32-input MFMA runs at 1/16 of the bf16 rate.  A float32 value is EXACTLY the sum of
 // three bf16 values (8 + 8 + 8 significand bits: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid), round to
@@ -9,23 +10,28 @@
 // So  a * b = (ah + am + al)(bh + bm + bl)  is evaluated as the six products  ah bh + ah bm + am bh + am bm + ah bl + al bh;
 // the three dropped ones (am bl, al bm, al bl) are below 2^-24 |a b| together, i.e. under half a unit in the last place of
 // the product a float32 FMA chain starts from.  The result is not bit-equal to the f32-input MFMA chain (nor is any
-// re-tiled float32 GEMM); its error against a float64 evaluation is measured equal to the library float32 GEMM's
-// (tests/test_mlp_split_gpu.py).  Six bf16 MFMAs replace sixteen f32-input MFMA cycles' worth of work: 2.7x the rate.
+// re-tiled float32 GEMM); its error against a float64 evaluation is that of the library float32 GEMMs (measured side by
+// side in tests/test_mlp_split.py).  Six bf16 MFMAs replace sixteen f32-input MFMA cycles' worth of work: 2.7x the rate.
 //
-// Structure (one wavefront = 32 rows of x, one workgroup = 8 wavefronts = 256 rows, persistent over row blocks):
-//   * both products are computed TRANSPOSED (h^T = W1 x^T, out^T = skip^T + W2 h^T) with v_mfma_f32_32x32x16_bf16, so that
-//     the rows of x are the COLUMNS of the accumulator tiles (lane l owns row l & 31) and the accumulators of the first
-//     product are, after bias + ReLU and a split in registers, directly the B operands of the second -- h never leaves the
-//     registers; the K order of a sum is free, so lane half g = l >> 5 contracts over exactly the features its accumulator
-//     registers hold (row (reg & 3) + 8 (reg >> 2) + 4 g of a 32-row tile);
-//   * x is read as the B operand straight from global memory (a lane reads 32 contiguous bytes of its own row per K step)
-//     and split in registers ONCE per element -- a wavefront covers all output features of its rows;
+// Structure (one wavefront = 32 rows of x; a workgroup = 8 wavefronts, two per SIMD with 256 registers each, for widths up
+// to 128, and 4 wavefronts, one per SIMD with 512 registers, for 192 / 256; persistent over row blocks):
+//   * every product is computed TRANSPOSED (h^T = W1 x^T, y^T = skip^T + W2 h^T) with v_mfma_f32_32x32x16_bf16, so that the
+//     rows of x are the COLUMNS of the accumulator tiles (lane l owns row l & 31) and the accumulators of one product are,
+//     after bias + ReLU and a split in registers, directly the B operands of the next -- h never leaves the registers, and
+//     neither does y between chained layers; the K order of a sum is free, so lane half g = l >> 5 contracts over exactly
+//     the features its accumulator registers hold (row (reg & 3) + 8 (reg >> 2) + 4 g of a 32-row tile) and the weights
+//     are packed in that order;
+//   * a projection layer's x W0^T rides along with x W1^T (same B operand, W0's tiles behind W1's): one pass over x;
+//   * x is the B operand of the first product: a wavefront's tile of one K step (32 rows x 16 features) travels
+//     global -> LDS by LDS-DMA three K steps ahead of its use and is split in registers ONCE per element (a wavefront
+//     covers all output features of its rows);
 //   * the A operands (the weights, pre-split on the host into the per-lane fragment order: cppf2_amd.models.pack_split)
-//     stream through a two-stage LDS ring by LDS-DMA (global_load_lds_dwordx4), one K step of all output tiles per stage,
-//     shared by the eight wavefronts: the layer's weights are read from L2 once per 256 rows;
-//   * layers wider than 128 produce their output in two halves of the feature range (the h accumulators stay, the skip and
-//     the second product run per half), which keeps a wavefront under 256 registers at two wavefronts per SIMD.
-// HBM traffic per row: dim_in + dim_out floats (+ the residual re-read of an identity layer, which hits L2 / MALL).
+//     stream through a two-stage LDS ring by LDS-DMA, shared by the workgroup's wavefronts: the layer's weights are read
+//     from L2 once per row block; the pieces of the next chunk are issued between the MFMAs of the current one;
+//   * the split of the next K step's B operand and the LDS reads of the next tile's fragments are placed in the shadow of
+//     the current tile's six MFMAs; all memory waits of the main loops are counted (vmcnt(N), raw s_barrier): nothing drains
+//     the queue while tiles are in flight.
+// HBM traffic per row: dim_in + dim_out floats per kernel (+ the residual re-read of an identity first layer: L2 / MALL).
 #include "cppf_common.h"
 #include <mutex>
 
@@ -38,7 +44,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) for layers up to 192 wide, 4 (one per SIMD, 512 registers:
 // both accumulator sets of a 256-wide layer at once) for 256
-__host__ __device__ constexpr int rs_waves(int nt) { return nt >= 8 ? 4 : 8; }
+__host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
 #define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
@@ -100,16 +106,15 @@ __host__ __device__ constexpr int rs_waitcnt(int vm, int lgkm) {
 }
 #define RS_WAIT(vm, lgkm) __builtin_amdgcn_s_waitcnt(rs_waitcnt(vm, lgkm))
 
-// The weight stream of one layer, consumed in order by every wavefront of the workgroup (cppf2_amd.models.pack_split):
-// segment 0 = ks1 K steps of T0 tiles (W1; for a narrow projection layer W1 and W0 side by side), then per output half
-// [XH: W0 of the half, ks1 steps of NTH tiles] + W2 of the half (2 NT steps of NTH tiles), then W1, W2 of each chained
-// layer.  It moves through a two-stage LDS ring by LDS-DMA in chunks of up to rs_spc(tiles) K steps of one segment: the
+// The weight stream of one kernel, consumed in order by every wavefront of the workgroup (cppf2_amd.models.pack_split):
+// segment 0 = ks1 K steps of T0 tiles (W1; for a projection layer W1 and W0 side by side), then W2 (2 NT steps of NT
+// tiles), then W1, W2 of each chained layer (2 NT steps of NT tiles each).  It moves through a two-stage LDS ring by LDS-DMA in chunks of up to rs_spc(tiles) K steps of one segment: the
 // pieces of chunk c + 1 (1 KiB per wavefront instruction) are issued between the MFMAs of the first K step of chunk c.
 // All memory waits of the kernel's main loops are COUNTED (the vector-memory queue completes in order): see acquire().
-template <int NT, int T0, int NTH, bool XH, int WAVES>
+template <int NT, int T0, int WAVES>
 struct RsStream {
   static constexpr int PMAX = 48 / WAVES;      // pieces of a chunk per wavefront, at most
-  int nseg;                    // 1 + per half (W0?, W2) + per chained identity layer (W1, W2)
+  int nseg;                    // 2 + 2 per chained identity layer
   int chunks;                  // chunks per row block
   const char* base;            // packed stream in global memory
   char* ring;                  // LDS, two stages
@@ -124,18 +129,17 @@ struct RsStream {
   int p_n;
 
   __device__ __forceinline__ void shape(int chain) {
-    const int cx = (ks1 + rs_spc(T0) - 1) / rs_spc(T0), cxh = (ks1 + rs_spc(NTH) - 1) / rs_spc(NTH);
-    nseg = 1 + (NT / NTH) * (XH ? 2 : 1) + 2 * chain;
-    chunks = cx + (NT / NTH) * ((XH ? cxh : 0) + 2 * NT / rs_spc(NTH)) + chain * 2 * (2 * NT / rs_spc(NTH));
+    nseg = 2 + 2 * chain;
+    chunks = (ks1 + rs_spc(T0) - 1) / rs_spc(T0) + (1 + 2 * chain) * (2 * NT / rs_spc(NT));
   }
   // selects the next chunk of the stream (destination: stage st); its pieces are then issued one by one with piece()
   __device__ __forceinline__ void plan(int st) {
     p_n = 0;
     if (left <= 0) return;
     const bool first = seg == 0;
-    const int tiles = first ? T0 : NTH;
-    const int spc = first ? rs_spc(T0) : rs_spc(NTH);
-    const int steps = (first || (XH && (seg & 1))) ? ks1 : 2 * NT;
+    const int tiles = first ? T0 : NT;
+    const int spc = first ? rs_spc(T0) : rs_spc(NT);
+    const int steps = first ? ks1 : 2 * NT;
     const int ns = steps - pos < spc ? steps - pos : spc;
     const int pieces = ns * tiles * 3;
     p_src = base + off + wave * RS_FRAG_BYTES + lane * 16;
@@ -323,19 +327,13 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
 
 template <int NT, bool PROJ>
 __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
-                                                                       int64_t ldo, int64_t rows, const char* __restrict__ wq,
-                                                                       const float* __restrict__ b1,
-                                                                       const float* __restrict__ b0, int chain) {
+                                                                              int64_t ldo, int64_t rows,
+                                                                              const char* __restrict__ wq,
+                                                                              const float* __restrict__ b1,
+                                                                              const float* __restrict__ b0, int chain) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
-  constexpr int NH = (NT > 4 && WAVES == 8) ? 2 : 1;            // output halves
-  constexpr int NTH = NT / NH;
-  constexpr bool FUSE0 = PROJ && NH == 1;       // narrow projection layer: x W0^T rides along with x W1^T (one pass over x)
-  constexpr bool XH = PROJ && !FUSE0;           // wide projection layer: x W0^T per output half
-  constexpr int T0 = FUSE0 ? 2 * NT : NT;       // tiles of the first product
-  constexpr int SPC2 = rs_spc(NTH);
-  constexpr bool PF = RS_PREFETCH_MAX_NT >= NT; // LDS read-ahead of the next tile's fragments
-  constexpr bool AHEAD = NH == 1;               // the next row block's first x values are fetched during the second product
-  static_assert((2 * NT) % SPC2 == 0, "second product: whole chunks");
+  constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
+  constexpr bool PF = true;                     // LDS read-ahead of the next tile's fragments
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: keeps its derived addresses scalar
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
 
-  RsStream<NT, T0, NTH, XH, WAVES> ws;
+  RsStream<NT, T0, WAVES> ws;
   ws.base = wq;
   ws.ring = s_ring;
   ws.ks1 = ks1;
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   ws.prime();
   // the biases live in LDS: as kernel-lifetime registers (where the compiler would hoist them) they cost 16 per tile
   float* s_b1 = reinterpret_cast<float*>(s_ring + 2 * RS_STAGE_BYTES + WAVES * 3 * 2048);
-  float* s_b0 = s_b1 + 32 * NT;                 // directly behind b1: the fused first product initialises both in one sweep
+  float* s_b0 = s_b1 + 32 * NT;                 // directly behind b1: the first product initialises both in one sweep
   for (int i = threadIdx.x; i < 32 * NT; i += THREADS) {
     s_b1[i] = b1[i];
     if (PROJ) s_b0[i] = b0[i];
@@ -382,22 +380,21 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     xs.issue(1, 1);
     xs.issue(2, 2);
   };
-  if (AHEAD && blockIdx.x < nblocks) first_tiles(row_ptr(blockIdx.x));
+  if (blockIdx.x < nblocks) first_tiles(row_ptr(blockIdx.x));
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
     const float* xrow = row_ptr(blk);
-    // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a narrow projection layer] ---------------------
-    f32x16 acc[T0 + (FUSE0 ? 0 : NTH)];         // h tiles, then the output tiles (of one half)
+    // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a projection layer] ----------------------------
+    f32x16 acc[2 * NT];                         // h tiles, then the output tiles
     f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
-    f32x16 (&o)[NTH] = *reinterpret_cast<f32x16 (*)[NTH]>(&acc[NT]);
+    f32x16 (&o)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
 #pragma unroll
     for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
-    if (!PROJ && AHEAD) {                       // residual of a narrow identity layer: requested before the first product
+    if (!PROJ) {                                // residual of an identity layer: requested before the first product
 #pragma unroll
-      for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
+      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
-    if (!AHEAD) first_tiles(xrow);
     xs.xrow = xrow;
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
@@ -408,48 +405,34 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
 #pragma unroll
       for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];        // NaN stays NaN like torch.relu
     }
-    // ---- out^T = skip^T + W2 h^T, one half of the output features at a time ------------------------------
-#pragma unroll
-    for (int hf = 0; hf < NH; ++hf) {
-      if (XH) {
-#pragma unroll
-        for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], s_b0 + 32 * (hf * NTH + u), g);
-        first_tiles(xrow);
-        rs_product_x<NTH, PF>(o, xs, ks1, ws);
-      } else if (!PROJ && !AHEAD) {
-#pragma unroll
-        for (int u = 0; u < NTH; ++u) rs_load_tile(o[u], xrow + 32 * (hf * NTH + u), g);
-      }
-      if (AHEAD && blk + gridDim.x < nblocks) first_tiles(row_ptr(blk + gridDim.x));
-      rs_product_h<NT, NTH, PF>(o, h, ws);
-      if (NH == 1) {
-        // ---- the identity layers chained behind (same width): x <- x + relu(x W1^T + b1) W2^T with x = the output tiles,
-        // never leaving the registers; their W1 is packed in accumulator feature order like every W2
+    // the next row block's first x tiles travel during the remaining products (their slots are free now)
+    if (blk + gridDim.x < nblocks) first_tiles(row_ptr(blk + gridDim.x));
+    // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
+    rs_product_h<NT, NT, PF>(o, h, ws);
+    // ---- the identity layers chained behind (same width): y <- y + relu(y W1^T + b1) W2^T with y = the output tiles,
+    // never leaving the registers; their W1 is packed in accumulator feature order like every W2
 #pragma unroll 1
-        for (int l = 0; l < chain; ++l) {
-          const float* bl = s_b1 + 32 * NT * (2 + l);
+    for (int l = 0; l < chain; ++l) {
+      const float* bl = s_b1 + 32 * NT * (2 + l);
 #pragma unroll
-          for (int u = 0; u < NT; ++u) rs_load_tile(h[u], bl + 32 * u, g);
-          f32x16 (&xo)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
-          rs_product_h<NT, NT, PF>(h, xo, ws);
+      for (int u = 0; u < NT; ++u) rs_load_tile(h[u], bl + 32 * u, g);
+      rs_product_h<NT, NT, PF>(h, o, ws);
 #pragma unroll
-          for (int u = 0; u < NT; ++u) {
+      for (int u = 0; u < NT; ++u) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];
-          }
-          rs_product_h<NT, NT, PF>(xo, h, ws);
-        }
+        for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];
       }
-      if (in) {
-        float* orow = out + row * ldo + 32 * hf * NTH + 4 * g;
+      rs_product_h<NT, NT, PF>(o, h, ws);
+    }
+    if (in) {
+      float* orow = out + row * ldo + 4 * g;
 #pragma unroll
-        for (int u = 0; u < NTH; ++u) {
+      for (int u = 0; u < NT; ++u) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-            v.x = o[u][4 * q + 0]; v.y = o[u][4 * q + 1]; v.z = o[u][4 * q + 2]; v.w = o[u][4 * q + 3];
-            *reinterpret_cast<f32x4*>(orow + 32 * u + 8 * q) = v;
-          }
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v.x = o[u][4 * q + 0]; v.y = o[u][4 * q + 1]; v.z = o[u][4 * q + 2]; v.w = o[u][4 * q + 3];
+          *reinterpret_cast<f32x4*>(orow + 32 * u + 8 * q) = v;
         }
       }
     }
@@ -457,12 +440,9 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
 }
 
 extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
-  if (k_in <= 0 || n_out <= 0 || (n_out & 31) || n_out > 256 || chain < 0 || chain > 15) return -1;
-  const int nt = n_out / 32, nh = (nt > 4 && rs_waves(nt) == 8) ? 2 : 1, nth = nt / nh;
-  if (nt != nth * nh || (chain > 0 && nh != 1)) return -1;
-  const int64_t ks1 = (k_in + 15) / 16;
-  return ks1 * nt * RS_TILE_BYTES + (int64_t)nh * ((proj ? ks1 : 0) + 2 * nt) * nth * RS_TILE_BYTES +
-         (int64_t)chain * 2 * (2 * nt) * nt * RS_TILE_BYTES;
+  if (k_in <= 0 || !(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256) || chain < 0 || chain > 15) return -1;
+  const int64_t nt = n_out / 32, ks1 = (k_in + 15) / 16;
+  return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * RS_TILE_BYTES;
 }
 
 template <int NT, bool PROJ>
@@ -480,7 +460,7 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
 
 // out[rows, n_out] = L_chain(...L_1(L_0(x))): L_0(x) = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T with skip = x (b0 == NULL;
 // then k_in == n_out and out may be x itself) or x W0^T + b0, followed by `chain` identity-skip layers of the same width
-// (any width but 192) evaluated on the output tiles in registers.  x float32 [rows, >= k_in] with row stride ldx, out float32
+// evaluated on the output tiles in registers.  x float32 [rows, >= k_in] with row stride ldx, out float32
 // with row stride ldo (device; 16-byte aligned rows: ldx, ldo multiples of 4); k_in a multiple of 8; n_out in {64, 128,
 // 192, 256}.  wq = the layers' weights as the packed split stream (cppf_reslayer_split_stream_bytes bytes;
 // cppf2_amd.models.pack_split documents the order); b1 = float32[(1 + chain) * n_out], the first-layer biases of L_0,
@@ -492,7 +472,7 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out);
   CPPF_CHECK_ARG(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256);
   CPPF_CHECK_ARG(b0 != nullptr || k_in == n_out);
-  CPPF_CHECK_ARG(chain >= 0 && chain <= 15 && (chain == 0 || n_out != 192));
+  CPPF_CHECK_ARG(chain >= 0 && chain <= 15);
   CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
   CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr, chain));
   if (rows == 0) return CPPF_OK;

@@ -55,46 +55,37 @@ def split_bf16(w):
 def pack_split(w1, w0, w2, k_in, chain=()):
     """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
     nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights), optionally
-    followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width (N != 192).
+    followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width.
     One operand fragment = 64 lanes x 8 bf16; lane = 32 g + i multiplies output feature 32 u + i of tile u; a tile is its
-    (hi, mid, lo) fragments; a K step (16 input features) of a phase is its tiles one after the other:
-      first product, step s: lane half g holds input features 16 s + 8 g + j, j < 8; tiles = all N/32 tiles of W1, and
-        for a projection layer with N <= 128 the N/32 tiles of W0 behind them (one pass over x computes both);
-      then per output half (one half for N <= 128, two otherwise):
-        [W0 of the half's tiles, same K order]  (projection layers with N > 128 only)
-        W2 of the half's tiles, step (t, s') over the hidden features in the accumulator order of the first product:
+    (hi, mid, lo) fragments; a K step (16 input features) of a product is its tiles one after the other:
+      first product, step s: lane half g holds input features 16 s + 8 g + j, j < 8; tiles = the N/32 tiles of W1 and, for
+        a projection layer, the N/32 tiles of W0 behind them (one pass over x computes both);
+      second product (W2), step (t, s') over the hidden features in the accumulator order of the first product:
         lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2);
       then per chained layer W1_l and W2_l, both in that accumulator feature order (their input is the previous layer's
       output tiles in registers)."""
     n = w1.shape[0]
     nt = n // 32
-    nh = 2 if 4 < nt < 8 else 1            # output halves of the kernel (192-wide layers only)
-    nth = nt // nh
     ks1 = (k_in + 15) // 16
     dev = w1.device
 
-    def pack_x(w, first, tiles):
-        s = split_bf16(F.pad(w.detach().float(), (0, ks1 * 16 - w.shape[1])))[:, 32 * first:32 * (first + tiles)]
+    def pack_x(w, tiles):
+        s = split_bf16(F.pad(w.detach().float(), (0, ks1 * 16 - w.shape[1])))
         return s.reshape(3, tiles, 32, ks1, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)      # [s, u, slice, g, i, j]
 
-    def pack_h(w, first, tiles):
+    def pack_h(w):
         t = torch.arange(nt, device=dev).view(nt, 1, 1, 1)
         sp = torch.arange(2, device=dev).view(1, 2, 1, 1)
         g = torch.arange(2, device=dev).view(1, 1, 2, 1)
         j = torch.arange(8, device=dev).view(1, 1, 1, 8)
         col = (32 * t + 16 * sp + 4 * g + (j & 3) + 8 * (j >> 2)).reshape(-1)
-        s = split_bf16(w)[:, 32 * first:32 * (first + tiles)][:, :, col]
-        return s.reshape(3, tiles, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)  # [t, s', u, slice, g, i, j]
+        s = split_bf16(w)[:, :, col]
+        return s.reshape(3, nt, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)    # [t, s', u, slice, g, i, j]
 
-    fuse0 = w0 is not None and nh == 1
-    parts = [pack_x(torch.cat([w1, w0]), 0, 2 * nt) if fuse0 else pack_x(w1, 0, nt)]
-    for hf in range(nh):
-        if w0 is not None and not fuse0:
-            parts.append(pack_x(w0, hf * nth, nth))
-        parts.append(pack_h(w2, hf * nth, nth))
+    parts = [pack_x(w1, nt) if w0 is None else pack_x(torch.cat([w1, w0]), 2 * nt), pack_h(w2)]
     for w1_l, w2_l in chain:
-        assert nh == 1 and w1_l.shape == (n, n) and w2_l.shape == (n, n)
-        parts += [pack_h(w1_l, 0, nt), pack_h(w2_l, 0, nt)]
+        assert w1_l.shape == (n, n) and w2_l.shape == (n, n)
+        parts += [pack_h(w1_l), pack_h(w2_l)]
     return torch.cat(parts).contiguous()
 
 

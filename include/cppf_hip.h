@@ -319,7 +319,7 @@ int cppf_reslayer128(float* x, int64_t rows, const float* w1, const float* b1, c
  * exact-product MFMAs per K step, float32 accumulate; error against float64 = a float32 GEMM's, see cppf_mlp_split.hip):
  *     y = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T          skip(x) = x when b0 == NULL (then k_in == n_out; out may be
  *                                                              x itself: in place), x W0^T + b0 otherwise
- *     then `chain` times (n_out != 192)       y <- y + relu(y W1_l^T + b1_l) W2_l^T   without leaving the registers
+ *     then `chain` times                       y <- y + relu(y W1_l^T + b1_l) W2_l^T   without leaving the registers
  * x float32 with row stride ldx >= k_in, out float32 with row stride ldo >= n_out (elements; both multiples of 4, base
  * pointers 16-byte aligned); k_in a multiple of 8 (columns of x beyond the layer's true dim_in must hold finite values;
  * their weights are zero in the stream); n_out in {64, 128, 192, 256}; b1 float32[(1 + chain) * n_out].  wq = the weights

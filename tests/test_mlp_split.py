@@ -41,10 +41,8 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
         q = models.pack_split(w1, w0, w2, k_in)
         assert q.dtype == torch.bfloat16
         assert q.numel() * 2 == ops._L.cppf_reslayer_split_stream_bytes(k_in, n, int(proj), 0)
-        # walk the stream the way the header describes it and rebuild the three matrices
+        # walk the stream the way pack_split's docstring describes it and rebuild the three matrices
         nt = n // 32
-        nh = 2 if 4 < nt < 8 else 1
-        nth = nt // nh
         ks1 = (k_in + 15) // 16
         f = q.float().numpy()
         pos = 0
@@ -54,39 +52,26 @@ def test_split_is_exact_and_stream_order_is_the_documented_one():
             c = f[pos:pos + steps * tiles * 3 * 512].reshape(steps, tiles, 3, 2, 32, 8)   # [step, tile, slice, g, i, j]
             pos += c.size
             return c.sum(2)                                                                # hi + mid + lo
-        fuse0 = proj and nh == 1                      # narrow projection layer: W0's tiles ride behind W1's
-        t0 = 2 * nt if fuse0 else nt
+        t0 = 2 * nt if proj else nt                   # projection layer: W0's tiles ride behind W1's
         c1 = take(t0, ks1)
         got1 = np.zeros((32 * t0, ks1 * 16), np.float32)
         for s_ in range(ks1):
             for g_ in range(2):
                 got1[:, 16 * s_ + 8 * g_:16 * s_ + 8 * g_ + 8] = c1[s_, :, g_].reshape(32 * t0, 8)
         assert np.array_equal(got1[:n, :k], w1.numpy()) and not got1[:, k:].any()
-        if fuse0:
+        if proj:
             assert np.array_equal(got1[n:, :k], w0.numpy())
+        c2 = take(nt, 2 * nt)
         got2 = np.zeros((n, n), np.float32)
-        for hf in range(nh):
-            if proj and not fuse0:
-                c0 = take(nth, ks1)
-                for s_ in range(ks1):
-                    for g_ in range(2):
-                        blk = c0[s_, :, g_].reshape(nth * 32, 8)
-                        cols = slice(16 * s_ + 8 * g_, 16 * s_ + 8 * g_ + 8)
-                        want = np.zeros((nth * 32, 8), np.float32)
-                        src = w0.numpy()[32 * hf * nth:32 * (hf + 1) * nth, cols]
-                        want[:, :src.shape[1]] = src
-                        assert np.array_equal(blk, want)
-            c2 = take(nth, 2 * nt)
-            for t in range(nt):
-                for sp in range(2):
-                    for g_ in range(2):
-                        for j in range(8):
-                            col = 32 * t + 16 * sp + 4 * g_ + (j & 3) + 8 * (j >> 2)
-                            got2[32 * hf * nth:32 * (hf + 1) * nth, col] = c2[2 * t + sp, :, g_, :, j].reshape(-1)
+        for t in range(nt):
+            for sp in range(2):
+                for g_ in range(2):
+                    for j in range(8):
+                        got2[:, 32 * t + 16 * sp + 4 * g_ + (j & 3) + 8 * (j >> 2)] = c2[2 * t + sp, :, g_, :, j].reshape(-1)
         assert pos == f.size and np.array_equal(got2, w2.numpy())
     assert ops._L.cppf_reslayer_split_stream_bytes(128, 96 + 1, 0, 0) == -1
     assert ops._L.cppf_reslayer_split_stream_bytes(128, 320, 0, 0) == -1
-    assert ops._L.cppf_reslayer_split_stream_bytes(256, 192, 1, 1) == -1            # chains: not behind 192-wide layers
+    assert ops._L.cppf_reslayer_split_stream_bytes(256, 192, 1, 16) == -1           # at most 15 chained layers
     # chained identity layers: their W1 and W2 follow, both in accumulator feature order
     w1, b1, w0, b0, w2 = _layer(72, 64, True, "cpu", seed=5)
     wa, _, _, _, wb = _layer(64, 64, False, "cpu", seed=6)
@@ -127,7 +112,7 @@ def test_reslayer_split_matches_float64_like_a_float32_gemm():
             worst = max(worst, e_split / max(e_nat, 1e-9))
     # a projection layer with identity layers chained behind it in the same kernel (the tuple / point encoders' shape)
     for k, n, proj, chain in ((360, 128, True, 4), (352, 128, True, 4), (128, 128, False, 3), (64, 64, False, 1), (128, 64, True, 2),
-                              (128, 256, True, 2), (256, 256, False, 1)):
+                              (128, 256, True, 2), (256, 256, False, 1), (256, 192, True, 1)):
         w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=11)
         rest = [_layer(n, n, False, dev, seed=20 + l) for l in range(chain)]
         wq = models.pack_split(w1, w0, w2, k, chain=[(e[0], e[4]) for e in rest])
@@ -181,10 +166,8 @@ def test_reslayer_split_rejects_bad_arguments():
         ops.reslayer_split(x, wq, b1[:96], None, 96, out=torch.empty(8, 96, device=dev))   # unsupported width
     with pytest.raises(_lib.CppfError):
         ops.reslayer_split(torch.randn(8, 132, device=dev), wq, b1, None, 128, out=torch.empty(8, 128, device=dev))   # k_in % 8
-    with pytest.raises(_lib.CppfError):
-        ops.reslayer_split(torch.randn(8, 192, device=dev), wq, torch.zeros(384, device=dev), None, 192, chain=1)     # chain behind 192
     assert not ops.reslayer_split_supported(132, 128, False) and ops.reslayer_split_supported(360, 128, True, 4)
-    assert ops.reslayer_split_supported(128, 256, True, 2) and not ops.reslayer_split_supported(192, 192, False, 1)
+    assert ops.reslayer_split_supported(128, 256, True, 2) and not ops.reslayer_split_supported(192, 192, False, 16)
 
 
 @pytest.mark.gpu
