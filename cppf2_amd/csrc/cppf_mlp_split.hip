@@ -49,6 +49,12 @@ __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
 
+#ifndef RS_DEEP_PREFETCH
+#define RS_DEEP_PREFETCH 0
+#endif
+#ifndef RS_INTERLEAVE
+#define RS_INTERLEAVE 1
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -76,6 +82,7 @@ __device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, u
   h = __builtin_bit_cast(unsigned, hb);
   m = __builtin_bit_cast(unsigned, mb);
   l = __builtin_bit_cast(unsigned, lb);
+  if (PIN) asm volatile("" : "+v"(h), "+v"(m), "+v"(l));      // ... and from sinking the arithmetic down to its first use
 }
 
 __device__ __forceinline__ RsFrag rs_split(const float (&v)[8]) {
@@ -124,9 +131,9 @@ struct RsStream {
   int64_t left;                // chunks still to fetch over the remaining row blocks of this workgroup
   int stage;                   // stage the next acquire() returns
   int wave, lane;
-  const char* p_src;           // this wavefront's first piece of the chunk being fetched, and how many pieces it has
+  const char* p_src;           // the chunk being fetched (this lane's 16 bytes of its piece 0), its stage, its last piece
   char* p_dst;
-  int p_n;
+  int p_last;
 
   __device__ __forceinline__ void shape(int chain) {
     nseg = 2 + 2 * chain;
@@ -134,18 +141,20 @@ struct RsStream {
   }
   // selects the next chunk of the stream (destination: stage st); its pieces are then issued one by one with piece()
   __device__ __forceinline__ void plan(int st) {
-    p_n = 0;
-    if (left <= 0) return;
+    p_dst = ring + st * RS_STAGE_BYTES;
+    if (left <= 0) {                             // past the end: piece() re-reads the stream's first KiB into the idle stage
+      p_src = base + lane * 16;
+      p_last = 0;
+      return;
+    }
     const bool first = seg == 0;
     const int tiles = first ? T0 : NT;
     const int spc = first ? rs_spc(T0) : rs_spc(NT);
     const int steps = first ? ks1 : 2 * NT;
     const int ns = steps - pos < spc ? steps - pos : spc;
     const int pieces = ns * tiles * 3;
-    p_src = base + off + wave * RS_FRAG_BYTES + lane * 16;
-    p_dst = ring + st * RS_STAGE_BYTES + wave * RS_FRAG_BYTES;
-    p_n = (pieces - wave + WAVES - 1) / WAVES;
-    if (p_n < 0) p_n = 0;
+    p_src = base + off + lane * 16;
+    p_last = pieces - 1;
     off += (int64_t)pieces * RS_FRAG_BYTES;
     pos += ns;
     if (pos == steps) {
@@ -157,12 +166,14 @@ struct RsStream {
     }
     --left;
   }
-  // the q-th piece of this wavefront (pieces wave, wave + WAVES, ...): at most PMAX per chunk
+  // the q-th piece of this wavefront (pieces wave, wave + WAVES, ...; at most PMAX per chunk).  Branch-free: past the
+  // chunk's last piece it re-issues that one (same bytes to the same place), which also keeps the number of
+  // vector-memory operations per chunk the same for every wavefront.
   __device__ __forceinline__ void piece(int q) {
-    if (q < p_n) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + q * (WAVES * RS_FRAG_BYTES)),
-                                       (__attribute__((address_space(3))) void*)(p_dst + q * (WAVES * RS_FRAG_BYTES)), 16, 0, 0);
-    }
+    int j = wave + q * WAVES;
+    j = j < p_last ? j : p_last;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + j * RS_FRAG_BYTES),
+                                     (__attribute__((address_space(3))) void*)(p_dst + j * RS_FRAG_BYTES), 16, 0, 0);
   }
   __device__ __forceinline__ void prime() {                // the very first chunk: all pieces at once
     plan(0);
@@ -205,19 +216,38 @@ __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
 // per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
 template <int NTILES, bool PREFETCH, int PMAX, class F, class D>
 __device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler, D&& dma) {
-  RsFrag a = rs_read(w, 0);
+  // PREFETCH: fragments are requested two tiles ahead (one wavefront per SIMD: nobody else covers the LDS latency);
+  // otherwise one tile ahead
+  RsFrag a0 = rs_read(w, 0), a1 = a0;
+  if (PREFETCH && NTILES > 1) a1 = rs_read(w, 1);
 #pragma unroll
   for (int u = 0; u < NTILES; ++u) {
-    RsFrag an = a;
-    if (PREFETCH && u + 1 < NTILES) an = rs_read(w, u + 1);
-    if (!PREFETCH && u > 0) a = rs_read(w, u);
+    RsFrag a2 = a1;
+    if (PREFETCH) {
+      if (u + 2 < NTILES) a2 = rs_read(w, u + 2);
+    } else {
+      if (u + 1 < NTILES) a1 = rs_read(w, u + 1);
+    }
 #pragma unroll
     for (int q = (u * PMAX + NTILES - 1) / NTILES; q < ((u + 1) * PMAX + NTILES - 1) / NTILES; ++q) dma(q);
 #pragma unroll
     for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
-    rs_mma6(acc[u], a, b);
+    rs_mma6(acc[u], a0, b);
+#if RS_INTERLEAVE
+    // issue order within the tile: one MFMA, then a few of the independent instructions (the three LDS reads, a DMA piece,
+    // a slice of the split) that fit its 32-cycle shadow -- not all of them behind the first MFMA
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+      if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      if (k == 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read (LDS-DMA)
+      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);       // SALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);       // VALU
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    if (PREFETCH) a = an;
+    a0 = a1;
+    if (PREFETCH) a1 = a2;
   }
 }
 
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
                                                                               const float* __restrict__ b0, int chain) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
-  constexpr bool PF = true;                     // LDS read-ahead of the next tile's fragments
+  constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: keeps its derived addresses scalar
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     f32x16 (&o)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
 #pragma unroll
     for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
-    if (!PROJ) {                                // residual of an identity layer: requested before the first product
+    if (!PROJ && WAVES == 8) {                  // residual of a narrow identity layer: requested before the first product
 #pragma unroll
       for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
@@ -404,6 +434,10 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     for (int u = 0; u < NT; ++u) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];        // NaN stays NaN like torch.relu
+    }
+    if (!PROJ && WAVES == 4) {                  // ... of a wide one: after it (L2-hot), its registers were the first product's
+#pragma unroll
+      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
     if (blk + gridDim.x < nblocks) first_tiles(row_ptr(blk + gridDim.x));
