@@ -22,16 +22,23 @@ for r in stats:
     rows.append((key, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, hbm))
 rows.sort(key=lambda x: -x[1] * x[2])
 with open(os.path.join(P, RND + "_summary.md"), "w") as f:
-    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --no-reference-order`, %d passes incl. priming)\n\n" % (RND, steps))
+    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith`, %d passes incl. priming)\n\n" % (RND, steps))
     f.write("Sources: `%s_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `%s_pmc_traffic.json` = "
             "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (KB per launch; HBM bytes = "
             "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `%s_bench_n1.json` = the bench line of the same build. "
             "Regenerate with `scratch/refresh_profiles.sh` + `scratch/profile_table.py`.\n\n" % (RND, RND, RND))
-    f.write("Bench: %.0f scenes/s, %.2f ms/step (64 scenes); dominant HIP kernel `%s` %.3f ms per launch, "
-            "roofline %.0f GB/s of %d (frac %.3f), PMC traffic %.0f MB per launch.\n\n"
-            % (bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_name"], bench["roofline"]["launch_ms"],
-               bench["roofline"]["achieved"], bench["roofline"]["peak"], bench["roofline"]["frac"],
-               (bench["roofline"]["traffic"] or 0) / 1e6))
+    rf = bench["roofline"]
+    f.write("Bench: %.0f scenes/s, %.2f ms/step (64 scenes); dominant kernel `%s` (%s-bound) %.3f ms per step, "
+            "roofline %.0f %s of %d (frac %.3f), PMC traffic %.0f MB.\n"
+            % (bench["value"], bench["ms_per_step"], rf["kernel_name"], rf["bound"], rf["launch_ms"],
+               rf["achieved"], rf["unit"], rf["peak"], rf["frac"], (rf["traffic"] or 0) / 1e6))
+    if "hbm" in rf:
+        h = rf["hbm"]
+        f.write("HBM-bound kernel with the longest launch: `%s` %.3f ms, %.0f GB/s of %d algorithmic (frac %.3f), PMC traffic %.0f MB per launch; "
+                "same run with the MLP on the f32-input matrix cores: %s scenes/s.\n"
+                % (h["kernel_name"], h["launch_ms"], h["achieved"], h["peak"], h["frac"], (h["traffic"] or 0) / 1e6,
+                   "%.0f" % bench["value_f32_input_mfma"] if bench.get("value_f32_input_mfma") else "n/a"))
+    f.write("\n")
     f.write("| HIP kernel | launches / step | avg us / launch | ms / step | HBM MB / launch (PMC) | HBM GB/s (PMC) |\n|---|---|---|---|---|---|\n")
     tot = 0.0
     for k, c, us, hbm in rows:
@@ -39,7 +46,7 @@ with open(os.path.join(P, RND + "_summary.md"), "w") as f:
         f.write("| `%s` | %.0f | %.1f | %.3f | %s | %s |\n" % (k, c, us, c * us / 1e3, "%.1f" % (hbm / 1e6) if hbm else "-",
                                                             "%.0f" % (hbm / 1e9 / (us / 1e6)) if hbm else "-"))
     f.write("| **all HIP kernels** | | | **%.3f** | | |\n" % tot)
-    f.write("| hipBLASLt / rocBLAS GEMMs (tuple MLP + point encoder, PyTorch) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
+    f.write("| hipBLASLt / rocBLAS GEMMs (PyTorch: the 64 -> 3 output layer of the scale head) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
     f.write("| PyTorch elementwise / copies | | | %.3f | | |\n" % (elt_ns / steps / 1e6))
     f.write("\nPer-stage HIP-event times of the bench (ms per step): `%s`\n" % json.dumps(bench["roofline"]["per_stage_ms"]))
 print(open(os.path.join(P, RND + "_summary.md")).read())
