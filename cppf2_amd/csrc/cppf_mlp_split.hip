@@ -486,6 +486,19 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
+  {
+    // more than 64 KiB of dynamic LDS: declared once per kernel and device
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    CPPF_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev & 63]) {
+      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+      done[dev & 63] = true;
+    }
+  }
   hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx, k_in, out, ldo,
                      rows, wq, b1, b0, chain);
   CPPF_LAUNCH_CHECK();
