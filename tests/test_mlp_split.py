@@ -129,6 +129,17 @@ def test_reslayer_split_matches_float64_like_a_float32_gemm():
             e_split = (got.double() - want.double()).abs().max().item() / scale
             e_nat = (nat.double() - want.double()).abs().max().item() / scale
             assert e_split < 3e-6 and e_split < 3.0 * e_nat + 2e-7, (k, n, chain, rows, e_split, e_nat)
+    # K at the edges of the supported range (one half-step; a long contraction with a ragged last step), output rows inside
+    # a wider buffer (row stride > n_out) whose other columns stay untouched
+    for k, n, proj in ((8, 64, True), (1032, 128, True), (520, 256, True)):
+        w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=3)
+        wq = models.pack_split(w1, w0, w2, k)
+        x = torch.randn(777, k, device=dev)
+        buf = torch.full((777, n + 12), 7.0, device=dev)
+        got = ops.reslayer_split(x, wq, b1, b0, n, out=buf[:, 4:4 + n])
+        want = _ref64(x, w1, b1, w0, b0, w2)
+        assert (got.double() - want).abs().max().item() < 3e-6 * want.abs().max().item()
+        assert bool((buf[:, :4] == 7.0).all()) and bool((buf[:, 4 + n:] == 7.0).all())
     # in place on a strided view (row stride > k), rows of the parent beyond the view untouched; NaN stays NaN through relu
     k = n = 128
     w1, b1, w0, b0, w2 = _layer(k, n, False, dev)
