@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--mlp-arith", choices=("split", "native"), default=None,
                     help="arithmetic of the tuple MLP: split = float32 as 3 x bf16 on the bf16 matrix cores (default, "
                          "cppf_reslayer_split), native = f32-input matrix cores (library GEMMs + cppf_reslayer128)")
+    ap.add_argument("--materialize-tuples", action="store_true",
+                    help="write the [T, 360] tuple rows (cppf_encode_tuples_shot) and let the MLP read them back, instead of "
+                         "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
     ap.add_argument("--no-native-arith", action="store_true",
                     help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
@@ -130,9 +133,18 @@ class Step:
         self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
         self.side = torch.cuda.Stream(device=dev)
         self.eager = bool(args.eager_scale_head)
+        self.materialize = bool(getattr(args, "materialize_tuples", False))
+        self.host_times = None          # debugging aid: host-side time stamps of the stage boundaries (CPPF_BENCH_HOSTTIMES=1)
         self.ev = None
 
+    @property
+    def gather(self):
+        from cppf2_amd import models
+        return (not self.materialize) and models.MLP_ARITH == "split" and self.model.gather_supported(64, 5)
+
     def _mark(self, name):
+        if self.host_times is not None:
+            self.host_times.append((name, time.perf_counter()))
         if self.ev is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -155,10 +167,24 @@ class Step:
         normal = torch.nan_to_num_(self.normal, nan=0.0)
         feat = self.model.encode_points(shot)
         self._mark("shot_encoder")
-        x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
-        self._mark("encode_tuples")
         eager = self.eager
-        logits, feat = self.model.heads(x, lazy_scale=not eager)
+        if self.gather:
+            # train_shot.py:75-83 without its 1.8 GB of rows: pair features + global indices, the first ResLayer gathers
+            heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+            self._mark("encode_tuples")
+            from cppf2_amd.models import fused_stack
+            tf = fused_stack(self.model.tuple_encoder, None, gather=(heads, gidx, feat))
+            if eager:
+                scales = fused_stack(self.model.scale_encoder, tf)
+                logits = fused_stack(self.model.logit_encoder, tf).reshape(tf.shape[0], 6, -1)
+                feat = scales
+            else:
+                logits = fused_stack(self.model.logit_encoder, tf, keep_input=True).reshape(tf.shape[0], 6, -1)
+                feat = tf
+        else:
+            x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
+            self._mark("encode_tuples")
+            logits, feat = self.model.heads(x, lazy_scale=not eager)
         self._mark("tuple_mlp")
         u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
@@ -192,8 +218,13 @@ class Step:
         return self.ev
 
 
+GATHERED_TUPLES = False         # set by main(): the encode stage writes pair features + indices only
+
+
 def algorithmic_bytes(stage, B, N, T, R, S, G):
     """Compulsory bytes one launch of the stage's kernel moves for B scenes (SURVEY.md 8d per-scene figures)."""
+    if stage == "encode_tuples" and GATHERED_TUPLES:
+        return (T * 5 * 4 + N * 12 + N * 12 + T * 40 * 4 + T * 5 * 4) * B
     per_scene = {
         "sample_tuples": T * 5 * 4,
         "shot_frames": N * 12 * 2 + N * 12 + N * 19 * 8 * 2 + N * 56,   # points in+sorted, normals out, sums w+r, frames
@@ -296,6 +327,10 @@ def main():
     if args.mlp_arith:
         _models.MLP_ARITH = args.mlp_arith
     step = Step(args, rank, world, dev)
+    global GATHERED_TUPLES
+    GATHERED_TUPLES = step.gather
+    if GATHERED_TUPLES:
+        STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_kernel"
     step.run()                      # part of the untimed setup: allocator pools of both streams, GEMM solution table,
     torch.cuda.synchronize()        # kernel attributes -- so that even --warmup 0 times steady-state steps
     for _ in range(args.warmup):
@@ -323,6 +358,16 @@ def main():
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         return float(tmax.item()), evs_
 
+    if os.environ.get("CPPF_BENCH_HOSTTIMES"):
+        torch.cuda.synchronize()
+        for _ in range(4):              # back to back, like the timed loop
+            step.host_times = []
+            step.run()
+            ht = step.host_times + [("returned", time.perf_counter())]
+            print("host enqueue times (ms since step start): " + ", ".join("%s %.3f" % (n_, 1e3 * (t_ - ht[0][1])) for n_, t_ in ht),
+                  file=sys.stderr)
+        torch.cuda.synchronize()
+        step.host_times = None
     dt, evs = timed_loop(args.steps)
     # the other placement of the scale head (see --eager-scale-head), measured the same way right after the headline
     # loop (untimed for the headline): the reference's forward order when the headline uses the kept-pairs-only order
@@ -450,11 +495,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SHOT model, %d scenes/GPU x %d pts x %d tuples x %d rots, "
                                    "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s; "
-                                   "MLP arithmetic: %s"
+                                   "MLP arithmetic: %s; tuple rows %s"
                                    % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only",
                                       "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
                                       "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
-                                      if _models.MLP_ARITH == "split" else "f32-input matrix cores"),
+                                      if _models.MLP_ARITH == "split" else "f32-input matrix cores",
+                                      "gathered inside the first ResLayer's kernel (never written)" if GATHERED_TUPLES
+                                      else "materialised ([T, 360] float32)"),
                        "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
             # the same run with the scale head on every tuple (the reference's forward order), same loop protocol
             "value_reference_order" if not args.eager_scale_head else "value_kept_pairs_order":

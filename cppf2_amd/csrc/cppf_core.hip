@@ -340,6 +340,80 @@ extern "C" int cppf_encode_tuples_shot(int B, const float* pts, const float* nor
   return CPPF_OK;
 }
 
+// The pair-feature block of the tuple rows alone (the first 4 C(k,2) columns of encode_shot_kernel's rows, same
+// arithmetic) plus the tuples' GLOBAL point indices: what cppf_reslayer_split_gather needs to read the per-point
+// descriptors itself instead of having them copied into 1.8 GB of rows.
+template <int KC>
+__global__ __launch_bounds__(256) void encode_shot_heads_kernel(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                                const int32_t* __restrict__ idx, int k_rt,
+                                                                const int32_t* __restrict__ pt_off,
+                                                                const int32_t* __restrict__ tup_off, ComboTable cb,
+                                                                float* __restrict__ heads, int ld,
+                                                                int32_t* __restrict__ gidx) {
+  // thread / tuple: its k points and normals are fetched once (the row kernel fetches them per output float4) and all
+  // C(k,2) pair features leave as one contiguous 16 C(k,2)-byte run
+  const unsigned b = blockIdx.y;
+  const int p0 = pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const int k = KC > 0 ? KC : k_rt;
+  const int np = k * (k - 1) / 2;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned)nt; t += gridDim.x * blockDim.x) {
+    const int64_t row = (int64_t)t0 + t;
+    float p[8][3], n[8][3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < k) {
+        const int g = p0 + idx[row * k + q];
+        gidx[row * k + q] = g;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          p[q][c] = pts[3 * (int64_t)g + c];
+          n[q][c] = nrm[3 * (int64_t)g + c];
+        }
+      }
+    }
+    float* dst = heads + row * ld;
+    // columns [0, 3 np): point differences of the pairs; [3 np, 4 np): |cos| of their normals (encode_scalar's arithmetic)
+    float o[4];
+    for (int f = 0; f < 4 * np; ++f) {
+      float v;
+      if (f < 3 * np) {
+        const int q = f / 3, c = f - 3 * q;
+        v = p[cb.i[q]][c] - p[cb.j[q]][c];
+      } else {
+        const int q = f - 3 * np;
+        const float* ni = n[cb.i[q]];
+        const float* nj = n[cb.j[q]];
+        const float s_ = (ni[0] * nj[0] + ni[1] * nj[1]) + ni[2] * nj[2];
+        v = fmaxf(s_, -s_);
+      }
+      o[f & 3] = v;
+      if ((f & 3) == 3) *reinterpret_cast<float4*>(dst + (f - 3)) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+extern "C" int cppf_encode_tuples_shot_heads(int B, const float* pts, const float* normals, const int32_t* idx, int k,
+                                             const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples,
+                                             float* heads, int32_t ld_heads, int32_t* gidx, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && normals && idx && pt_off && tup_off && heads && gidx);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  const int np = k * (k - 1) / 2;
+  CPPF_CHECK_ARG(ld_heads >= 4 * np && (ld_heads & 3) == 0 && (((uintptr_t)heads) & 15) == 0);
+  if (total_tuples <= 0) return CPPF_OK;
+  int64_t bx = ((total_tuples + B - 1) / B + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  if (k == 5)
+    hipLaunchKernelGGL(encode_shot_heads_kernel<5>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, idx,
+                       k, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
+  else
+    hipLaunchKernelGGL(encode_shot_heads_kernel<0>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, idx,
+                       k, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
 __device__ __forceinline__ void combo_of(int q, int k, int& i, int& j) {
   i = 0;
   int rem = q;

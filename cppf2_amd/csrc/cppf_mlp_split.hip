@@ -39,16 +39,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef RS_PREFETCH_MAX_NT
-#define RS_PREFETCH_MAX_NT 8
-#endif
-// wavefronts per workgroup: 8 (two per SIMD, 256 registers each) for layers up to 192 wide, 4 (one per SIMD, 512 registers:
-// both accumulator sets of a 256-wide layer at once) for 256
+// wavefronts per workgroup: 8 (two per SIMD, 256 registers each) for layers up to 128 wide, 4 (one per SIMD, 512 registers:
+// both accumulator sets of a 192- / 256-wide layer at once) above
 __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
 #define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
 
+// measured variants kept as switches: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more),
+// and the MFMA / filler interleave below (1-3 % over the compiler's own order)
 #ifndef RS_DEEP_PREFETCH
 #define RS_DEEP_PREFETCH 0
 #endif
@@ -254,15 +253,30 @@ __device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, c
 // The x tile of one K step of a wavefront's 32 rows -- lane (r, g): features 16 s + 8 g + (0..7) of row r, 32 bytes --
 // travels global -> LDS by two LDS-DMA instructions (16 bytes per lane each) into one of three 2 KiB slots of the
 // wavefront, three K steps ahead of its use; nothing of it is tracked by the compiler, the waits are counted by hand.
+// GATHER (the tuple inputs of the SHOT model, train_shot.py:75-83, never materialised): features [0, head) of a row come
+// from its block of pair features (xrow, `head` floats per tuple), feature head + fdim j + c from table[gi[j]][c] -- the
+// per-point descriptor of the tuple's j-th point; 8 consecutive features never straddle two sources (head, fdim % 8 == 0).
+template <bool GATHER>
 struct RsX {
-  const float* xrow;           // this lane's row
+  const float* xrow;           // this lane's row (GATHER: its head block)
   char* slots;                 // the wavefront's three slots in LDS
   int k_in, g, lane;
+  const float* table;          // GATHER: [points, fdim] descriptors, the row's point indices, head width, log2(fdim)
+  int gi[8];
+  int head, fshift;
 
+  __device__ __forceinline__ const float* source(int f) const {
+    if (!GATHER || f < head) return xrow + f;
+    const int j = (f - head) >> fshift, c = (f - head) & ((1 << fshift) - 1);
+    int p = gi[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) p = (j == q) ? gi[q] : p;
+    return table + ((int64_t)p << fshift) + c;
+  }
   __device__ __forceinline__ void issue(int s, int slot) const {        // always exactly two vector-memory operations
     int f = 16 * s + 8 * g;
     if (f + 8 > k_in) f = 0;                     // past the end (or the zero tail): any valid address, the value is masked
-    const float* src = xrow + f;
+    const float* src = source(f);
     char* dst = slots + slot * 2048;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -283,8 +297,8 @@ struct RsX {
 // weight pieces.  Step s: wait for tile s + 1 (two tiles younger: vmcnt(4) before, vmcnt(2) after the issue of tile
 // s + 3 -- the wait comes first), read it, issue tile s + 3 into the slot tile s left, split tile s + 1 in the shadow of
 // step s's MFMAs.
-template <int NTILES, bool PREFETCH, class Stream>
-__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const RsX& xs, int ks1, Stream& ws) {
+template <int NTILES, bool PREFETCH, class X, class Stream>
+__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X& xs, int ks1, Stream& ws) {
   constexpr int SPC = rs_spc(NTILES);
   float xv[8];
   RS_WAIT(4, 15);                                    // tile 0 has landed (tiles 1, 2 may be in flight)
@@ -319,7 +333,7 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const RsX& x
 // dst[u] (u < NTILES) += W[tile u] src^T where src is NS accumulator tiles of this lane's row (the output of a previous
 // product): step (t, sp) contracts over the lane's registers 8 sp .. 8 sp + 7 of src tile t -- the weights are packed in
 // that feature order.  The split of step + 1 runs in the shadow of step's MFMAs (pinned there, which also keeps CSE from
-// carrying the split of one output half over to the next at 24 registers per tile).
+// keeping a once-computed split alive across products at 24 registers per tile).
 template <int NS, int NTILES, bool PREFETCH, class Stream>
 __device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16 (&src)[NS], Stream& ws) {
   constexpr int SPC = rs_spc(NTILES);
@@ -355,12 +369,19 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
   }
 }
 
-template <int NT, bool PROJ>
+struct RsGather {               // GATHER launches: see RsX
+  const int32_t* gidx;          // [rows, slots] global point indices
+  const float* table;           // [points, 1 << fshift]
+  int slots, head, fshift;
+};
+
+template <int NT, bool PROJ, bool GATHER>
 __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                               int64_t ldo, int64_t rows,
                                                                               const char* __restrict__ wq,
                                                                               const float* __restrict__ b1,
-                                                                              const float* __restrict__ b0, int chain) {
+                                                                              const float* __restrict__ b0, int chain,
+                                                                              RsGather ga) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
@@ -399,22 +420,36 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     return x + (row < rows ? row : rows - 1) * ldx;
   };
-  RsX xs;
+  RsX<GATHER> xs;
   xs.slots = s_ring + 2 * RS_STAGE_BYTES + wave * (3 * 2048);
   xs.k_in = k_in;
   xs.g = g;
   xs.lane = lane;
+  xs.table = ga.table;
+  xs.head = ga.head;
+  xs.fshift = ga.fshift;
+  int gnext[8];                                   // GATHER: the point indices of this lane's row in the NEXT row block
+  auto load_indices = [&](int64_t blk, int (&dst)[8]) {
+    const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
+    const int32_t* p = ga.gidx + (row < rows ? row : rows - 1) * ga.slots;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = q < ga.slots ? p[q] : 0;
+  };
   auto first_tiles = [&](const float* rowp) {     // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
     xs.xrow = rowp;
     xs.issue(0, 0);
     xs.issue(1, 1);
     xs.issue(2, 2);
   };
-  if (blockIdx.x < nblocks) first_tiles(row_ptr(blockIdx.x));
+  if (blockIdx.x < nblocks) {
+    if (GATHER) load_indices(blockIdx.x, xs.gi);
+    first_tiles(row_ptr(blockIdx.x));
+  }
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
     const float* xrow = row_ptr(blk);
+    if (GATHER && blk + gridDim.x < nblocks) load_indices(blk + gridDim.x, gnext);      // used after the first product
     // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a projection layer] ----------------------------
     f32x16 acc[2 * NT];                         // h tiles, then the output tiles
     f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
@@ -440,7 +475,13 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
-    if (blk + gridDim.x < nblocks) first_tiles(row_ptr(blk + gridDim.x));
+    if (blk + gridDim.x < nblocks) {
+      if (GATHER) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xs.gi[q] = gnext[q];
+      }
+      first_tiles(row_ptr(blk + gridDim.x));
+    }
     // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
     rs_product_h<NT, NT, PF>(o, h, ws);
     // ---- the identity layers chained behind (same width): y <- y + relu(y W1^T + b1) W2^T with y = the output tiles,
@@ -479,9 +520,9 @@ extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out,
   return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * RS_TILE_BYTES;
 }
 
-template <int NT, bool PROJ>
+template <int NT, bool PROJ, bool GATHER = false>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
-                     const float* b1, const float* b0, int chain, int cus, hipStream_t stream) {
+                     const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather()) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -494,13 +535,13 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
     CPPF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev & 63]) {
-      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
+      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev & 63] = true;
     }
   }
-  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx, k_in, out, ldo,
-                     rows, wq, b1, b0, chain);
+  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx, k_in, out,
+                     ldo, rows, wq, b1, b0, chain, ga);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
@@ -549,4 +590,41 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
     default: return proj ? rs_launch<8, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
                          : rs_launch<8, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
   }
+}
+
+// The first ResLayer of the SHOT model's tuple encoder fed by the tuple encode itself (train_shot.py:75-83 never materialised):
+// row t of the layer's input is [heads[t, 0:head_cols] | table[gidx[t, 0]] | ... | table[gidx[t, slots-1]]], i.e. k_in =
+// head_cols + slots * fdim columns, gathered by the kernel's x-tile fetches.  heads float32 [rows, >= head_cols] with row
+// stride ld_heads (cppf_encode_tuples_shot_heads writes it, with gidx int32 [rows, slots] = scene base + tuple index);
+// table float32 [points, fdim], fdim a power of two >= 8, head_cols % 8 == 0, slots <= 8.  Everything else as
+// cppf_reslayer_split (a projection layer, n_out = 128; `chain` identity layers behind it); the results are bit-identical
+// to cppf_reslayer_split on the materialised rows.
+extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx,
+                                          int32_t slots, const float* table, int32_t fdim, float* out, int64_t ldo,
+                                          int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
+                                          const float* b0, int32_t chain, void* stream) {
+  CPPF_CHECK_ARG(heads && gidx && table && out && wq && b1 && b0 && rows >= 0);
+  CPPF_CHECK_ARG(head_cols >= 0 && (head_cols & 7) == 0 && ld_heads >= head_cols && (ld_heads & 3) == 0);
+  CPPF_CHECK_ARG(slots >= 1 && slots <= 8 && fdim >= 8 && (fdim & (fdim - 1)) == 0);
+  CPPF_CHECK_ARG((ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
+  CPPF_CHECK_ARG((((uintptr_t)heads | (uintptr_t)table | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
+  const int k_in = head_cols + slots * fdim;
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, 1, chain));
+  if (n_out != 128) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_reslayer_split_gather: n_out = %d (only the 128-wide projection layer of the "
+             "tuple encoder has a gathering kernel)", n_out);
+    return CPPF_EUNSUPPORTED;
+  }
+  if (rows == 0) return CPPF_OK;
+  int dev = 0, n_cu = 0;
+  CPPF_HIP(hipGetDevice(&dev));
+  CPPF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  RsGather ga;
+  ga.gidx = gidx;
+  ga.table = table;
+  ga.slots = slots;
+  ga.head = head_cols;
+  ga.fshift = __builtin_ctz((unsigned)fdim);
+  return rs_launch<4, true, true>(heads, ld_heads, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
+                                  n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga);
 }

@@ -115,7 +115,7 @@ def _fused_plan(seq):
     return plan, c
 
 
-def fused_stack(seq, x, keep_input=False):
+def fused_stack(seq, x, keep_input=False, gather=None):
     """Inference-only execution of a stack of ResLayers with the elementwise work folded into GEMM epilogues
     (same fp32 math, fewer passes over the [T, C] activations, which are 1.3 M rows at bench size):
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
@@ -128,9 +128,27 @@ def fused_stack(seq, x, keep_input=False):
     next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
     models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`
     unless keep_input is set.
-    The folded biases depend on the weights only and are computed once per weight version (_fused_plan)."""
+    The folded biases depend on the weights only and are computed once per weight version (_fused_plan).
+    gather = (heads [T, H], gidx int32 [T, k], table [points, F]) instead of x: the rows [heads | table[gidx[:, 0]] | ...] are
+    read by the first layer's kernel itself (ops.reslayer_split_gather; split arithmetic, 128-wide projection first layer)."""
     plan, c = _fused_plan(seq)
     li = 0
+    if gather is not None:
+        heads, gidx, table = gather
+        entry = plan[0]
+        w1t, b1, w0t, b0, w2t = entry[:5]
+        k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
+        assert MLP_ARITH == "split" and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
+        chain = 0
+        while (1 + chain < len(plan) and plan[1 + chain][2] is None and chain < 15 and plan[1 + chain][0].shape == (128, 128)):
+            chain += 1
+        key = (k_in, chain)
+        if entry[5] is None or entry[5][0] != key:
+            rest = plan[1:1 + chain]
+            wq = pack_split(w1t.t(), w0t.t(), w2t.t(), k_in, chain=[(e[0].t(), e[4].t()) for e in rest])
+            entry[5] = (key, wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
+        x = ops.reslayer_split_gather(heads, gidx, table, entry[5][1], entry[5][2], b0, 128, chain=chain)
+        li = 1 + chain
     while li < len(plan):
         entry = plan[li]
         w1t, b1, w0t, b0, w2t = entry[:5]
@@ -235,6 +253,30 @@ class BeyondCPPFShot(nn.Module):
         preds_scale = self.scale_encoder(feat)
         preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
         return preds_cls, preds_scale
+
+    def gather_supported(self, feat_dim, k):
+        """True when heads_from_tuples can feed the tuple encoder without materialising its input rows."""
+        first = self.tuple_encoder[0]
+        return (MLP_ARITH == "split" and not torch.is_grad_enabled() and first.fc0 is not None and first.fc1.out_features == 128
+                and feat_dim >= 8 and feat_dim & (feat_dim - 1) == 0 and (k * (k - 1) // 2 * 4) % 8 == 0 and k <= 8
+                and first.fc1.in_features == k * (k - 1) // 2 * 4 + k * feat_dim)
+
+    def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False):
+        """heads(prepare_tuple_inputs(...)) with the [T, 360] tuple rows never written: the pair features (40 columns) and the
+        tuples' global point indices go to the first ResLayer's kernel, which reads the per-point descriptors `feat` itself
+        (same values, same arithmetic, bit-identical logits).  Falls back to the materialised rows when the first layer has
+        no gathering kernel (other widths, training, native arithmetic)."""
+        idx = point_idxs_all.to(torch.int32)
+        if not (points.is_cuda and self.gather_supported(feat.shape[1], idx.shape[1])):
+            return self.heads(ops.encode_tuples_shot(points, idx, feat, normal, pt_off, tup_off), lazy_scale=lazy_scale)
+        heads, gidx = ops.encode_tuples_shot_heads(points, idx, normal, pt_off, tup_off)
+        feat = fused_stack(self.tuple_encoder, None, gather=(heads, gidx, feat.contiguous()))
+        if lazy_scale:
+            preds_cls = fused_stack(self.logit_encoder, feat, keep_input=True)
+            return preds_cls.reshape(feat.shape[0], 6, -1), feat
+        preds_scale = fused_stack(self.scale_encoder, feat)
+        preds_cls = fused_stack(self.logit_encoder, feat)
+        return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
 
     def scale_head(self, feat_rows):
         """scale_encoder on a subset of tuple features (rows of the `feat` heads(lazy_scale=True) returned)."""

@@ -290,6 +290,44 @@ def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0):
     return out
 
 
+def encode_tuples_shot_heads(points, point_idxs_all, normal, pt_off=None, tup_off=None):
+    """The pair-feature block of prepare_tuple_inputs (train_shot.py:75-81: the first 4 C(k,2) columns of
+    encode_tuples_shot's rows, bit for bit) and the tuples' global point indices: (heads float32 [T, 4 C(k,2)], gidx int32
+    [T, k]) -- the inputs of reslayer_split_gather, which reads the per-point descriptors itself."""
+    dev = _dev()
+    pts = _t(points, torch.float32, dev)
+    nrm = _t(normal, torch.float32, dev)
+    idx = _t(point_idxs_all, torch.int32, dev)
+    T, k = idx.shape
+    B = 1 if pt_off is None else pt_off.numel() - 1
+    if pt_off is None:
+        pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    ncol = k * (k - 1) // 2 * 4
+    heads = torch.empty((T, ncol), dtype=torch.float32, device=dev)
+    gidx = torch.empty((T, k), dtype=torch.int32, device=dev)
+    _lib.check(_L.cppf_encode_tuples_shot_heads(B, _p(pts), _p(nrm), _p(idx), k, _p(pt_off), _p(tup_off), T, _p(heads), ncol,
+                                                _p(gidx), _stream()), "cppf_encode_tuples_shot_heads")
+    return heads, gidx
+
+
+def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
+    """The first ResLayer of the tuple encoder (+ `chain` identity layers) on rows [heads | table[gidx[:, 0]] | ... ] that
+    are gathered by the kernel instead of being materialised (cppf_reslayer_split_gather); same arithmetic and results as
+    reslayer_split on encode_tuples_shot's rows.  Returns float32 [T, n_out]."""
+    assert heads.is_cuda and heads.dtype == torch.float32 and heads.dim() == 2 and heads.stride(1) == 1
+    assert gidx.dtype == torch.int32 and gidx.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
+    rows = heads.shape[0]
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=heads.device)
+    b1 = b1.contiguous()
+    b0 = b0.contiguous()
+    assert b1.numel() == (1 + chain) * n_out
+    _lib.check(_L.cppf_reslayer_split_gather(_p(heads), heads.stride(0), heads.shape[1], _p(gidx), gidx.shape[1], _p(table),
+                                             table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
+                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+               "cppf_reslayer_split_gather")
+    return out
+
+
 def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=None):
     """Coordinate part of the DINO model's prepare_tuple_inputs (train_dino.py:92): [T, C(k,2)*3]
     (written into the leading columns of `out` if given)."""

@@ -128,8 +128,8 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
             x = dino_model.prepare_tuple_inputs(pts, desc, idx + base[:, None].to(torch.int32))
             pred_cls, pred_scales = dino_model.heads(x)
         else:
-            x = ops.encode_tuples_shot(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off)
-            pred_cls, pred_scales = shot_model.heads(x)
+            # train_shot.py:75-83 + :100-111; the tuple rows are gathered inside the first ResLayer's kernel
+            pred_cls, pred_scales = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off)
         raw_cls = pred_cls
         if prior is not None:
             pred_cls = pred_cls + prior

@@ -330,6 +330,23 @@ int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t pr
 int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                         const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, void* stream);
 
+/* ---- the tuple encode feeding the tuple MLP without materialising its rows (train_shot.py:75-83 -> :100-111): the pair
+ * features alone and the tuples' global point indices ...
+ *   heads float32 [T, ld_heads >= 4 C(k,2)]: the first 4 C(k,2) columns of cppf_encode_tuples_shot's rows, bit for bit;
+ *   gidx  int32 [T, k] = scene point base + idx
+ * ... and the first ResLayer of the tuple encoder (a 128-wide projection layer, `chain` identity layers behind it) reading
+ * row t = [heads[t, 0:head_cols] | table[gidx[t, 0]] | ... | table[gidx[t, slots-1]]] through its x-tile fetches: table
+ * float32 [points, fdim] (the point encoder's output), fdim a power of two >= 8, head_cols % 8 == 0, slots <= 8; wq / b1 /
+ * b0 / chain as cppf_reslayer_split for k_in = head_cols + slots * fdim.  Bit-identical to cppf_reslayer_split on the
+ * materialised rows; saves writing and re-reading them (1.8 GB per 64 scenes). */
+int cppf_encode_tuples_shot_heads(int B, const float* pts, const float* normals, const int32_t* idx, int k,
+                                  const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, float* heads,
+                                  int32_t ld_heads, int32_t* gidx, void* stream);
+int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
+                               const float* table, int32_t fdim, float* out, int64_t ldo, int32_t n_out, int64_t rows,
+                               const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,3 +217,43 @@ def test_models_split_arithmetic_matches_native_and_module_forward():
             assert got.shape == want.shape
             assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), mode
         assert (shot.scale_head(feat_l) - ref[1]).abs().max().item() < 2e-5
+
+
+@pytest.mark.gpu
+def test_gathered_first_layer_is_bit_identical_to_the_materialised_rows():
+    """cppf_encode_tuples_shot_heads + cppf_reslayer_split_gather (the tuple rows of train_shot.py:75-83 never written)
+    against cppf_encode_tuples_shot + cppf_reslayer_split: same logits bit for bit, on a ragged batch."""
+    from cppf2_amd import models, ops
+    from cppf2_amd.config import load_config
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    Ns, Ts = [300, 77, 512], [1000, 33, 2049]
+    pts = torch.randn(sum(Ns), 3, device=dev)
+    nrm = torch.nn.functional.normalize(torch.randn(sum(Ns), 3, device=dev), dim=-1)
+    feat = torch.randn(sum(Ns), 64, device=dev)
+    idx = torch.cat([torch.randint(0, n, (t, 5), device=dev, dtype=torch.int32) for n, t in zip(Ns, Ts)])
+    pt_off, tup_off = ops._offsets(Ns, dev), ops._offsets(Ts, dev)
+    rows = ops.encode_tuples_shot(pts, idx, feat, nrm, pt_off, tup_off)
+    heads, gidx = ops.encode_tuples_shot_heads(pts, idx, nrm, pt_off, tup_off)
+    assert torch.equal(heads, rows[:, :40])
+    base = torch.repeat_interleave(pt_off[:-1].long(), torch.tensor(Ts, device=dev))
+    assert torch.equal(gidx.long(), idx.long() + base[:, None])
+    for j in range(5):
+        assert torch.equal(feat[gidx[:, j].long()], rows[:, 40 + 64 * j:104 + 64 * j])
+    net = models.BeyondCPPFShot(load_config("config", "config", ["category=bottle"])).to(dev).eval()
+    prev = models.MLP_ARITH
+    try:
+        models.MLP_ARITH = "split"
+        with torch.no_grad():
+            assert net.gather_supported(64, 5)
+            cls_a, sc_a = net.heads(rows.clone())
+            cls_b, sc_b = net.heads_from_tuples(pts, idx, feat, nrm, pt_off, tup_off)
+            assert torch.equal(cls_a, cls_b) and torch.equal(sc_a, sc_b)
+            cls_c, feat_c = net.heads_from_tuples(pts, idx, feat, nrm, pt_off, tup_off, lazy_scale=True)
+            assert torch.equal(cls_c, cls_a) and torch.equal(net.scale_head(feat_c), sc_a)
+            models.MLP_ARITH = "native"                      # no gathering kernel there: falls back to the materialised rows
+            assert not net.gather_supported(64, 5)
+            cls_n, _ = net.heads_from_tuples(pts, idx, feat, nrm, pt_off, tup_off)
+            assert (cls_n - cls_a).abs().max().item() < 2e-5 * max(1.0, cls_a.abs().max().item())
+    finally:
+        models.MLP_ARITH = prev
