@@ -256,7 +256,9 @@ def pmc_traffic(stage):
     try:
         cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
         with open(os.path.join(ROOT, "profiles", cands[-1])) as f:       # the latest round's passes
-            d = json.load(f).get(STAGE_KERNEL.get(stage, ""), None)
+            table = json.load(f)
+        name = STAGE_KERNEL.get(stage, "")
+        d = table.get(name) or next((v for k_, v in sorted(table.items()) if name and k_.startswith(name)), None)
         if not d:
             return None
         return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
@@ -265,7 +267,7 @@ def pmc_traffic(stage):
 
 
 def pmc_traffic_mlp():
-    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 3, point encoder 2, scale head 2) from the same
+    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 4, point encoder 2, scale head 2) from the same
     committed passes; None if absent."""
     try:
         cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
@@ -403,7 +405,10 @@ def main():
         # the rotation-vote stage shares the chip with the PyTorch scale head running on a side stream, so its event time
         # is not the kernel's own (0.26 ms alone, profiles/): the dominant kernel is picked among the stages that run alone
         shared = set() if args.eager_scale_head else {"rot_bins"}
-        dominant = max([s for s in hip_stages if s not in shared], key=lambda s: stage_ms.get(s, 0.0))
+        # the HBM roofline object describes the longest of the kernels that ARE bandwidth-bound (section 4 of DESIGN.md); the
+        # voting and descriptor kernels (VALU / LDS bound) have their fractions in per_kernel
+        hbm_bound = ("decode_bins", "encode_tuples", "sample_tuples")
+        dominant = max([s for s in hbm_bound if s not in shared], key=lambda s: stage_ms.get(s, 0.0))
         rows = []
         per_kernel = {}
         for s in Step.STAGES:
@@ -440,7 +445,7 @@ def main():
                         per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         if _models.MLP_ARITH == "split":
-            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 3 launches back to back: the stage
+            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 4 launches back to back: the stage
             # time is their sum): matrix-core bound.  `achieved` = the bf16 MFMA work it executes (6 exact-product MFMAs per
             # float32 product, K padded to 16) over the stage's HIP-event time, against the dense bf16 peak; the
             # float32-equivalent rate (2 M K N of the layers) is next to it.  The HBM-bound kernel's roofline stays under "hbm".
@@ -455,7 +460,7 @@ def main():
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
-                            launch_ms=mlp_ms_, launches=3,
+                            launch_ms=mlp_ms_, launches=4,
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = 6 bf16 "
