@@ -171,26 +171,33 @@ class Step:
         feat = self.model.encode_points(shot)
         self._mark("shot_encoder")
         eager = self.eager
+        from cppf2_amd.models import decode_supported, fused_stack
+        u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
+        drawn = False
         if self.gather:
             # train_shot.py:75-83 without its 1.8 GB of rows: pair features + global indices, the first ResLayer gathers
             heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
             self._mark("encode_tuples")
-            from cppf2_amd.models import fused_stack
             tf = fused_stack(self.model.tuple_encoder, None, gather=(heads, gidx, feat))
             if eager:
-                scales = fused_stack(self.model.scale_encoder, tf)
-                logits = fused_stack(self.model.logit_encoder, tf).reshape(tf.shape[0], 6, -1)
-                feat = scales
+                feat = fused_stack(self.model.scale_encoder, tf)         # the scale head on every tuple
+            drawn = decode_supported(self.model.logit_encoder, tf)
+            if drawn:
+                # eval.py:225-229 as the epilogue of the logit head's output layer: the logits are never written
+                fused_stack(self.model.logit_encoder, tf, keep_input=not eager, decode=(u, self.prior, pipe.bins))
             else:
-                logits = fused_stack(self.model.logit_encoder, tf, keep_input=True).reshape(tf.shape[0], 6, -1)
+                logits = fused_stack(self.model.logit_encoder, tf, keep_input=not eager).reshape(tf.shape[0], 6, -1)
+            if not eager:
                 feat = tf
         else:
             x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
             self._mark("encode_tuples")
             logits, feat = self.model.heads(x, lazy_scale=not eager)
         self._mark("tuple_mlp")
-        u = ops.philox_uniform(T, 6, a.seed, 1, tuple(range(self.scene0, self.scene0 + B)), self.dev)
-        pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
+        if drawn:
+            pipe.decode_from_bins(self.pts, idx)
+        else:
+            pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
         self._mark("decode_bins")
         pipe.vote_center(self.pts, idx, phase=1)      # scene bounds + per-pair circle frames
         self._mark("vote_frames")
@@ -222,12 +229,15 @@ class Step:
 
 
 GATHERED_TUPLES = False         # set by main(): the encode stage writes pair features + indices only
+FUSED_DRAW = False              # set by main(): the bins are drawn inside the MLP's output layer, the decode stage starts from them
 
 
 def algorithmic_bytes(stage, B, N, T, R, S, G):
     """Compulsory bytes one launch of the stage's kernel moves for B scenes (SURVEY.md 8d per-scene figures)."""
     if stage == "encode_tuples" and GATHERED_TUPLES:
         return (T * 5 * 4 + N * 12 + N * 12 + T * 40 * 4 + T * 5 * 4) * B
+    if stage == "decode_bins" and FUSED_DRAW:
+        return (T * 6 * 4 + T * 8 + N * 12 + T * (12 + 24 + 4 + 24)) * B
     per_scene = {
         "sample_tuples": T * 5 * 4,
         "shot_frames": N * 12 * 2 + N * 12 + N * 19 * 8 * 2 + N * 56,   # points in+sorted, normals out, sums w+r, frames
@@ -332,10 +342,15 @@ def main():
     if args.mlp_arith:
         _models.MLP_ARITH = args.mlp_arith
     step = Step(args, rank, world, dev)
-    global GATHERED_TUPLES
-    GATHERED_TUPLES = step.gather
-    if GATHERED_TUPLES:
-        STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_kernel"
+    global GATHERED_TUPLES, FUSED_DRAW
+    with torch.no_grad():           # the support checks look at the inference mode Step.run() executes in
+        GATHERED_TUPLES = step.gather
+        if GATHERED_TUPLES:
+            STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_kernel"
+            from cppf2_amd.models import decode_supported
+            FUSED_DRAW = decode_supported(step.model.logit_encoder, torch.empty((1, 256), device=dev))
+            if FUSED_DRAW:
+                STAGE_KERNEL["decode_bins"] = "decode_targets_kernel"
     step.run()                      # part of the untimed setup: allocator pools of both streams, GEMM solution table,
     torch.cuda.synchronize()        # kernel attributes -- so that even --warmup 0 times steady-state steps
     for _ in range(args.warmup):
@@ -508,8 +523,10 @@ def main():
                                       "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
                                       "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
                                       if _models.MLP_ARITH == "split" else "f32-input matrix cores",
-                                      "gathered inside the first ResLayer's kernel (never written)" if GATHERED_TUPLES
-                                      else "materialised ([T, 360] float32)"),
+                                      ("gathered inside the first ResLayer's kernel (never written)" if GATHERED_TUPLES
+                                       else "materialised ([T, 360] float32)")
+                                      + ("; bins drawn in the epilogue of the logit head's output layer (logits never written)"
+                                         if FUSED_DRAW else "")),
                        "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
             # the same run with the scale head on every tuple (the reference's forward order), same loop protocol
             "value_reference_order" if not args.eager_scale_head else "value_kept_pairs_order":

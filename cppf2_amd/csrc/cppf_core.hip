@@ -606,6 +606,57 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
   }
 }
 
+// The second half of decode_bins_kernel alone: vote parameters of every tuple from already drawn bins (the first half runs as
+// the epilogue of the MLP's output layer: cppf_reslayer_split_decode)
+__global__ __launch_bounds__(256) void decode_targets_kernel(int B, const int32_t* __restrict__ bins, int nb,
+                                                             const float* __restrict__ pts, const int32_t* __restrict__ idx, int k,
+                                                             const int32_t* __restrict__ pt_off,
+                                                             const int32_t* __restrict__ tup_off, int64_t total, Axes9 axes,
+                                                             float* __restrict__ scaled, float* __restrict__ scale_out,
+                                                             float* __restrict__ tr, float* __restrict__ rot) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = find_scene(tup_off, B, t);
+  const int p0 = pt_off[b];
+  const int i0 = idx[t * k + 0], i1 = idx[t * k + 1];
+  float pr[6];
+  const float den = (float)(nb - 1);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) pr[c] = (float)bins[t * 6 + c] / den - 0.5f;                 // eval.py:230
+  const float* pa = pts + 3 * (int64_t)(p0 + i0);
+  const float* pb = pts + 3 * (int64_t)(p0 + i1);
+  const float rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
+  const float real_len = __builtin_sqrtf((rx * rx + ry * ry) + rz * rz);                   // eval.py:233 (un-fused f32)
+  const float pred_len = norm3_fused(pr[3] - pr[0], pr[4] - pr[1], pr[5] - pr[2]);        // eval.py:234
+  const float sc = real_len / fmaxf(pred_len, 1e-7f);
+  float ps[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) ps[c] = pr[c] * sc;                                          // eval.py:235
+  if (scale_out) scale_out[t] = sc;
+  if (scaled) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) scaled[t * 6 + c] = ps[c];
+  }
+  float tr2[2], rot3[3];
+  target_pair(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], 0.0, 0.0, 0.0, axes.a, tr2, rot3);
+  if (tr) { tr[t * 2 + 0] = tr2[0]; tr[t * 2 + 1] = tr2[1]; }
+  if (rot) { rot[t * 3 + 0] = rot3[0]; rot[t * 3 + 1] = rot3[1]; rot[t * 3 + 2] = rot3[2]; }
+}
+
+extern "C" int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
+                                     const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
+                                     float* scaled, float* scale, float* tr, float* rot, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && bins && pts && idx && pt_off && tup_off && h_axes);
+  CPPF_CHECK_ARG(nb >= 2 && nb <= DEC_MAX_NB && k >= 2 && k <= 8);
+  if (total_tuples <= 0) return CPPF_OK;
+  Axes9 ax;
+  for (int i = 0; i < 9; ++i) ax.a[i] = h_axes[i];
+  hipLaunchKernelGGL(decode_targets_kernel, dim3((unsigned)((total_tuples + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B,
+                     bins, nb, pts, idx, k, pt_off, tup_off, total_tuples, ax, scaled, scale, tr, rot);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
 extern "C" int cppf_decode_bins(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms, const float* pts,
                                 const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                                 int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,

@@ -369,19 +369,94 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
   }
 }
 
+// The bin draw of eval.py:225-229 as the epilogue of the logit head's output layer (6 coordinates x 32 bins = the 6 output
+// tiles): tile u holds the logits of coordinate u of this lane's row, registers e <-> bins (e & 3) + 8 (e >> 2) + 4 g, the other
+// 16 bins sit in lane ^ 32.  Same arithmetic as decode_bins_kernel<32> (cppf_core.hip), bit for bit: logits (+ prior), max,
+// expf, a float32 running sum IN BIN ORDER -- so the running total alternates between the two lanes every four bins --
+// target = uniform * total, bin = #{cdf <= target} capped at 31.  The six coordinates' chains are independent and interleave.
+struct RsDecode {
+  const float* prior;           // [rows, 192] additive logit prior or NULL
+  const float* uniforms;        // [rows, 6]
+  int32_t* bins;                // [rows, 6] out
+};
+
+template <int NT>
+__device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDecode& dc, int64_t row, bool in, int g) {
+  static_assert(NT == 6, "6 coordinates x 32 bins");
+  if (dc.prior) {
+    const float* pr = dc.prior + row * 192 + 4 * g;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pr + 32 * u + 8 * q);
+        o[u][4 * q + 0] += v.x; o[u][4 * q + 1] += v.y; o[u][4 * q + 2] += v.z; o[u][4 * q + 3] += v.w;
+      }
+    }
+  }
+  float back[6], tot[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+    float m = o[u][0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) m = fmaxf(m, o[u][e]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[u][e] = expf(o[u][e] - m);
+    back[u] = 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float ta[6][4], tb[6][4], fwd[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {                // lanes g = 0: bins 8 q .. 8 q + 3 continue the total the partner sent back
+      ta[u][0] = back[u] + o[u][4 * q + 0];
+      ta[u][1] = ta[u][0] + o[u][4 * q + 1];
+      ta[u][2] = ta[u][1] + o[u][4 * q + 2];
+      ta[u][3] = ta[u][2] + o[u][4 * q + 3];
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) fwd[u] = __shfl_xor(ta[u][3], 32);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {                // lanes g = 1: bins 8 q + 4 .. 8 q + 7 continue from there
+      tb[u][0] = fwd[u] + o[u][4 * q + 0];
+      tb[u][1] = tb[u][0] + o[u][4 * q + 1];
+      tb[u][2] = tb[u][1] + o[u][4 * q + 2];
+      tb[u][3] = tb[u][2] + o[u][4 * q + 3];
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      back[u] = __shfl_xor(tb[u][3], 32);
+      tot[u] = g ? tb[u][3] : back[u];           // after q = 3: the total, on both lanes
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[u][4 * q + i] = g ? tb[u][i] : ta[u][i];   // this lane's CDF values
+    }
+  }
+  const float* ur = dc.uniforms + row * 6;
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+    const float target = ur[u] * tot[u];
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cnt += (o[u][e] <= target) ? 1 : 0;
+    cnt += __shfl_xor(cnt, 32);
+    if (in && g == 0) dc.bins[row * 6 + u] = cnt < 31 ? cnt : 31;
+  }
+}
+
 struct RsGather {               // GATHER launches: see RsX
   const int32_t* gidx;          // [rows, slots] global point indices
   const float* table;           // [points, 1 << fshift]
   int slots, head, fshift;
 };
 
-template <int NT, bool PROJ, bool GATHER>
+template <int NT, bool PROJ, bool GATHER, bool DECODE = false>
 __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                               int64_t ldo, int64_t rows,
                                                                               const char* __restrict__ wq,
                                                                               const float* __restrict__ b1,
                                                                               const float* __restrict__ b0, int chain,
-                                                                              RsGather ga) {
+                                                                              RsGather ga, RsDecode dc) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
@@ -499,7 +574,9 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       }
       rs_product_h<NT, NT, PF>(o, h, ws);
     }
-    if (in) {
+    if (DECODE) {
+      if constexpr (NT == 6) rs_decode_epilogue<NT>(o, dc, in ? row : rows - 1, in, g);
+    } else if (in) {
       float* orow = out + row * ldo + 4 * g;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
@@ -520,9 +597,10 @@ extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out,
   return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * RS_TILE_BYTES;
 }
 
-template <int NT, bool PROJ, bool GATHER = false>
+template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
-                     const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather()) {
+                     const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
+                     RsDecode dc = RsDecode()) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -535,13 +613,13 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
     CPPF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev & 63]) {
-      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER>,
+      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER, DECODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev & 63] = true;
     }
   }
-  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx, k_in, out,
-                     ldo, rows, wq, b1, b0, chain, ga);
+  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx,
+                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
@@ -627,4 +705,28 @@ extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, 
   ga.fshift = __builtin_ctz((unsigned)fdim);
   return rs_launch<4, true, true>(heads, ld_heads, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
                                   n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga);
+}
+
+// The output layer of the logit head (train_shot.py:62-66: a 192-wide projection ResLayer = 6 coordinates x 32 bins) with the
+// bin draw of eval.py:225-229 as its epilogue: bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :] (+ prior[t, c, :])) at
+// uniforms[t, c] -- the same arithmetic as cppf_decode_bins, bit for bit -- so the logits are never written; follow with
+// cppf_decode_from_bins for the vote parameters.  x / wq / b1 / b0 as cppf_reslayer_split with n_out = 192, chain = 0;
+// logit_prior float32 [rows, 192] or NULL, uniforms float32 [rows, 6], bins int32 [rows, 6].
+extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
+                                          const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
+                                          int32_t* bins, void* stream) {
+  CPPF_CHECK_ARG(x && wq && b1 && b0 && uniforms && bins && rows >= 0);
+  CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0);
+  CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)wq | (uintptr_t)logit_prior) & 15) == 0);
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, 192, 1, 0));
+  if (rows == 0) return CPPF_OK;
+  int dev = 0, n_cu = 0;
+  CPPF_HIP(hipGetDevice(&dev));
+  CPPF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  RsDecode dc;
+  dc.prior = logit_prior;
+  dc.uniforms = uniforms;
+  dc.bins = bins;
+  return rs_launch<6, true, false, true>(x, ldx, k_in, nullptr, 192, rows, static_cast<const char*>(wq), b1, b0, 0,
+                                         n_cu > 0 ? n_cu : 256, (hipStream_t)stream, RsGather(), dc);
 }

@@ -115,7 +115,7 @@ def _fused_plan(seq):
     return plan, c
 
 
-def fused_stack(seq, x, keep_input=False, gather=None):
+def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
     """Inference-only execution of a stack of ResLayers with the elementwise work folded into GEMM epilogues
     (same fp32 math, fewer passes over the [T, C] activations, which are 1.3 M rows at bench size):
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
@@ -130,7 +130,10 @@ def fused_stack(seq, x, keep_input=False, gather=None):
     unless keep_input is set.
     The folded biases depend on the weights only and are computed once per weight version (_fused_plan).
     gather = (heads [T, H], gidx int32 [T, k], table [points, F]) instead of x: the rows [heads | table[gidx[:, 0]] | ...] are
-    read by the first layer's kernel itself (ops.reslayer_split_gather; split arithmetic, 128-wide projection first layer)."""
+    read by the first layer's kernel itself (ops.reslayer_split_gather; split arithmetic, 128-wide projection first layer).
+    decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6] | None): the stack's last layer (the logit head's
+    192-wide projection layer) draws the bins in its epilogue instead of writing its logits (ops.reslayer_split_decode); the
+    return value is then the bins.  Use decode_supported(seq, x) first."""
     plan, c = _fused_plan(seq)
     li = 0
     if gather is not None:
@@ -153,6 +156,12 @@ def fused_stack(seq, x, keep_input=False, gather=None):
         entry = plan[li]
         w1t, b1, w0t, b0, w2t = entry[:5]
         n_out = w1t.shape[1]
+        if (decode is not None and li == len(plan) - 1):
+            assert c is None and decode_supported(seq, x), "fused bin draw: see decode_supported"
+            key = (x.shape[1], "decode")
+            if entry[5] is None or entry[5][0] != key:
+                entry[5] = (key, pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
+            return ops.reslayer_split_decode(x, entry[5][1], b1, b0, decode[0], prior=decode[1], bins=decode[2])
         if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.shape[1] >= w1t.shape[0] and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
@@ -193,6 +202,15 @@ def fused_stack(seq, x, keep_input=False, gather=None):
     if c is not None:
         x = x.add_(c)
     return x
+
+
+def decode_supported(seq, x):
+    """True when fused_stack(seq, x, decode=...) can draw the bins inside the stack's last layer: split arithmetic, inference,
+    a 192-wide projection layer (6 x 32 bins) last, preceded by a projection or nothing pending (no carried bias offset)."""
+    last = seq[len(seq) - 1]
+    plan, c = _fused_plan(seq)
+    return (MLP_ARITH == "split" and not torch.is_grad_enabled() and x.is_cuda and last.fc0 is not None
+            and last.fc1.out_features == 192 and last.fc1.in_features % 8 == 0 and c is None)
 
 
 class _EncodeShot(torch.autograd.Function):

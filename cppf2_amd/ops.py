@@ -290,6 +290,26 @@ def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0):
     return out
 
 
+def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
+    """The logit head's output layer (192-wide projection ResLayer) with the bin draw of eval.py:225-229 as its epilogue
+    (cppf_reslayer_split_decode): bins int32 [rows, 6] = what decode_bins draws from these logits (+ prior) at `uniforms`
+    [rows, 6], bit for bit; the logits are never written."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows = x.shape[0]
+    u = uniforms.contiguous()
+    assert u.dtype == torch.float32 and u.numel() == rows * 6
+    if prior is not None:
+        prior = prior.contiguous()
+        assert prior.dtype == torch.float32 and prior.numel() == rows * 192
+    if bins is None:
+        bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
+    assert bins.dtype == torch.int32 and bins.is_contiguous() and bins.numel() == rows * 6
+    _lib.check(_L.cppf_reslayer_split_decode(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
+                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(u), _p(bins), _stream()),
+               "cppf_reslayer_split_decode")
+    return bins
+
+
 def encode_tuples_shot_heads(points, point_idxs_all, normal, pt_off=None, tup_off=None):
     """The pair-feature block of prepare_tuple_inputs (train_shot.py:75-81: the first 4 C(k,2) columns of
     encode_tuples_shot's rows, bit for bit) and the tuples' global point indices: (heads float32 [T, 4 C(k,2)], gidx int32

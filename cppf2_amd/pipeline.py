@@ -100,6 +100,15 @@ class VotingPipeline:
                                        self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
                                        ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")
 
+    def decode_from_bins(self, pts, idx, nb=32):
+        """The vote parameters from bins already drawn into self.bins (by the MLP's output layer:
+        ops.reslayer_split_decode(..., bins=pipe.bins)): the second half of decode()."""
+        self.nb = int(nb)
+        _lib.check(_L.cppf_decode_from_bins(self.B, ops._p(self.bins), self.nb, ops._p(pts), ops._p(idx), self.k,
+                                            ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot, self.axes,
+                                            ops._p(self.scaled), ops._p(self.scale), ops._p(self.tr), ops._p(self.rot),
+                                            ops._stream()), "cppf_decode_from_bins")
+
     def vote_center(self, pts, idx, grid=None, grid_off=None, vote_wt=None, phase=0):
         """phase 0: bounds + frames + votes + argmax in one go.  phase 1: bounds + per-pair frames only;
         phase 2: votes + argmax on the frames left by phase 1 (CPPF_VC_FRAMES_ONLY / _READY, LDS-slab mode)."""

@@ -347,6 +347,19 @@ int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t hea
                                const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
                                void* stream);
 
+/* ---- the bin draw fused into the MLP's output layer (eval.py:225-229 behind train_shot.py:62-66): the 192-wide projection
+ * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]
+ * (+ logit_prior[t, c, :])) at uniforms[t, c]  as its epilogue -- cppf_decode_bins' arithmetic bit for bit -- so that the
+ * logits are never written; cppf_decode_from_bins then computes what the second half of cppf_decode_bins computes (scaled
+ * pair, scale, targets_tr, targets_rot) from the bins.  x / wq / b1 / b0 as cppf_reslayer_split (n_out = 192, chain = 0);
+ * logit_prior float32 [rows, 192] or NULL; uniforms float32 [rows, 6]; bins int32 [rows, 6]. */
+int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
+                               const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
+                               int32_t* bins, void* stream);
+int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
+                          const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
+                          float* scaled, float* scale, float* tr, float* rot, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

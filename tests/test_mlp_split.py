@@ -257,3 +257,42 @@ def test_gathered_first_layer_is_bit_identical_to_the_materialised_rows():
             assert (cls_n - cls_a).abs().max().item() < 2e-5 * max(1.0, cls_a.abs().max().item())
     finally:
         models.MLP_ARITH = prev
+
+
+@pytest.mark.gpu
+def test_bin_draw_fused_into_the_output_layer_equals_decode_bins():
+    """cppf_reslayer_split_decode + cppf_decode_from_bins against cppf_reslayer_split + cppf_decode_bins (eval.py:225-240):
+    the same bins and vote parameters bit for bit, with and without a logit prior, on a ragged batch."""
+    from cppf2_amd import models, ops
+    from cppf2_amd.config import load_config
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    Ns, Ts = [200, 333], [1500, 777]
+    T = sum(Ts)
+    pts = torch.randn(sum(Ns), 3, device=dev) * 0.1
+    idx = torch.cat([torch.randint(0, n, (t, 5), device=dev, dtype=torch.int32) for n, t in zip(Ns, Ts)])
+    net = models.BeyondCPPFShot(load_config("config", "config", ["category=bottle"])).to(dev).eval()
+    feat = torch.randn(T, 256, device=dev)
+    u = torch.rand(T, 6, device=dev)
+    prior = torch.randn(T, 6, 32, device=dev) * 3
+    prev = models.MLP_ARITH
+    try:
+        models.MLP_ARITH = "split"
+        with torch.no_grad():
+            assert models.decode_supported(net.logit_encoder, feat)
+            logits = models.fused_stack(net.logit_encoder, feat, keep_input=True).reshape(T, 6, 32)
+            for pr in (None, prior):
+                a = VotingPipeline(Ns, Ts, num_rots=36)
+                a.decode(pts, idx, logits, u, prior=pr)
+                b = VotingPipeline(Ns, Ts, num_rots=36)
+                bins = models.fused_stack(net.logit_encoder, feat, keep_input=True, decode=(u, pr, b.bins))
+                assert bins.data_ptr() == b.bins.data_ptr()
+                b.decode_from_bins(pts, idx)
+                for name in ("bins", "scaled", "scale", "tr", "rot"):
+                    assert torch.equal(getattr(a, name), getattr(b, name)), name
+            assert len(torch.unique(a.bins)) > 8                      # the draw is not degenerate
+            models.MLP_ARITH = "native"
+            assert not models.decode_supported(net.logit_encoder, feat)
+    finally:
+        models.MLP_ARITH = prev
