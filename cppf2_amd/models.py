@@ -279,22 +279,25 @@ class BeyondCPPFShot(nn.Module):
                 and feat_dim >= 8 and feat_dim & (feat_dim - 1) == 0 and (k * (k - 1) // 2 * 4) % 8 == 0 and k <= 8
                 and first.fc1.in_features == k * (k - 1) // 2 * 4 + k * feat_dim)
 
-    def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False):
+    def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False, decode=None):
         """heads(prepare_tuple_inputs(...)) with the [T, 360] tuple rows never written: the pair features (40 columns) and the
         tuples' global point indices go to the first ResLayer's kernel, which reads the per-point descriptors `feat` itself
         (same values, same arithmetic, bit-identical logits).  Falls back to the materialised rows when the first layer has
-        no gathering kernel (other widths, training, native arithmetic)."""
+        no gathering kernel (other widths, training, native arithmetic).
+        decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6]): the bins of eval.py:225-229 are drawn by the
+        logit head's output layer into `bins` (e.g. VotingPipeline.bins) and None is returned in place of the logits -- only when
+        decode_supported(); otherwise the logits are returned as usual and the caller decodes them."""
         idx = point_idxs_all.to(torch.int32)
         if not (points.is_cuda and self.gather_supported(feat.shape[1], idx.shape[1])):
             return self.heads(ops.encode_tuples_shot(points, idx, feat, normal, pt_off, tup_off), lazy_scale=lazy_scale)
         heads, gidx = ops.encode_tuples_shot_heads(points, idx, normal, pt_off, tup_off)
         feat = fused_stack(self.tuple_encoder, None, gather=(heads, gidx, feat.contiguous()))
-        if lazy_scale:
-            preds_cls = fused_stack(self.logit_encoder, feat, keep_input=True)
-            return preds_cls.reshape(feat.shape[0], 6, -1), feat
-        preds_scale = fused_stack(self.scale_encoder, feat)
-        preds_cls = fused_stack(self.logit_encoder, feat)
-        return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
+        second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
+        if decode is not None and decode_supported(self.logit_encoder, feat):
+            fused_stack(self.logit_encoder, feat, keep_input=lazy_scale, decode=decode)
+            return None, second
+        preds_cls = fused_stack(self.logit_encoder, feat, keep_input=lazy_scale)
+        return preds_cls.reshape(feat.shape[0], 6, -1), second
 
     def scale_head(self, feat_rows):
         """scale_encoder on a subset of tuple features (rows of the `feat` heads(lazy_scale=True) returned)."""
@@ -354,12 +357,16 @@ class BeyondCPPFDino(nn.Module):
         coord = ops.encode_tuples_coord(points, idx)
         return torch.cat([coord, desc_part], -1)
 
-    def heads(self, inputs):
+    def heads(self, inputs, decode=None):
         """(preds_cls [T,6,32], preds_scale [T,3]) from the tuple inputs (train_dino.py:130-132); inference on the GPU
-        runs the stacks with the elementwise work folded into GEMM epilogues (fused_stack), like the SHOT model."""
+        runs the stacks as matrix-core kernels (fused_stack), like the SHOT model.  decode: see
+        BeyondCPPFShot.heads_from_tuples (None is returned in place of the logits when the bins were drawn)."""
         if not torch.is_grad_enabled() and inputs.is_cuda:
             feat = fused_stack(self.tuple_encoder, inputs)
             preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
+            if decode is not None and decode_supported(self.logit_encoder, feat):
+                fused_stack(self.logit_encoder, feat, decode=decode)
+                return None, preds_scale
             preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
             return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
         feat = self.tuple_encoder(inputs)

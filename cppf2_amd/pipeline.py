@@ -219,8 +219,12 @@ class VotingPipeline:
 
     def vote(self, pts, idx, logits, uniforms, pred_scales=None, grid=None, grid_off=None):
         """Everything after the MLP: eval.py:225-313.  All arguments are device tensors in the batch layout.
-        Returns the device tensor of B result records (uint8 [B,160]); use results_to_numpy() to read them."""
-        self.decode(pts, idx, logits, uniforms)
+        Returns the device tensor of B result records (uint8 [B,160]); use results_to_numpy() to read them.
+        logits=None: the bins are already in self.bins (drawn by the MLP's output layer, ops.reslayer_split_decode)."""
+        if logits is None:
+            self.decode_from_bins(pts, idx)
+        else:
+            self.decode(pts, idx, logits, uniforms)
         self.vote_center(pts, idx, grid, grid_off)
         self.backvote(pts, idx)
         self.rot_bins(pts, idx)

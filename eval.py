@@ -123,20 +123,23 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     records, losses, kept = [], [], []
     scale = scale_norm = None
     for model_idx in (0, 1):                                                               # eval.py:219
+        u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
+        # eval.py:225-229 (the bin draw) runs as the epilogue of the logit head's output layer when the kernels allow it (split
+        # arithmetic, no intermediates requested): the heads then return None in place of the logits
+        draw = None if keep else (u, None if prior is None else prior.contiguous(), pipe.bins)
         if model_idx == 0:
             # batched forward: indices are scene-local, tables are concatenated -> add the scene base
             x = dino_model.prepare_tuple_inputs(pts, desc, idx + base[:, None].to(torch.int32))
-            pred_cls, pred_scales = dino_model.heads(x)
+            pred_cls, pred_scales = dino_model.heads(x, decode=draw)
         else:
             # train_shot.py:75-83 + :100-111; the tuple rows are gathered inside the first ResLayer's kernel
-            pred_cls, pred_scales = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off)
+            pred_cls, pred_scales = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off, decode=draw)
         raw_cls = pred_cls
-        if prior is not None:
+        if prior is not None and pred_cls is not None:
             pred_cls = pred_cls + prior
         if scale_prior is not None:
             pred_scales = scale_prior + 1e-3 * pred_scales
-        u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
-        pipe.vote(pts, idx, pred_cls.contiguous(), u, pred_scales.contiguous())
+        pipe.vote(pts, idx, None if pred_cls is None else pred_cls.contiguous(), u, pred_scales.contiguous())
         if opt:
             pipe.refine(pts, idx, up_sym)                                                  # eval.py:319-355
         rec = pipe.results_to_numpy()                                                      # the 160-byte records

@@ -173,3 +173,22 @@ def test_checkpoint_directory_layout(ev, tmp_path):
     rep = ev.main(num_pairs=3000, num_rots=36, num_scenes=1, num_points=512, opt=False, category="mug",
                   ckpt_dir=str(tmp_path), debug=True)
     assert rep["instances"] == 1 and np.all(np.isfinite(np.array(rep["results"][0]["pred_RT"])))
+
+
+def test_run_ensemble_is_the_same_with_the_bin_draw_fused_into_the_mlp(ev):
+    """eval.run_ensemble with keep=False draws the bins inside the logit heads' output layers (and gathers the SHOT model's
+    tuple rows inside its first layer); keep=True goes through the materialised logits: identical records and selection."""
+    from cppf2_amd import synth
+    dev = torch.device("cuda:0")
+    cfg, dino, shot_m = ev.load_category("mug", device=dev)
+    B = 3
+    scenes = [synth.make_scene(3, 40 + s, 1024) for s in range(B)]
+    g = torch.Generator().manual_seed(2)
+    descs = [torch.nn.functional.normalize(torch.randn((1024, 1024), generator=g), dim=-1).numpy() for _ in scenes]
+    prior = ev._teacher_prior(np.concatenate([s["pc_canon"] for s in scenes]), dev)
+    kw = dict(priors=prior, scale_priors=np.stack([s["extent"] for s in scenes]))
+    a = ev.run_ensemble(cfg, dino, shot_m, [s["pc"] for s in scenes], descs, 5, [40, 41, 42], 6000, 72, keep=True, **kw)
+    b = ev.run_ensemble(cfg, dino, shot_m, [s["pc"] for s in scenes], descs, 5, [40, 41, 42], 6000, 72, keep=False, **kw)
+    for m in (0, 1):
+        assert a["records"][m].tobytes() == b["records"][m].tobytes()
+    assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["pick"], b["pick"])
