@@ -134,7 +134,6 @@ class Step:
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         self.all_records = None
         self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
-        self.side = torch.cuda.Stream(device=dev)
         self.eager = bool(args.eager_scale_head)
         self.materialize = bool(getattr(args, "materialize_tuples", False))
         self.host_times = None          # debugging aid: host-side time stamps of the stage boundaries (CPPF_BENCH_HOSTTIMES=1)
@@ -145,20 +144,36 @@ class Step:
         from cppf2_amd import models
         return (not self.materialize) and models.MLP_ARITH == "split" and self.model.gather_supported(64, 5)
 
+    EVENT_SLOTS = 8      # timed steps sampled for the per-stage HIP-event times (events created and first recorded before timing)
+
+    def prepare_events(self):
+        """One set of HIP events per sampled step, created and recorded once OUTSIDE the timed region: creating ~15 timing
+        events per step inside it (round 1-2a) intermittently stalls the host for 30-40 ms a few dozen launches after a device
+        synchronisation on this ROCm -- the chip idles, +1 ms per step averaged over a 30-step loop."""
+        self.ev_pool = []
+        for _ in range(self.EVENT_SLOTS):
+            evs = [(n, torch.cuda.Event(enable_timing=True)) for n in ["start"] + self.STAGES]
+            for _, e in evs:
+                e.record()
+            self.ev_pool.append(evs)
+
     def _mark(self, name):
         if self.host_times is not None:
             self.host_times.append((name, time.perf_counter()))
         if self.ev is not None:
-            e = torch.cuda.Event(enable_timing=True)
+            n, e = self.ev_pool[self.ev_slot][len(self.ev)]
+            assert n == name
             e.record()
-            self.ev.append((name, e))
+            self.ev.append((n, e))
 
     @torch.no_grad()
-    def run(self, timed=False):
+    def run(self, timed=None):
+        """timed = None, or the slot (< EVENT_SLOTS) of the prepared event set this step records its stage boundaries in."""
         from cppf2_amd import shot as shotmod
         ops, pipe, a = self.ops, self.pipe, self.args
         B, N, T = self.B, self.N, self.T
-        self.ev = [] if timed else None
+        self.ev = [] if timed is not None else None
+        self.ev_slot = timed
         self._mark("start")
         idx = ops.sample_tuples(N, T, 5, a.seed, tuple(range(self.scene0, self.scene0 + B)), self.dev)
         self._mark("sample_tuples")
@@ -205,20 +220,16 @@ class Step:
         self._mark("vote_center")
         pipe.backvote(self.pts, idx)
         self._mark("backvote_filter")
+        pipe.rot_bins(self.pts, idx)
+        self._mark("rot_bins")
         if eager:
             scales = feat                                # heads() already ran the scale head on every tuple
         else:
-            # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples),
-            # on a side stream -- it needs the back-vote filter only, like the rotation votes it runs beside
-            cur = torch.cuda.current_stream()
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                rows = pipe.kept_rows()
-                scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
-        pipe.rot_bins(self.pts, idx)
-        self._mark("rot_bins")
-        if not eager:
-            torch.cuda.current_stream().wait_stream(self.side)
+            # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples).
+            # (Round 2a ran it on a second stream beside the rotation votes; with the head as two short matrix-core kernels
+            # the two orders take the same time -- 0.49 ms for both stages -- so it is in stream order: one stream, no waits.)
+            rows = pipe.kept_rows()
+            scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
         self._mark("scale_head")
         pipe.assemble(scales)
         self._mark("assemble_pose")
@@ -351,6 +362,7 @@ def main():
             FUSED_DRAW = decode_supported(step.model.logit_encoder, torch.empty((1, 256), device=dev))
             if FUSED_DRAW:
                 STAGE_KERNEL["decode_bins"] = "decode_targets_kernel"
+    step.prepare_events()
     step.run()                      # part of the untimed setup: allocator pools of both streams, GEMM solution table,
     torch.cuda.synchronize()        # kernel attributes -- so that even --warmup 0 times steady-state steps
     for _ in range(args.warmup):
@@ -362,13 +374,18 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    def timed_loop(k):
+    def timed_loop(k, sample=True):
         """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds."""
+        # per-stage times come from up to EVENT_SLOTS steps spread evenly over the (headline) loop
+        n_s = min(k, Step.EVENT_SLOTS) if sample else 0
+        sampled = {int(round((j + 0.5) * k / n_s - 0.5)): j for j in range(n_s)}
         sync()
         t0 = time.perf_counter()
         evs_ = []
-        for _ in range(k):
-            evs_.append(step.run(timed=True))
+        for i_ in range(k):
+            ev_ = step.run(timed=sampled.get(i_))
+            if ev_ is not None:
+                evs_.append(ev_)
         sync()
         dt_ = time.perf_counter() - t0
         tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
@@ -395,7 +412,7 @@ def main():
     if not args.no_reference_order:
         step.eager = not step.eager
         step.run()
-        dt_other, _ = timed_loop(args.steps)
+        dt_other, _ = timed_loop(args.steps, sample=False)
         step.eager = not step.eager
 
     # the same step with the tuple MLP on the f32-input matrix cores (the arithmetic of rounds 1-2), same loop protocol
@@ -403,9 +420,14 @@ def main():
     if _models.MLP_ARITH == "split" and not args.no_native_arith:
         _models.MLP_ARITH = "native"
         step.run()
-        dt_native, _ = timed_loop(args.steps)
+        dt_native, _ = timed_loop(args.steps, sample=False)
         _models.MLP_ARITH = "split"
 
+    if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
+        for i_, ev in enumerate(evs):
+            row = {n1: round(e0.elapsed_time(e1), 3) for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:])}
+            print("step %d: total %.3f  %s" % (i_, ev[0][1].elapsed_time(ev[-1][1]), {k_: v_ for k_, v_ in row.items() if v_ > 0.2}),
+                  file=sys.stderr)
     # per-stage HIP-event times (ms per launch, averaged over the timed steps) on the stream the kernels ran on
     stage_ms = {}
     for ev in evs:
@@ -422,7 +444,7 @@ def main():
         hip_stages = [s for s in Step.STAGES if s not in mlp_stages and s != "gather"]
         # the rotation-vote stage shares the chip with the PyTorch scale head running on a side stream, so its event time
         # is not the kernel's own (0.26 ms alone, profiles/): the dominant kernel is picked among the stages that run alone
-        shared = set() if args.eager_scale_head else {"rot_bins"}
+        shared = set()
         # the HBM roofline object describes the longest of the kernels that ARE bandwidth-bound (section 4 of DESIGN.md); the
         # voting and descriptor kernels (VALU / LDS bound) have their fractions in per_kernel
         hbm_bound = ("decode_bins", "encode_tuples", "sample_tuples")

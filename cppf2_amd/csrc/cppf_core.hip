@@ -375,6 +375,14 @@ __global__ __launch_bounds__(256) void encode_shot_heads_kernel(const float* __r
     float* dst = heads + row * ld;
     // columns [0, 3 np): point differences of the pairs; [3 np, 4 np): |cos| of their normals (encode_scalar's arithmetic)
     float o[4];
+    if (KC == 0) {                               // runtime k: no register arrays indexed by the pair table (scratch); re-gather
+      for (int f = 0; f < 4 * np; ++f) {
+        o[f & 3] = encode_scalar(pts, nrm, idx + row * k, p0, np, f, cb);
+        if ((f & 3) == 3) *reinterpret_cast<float4*>(dst + (f - 3)) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      continue;
+    }
+#pragma unroll
     for (int f = 0; f < 4 * np; ++f) {
       float v;
       if (f < 3 * np) {

@@ -256,27 +256,33 @@ __device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, c
 // GATHER (the tuple inputs of the SHOT model, train_shot.py:75-83, never materialised): features [0, head) of a row come
 // from its block of pair features (xrow, `head` floats per tuple), feature head + fdim j + c from table[gi[j]][c] -- the
 // per-point descriptor of the tuple's j-th point; 8 consecutive features never straddle two sources (head, fdim % 8 == 0).
+// what varies per row block: this lane's row (GATHER: its head block) and, for GATHER, its tuple's global point indices --
+// passed BY VALUE everywhere (scalars, not an array, and never behind a reference: selected by a lane-dependent j, anything
+// addressable would be kept in scratch memory and the selection turned into an indexed scratch load)
+struct RsRow {
+  const float* xrow;
+  int g0, g1, g2, g3, g4, g5, g6, g7;
+};
+
 template <bool GATHER>
 struct RsX {
-  const float* xrow;           // this lane's row (GATHER: its head block)
   char* slots;                 // the wavefront's three slots in LDS
   int k_in, g, lane;
-  const float* table;          // GATHER: [points, fdim] descriptors, the row's point indices, head width, log2(fdim)
-  int gi[8];
+  const float* table;          // GATHER: [points, fdim] descriptors, head width, log2(fdim)
   int head, fshift;
 
-  __device__ __forceinline__ const float* source(int f) const {
-    if (!GATHER || f < head) return xrow + f;
+  __device__ __forceinline__ const float* source(int f, const RsRow rw) const {
+    if (!GATHER || f < head) return rw.xrow + f;
     const int j = (f - head) >> fshift, c = (f - head) & ((1 << fshift) - 1);
-    int p = gi[0];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) p = (j == q) ? gi[q] : p;
+    int p = rw.g0;
+    p = j == 1 ? rw.g1 : p; p = j == 2 ? rw.g2 : p; p = j == 3 ? rw.g3 : p; p = j == 4 ? rw.g4 : p;
+    p = j == 5 ? rw.g5 : p; p = j == 6 ? rw.g6 : p; p = j == 7 ? rw.g7 : p;
     return table + ((int64_t)p << fshift) + c;
   }
-  __device__ __forceinline__ void issue(int s, int slot) const {        // always exactly two vector-memory operations
+  __device__ __forceinline__ void issue(int s, int slot, const RsRow rw) const {   // always exactly two vector-memory operations
     int f = 16 * s + 8 * g;
     if (f + 8 > k_in) f = 0;                     // past the end (or the zero tail): any valid address, the value is masked
-    const float* src = source(f);
+    const float* src = source(f, rw);
     char* dst = slots + slot * 2048;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -298,7 +304,7 @@ struct RsX {
 // s + 3 -- the wait comes first), read it, issue tile s + 3 into the slot tile s left, split tile s + 1 in the shadow of
 // step s's MFMAs.
 template <int NTILES, bool PREFETCH, class X, class Stream>
-__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X& xs, int ks1, Stream& ws) {
+__device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, const RsRow rw, int ks1, Stream& ws) {
   constexpr int SPC = rs_spc(NTILES);
   float xv[8];
   RS_WAIT(4, 15);                                    // tile 0 has landed (tiles 1, 2 may be in flight)
@@ -318,7 +324,7 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X& xs,
         RS_WAIT(2, 15);                              // x tile s + 1 has landed (tile s + 2 may be in flight)
         __builtin_amdgcn_sched_barrier(0);
         xs.read(xv, s0 + i + 1, slot);
-        xs.issue(s0 + i + 3, slot == 0 ? 2 : slot - 1);
+        xs.issue(s0 + i + 3, slot == 0 ? 2 : slot - 1, rw);
         slot = slot == 2 ? 0 : slot + 1;
         RsFrag bn;
         rs_step<NTILES, PREFETCH, Stream::PMAX>(acc, w + i * NTILES * 3 * 64, b,
@@ -491,10 +497,6 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   for (int i = threadIdx.x; i < 32 * NT * chain; i += THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
   __syncthreads();
 
-  auto row_ptr = [&](int64_t blk) {
-    const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
-    return x + (row < rows ? row : rows - 1) * ldx;
-  };
   RsX<GATHER> xs;
   xs.slots = s_ring + 2 * RS_STAGE_BYTES + wave * (3 * 2048);
   xs.k_in = k_in;
@@ -503,28 +505,33 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   xs.table = ga.table;
   xs.head = ga.head;
   xs.fshift = ga.fshift;
-  int gnext[8];                                   // GATHER: the point indices of this lane's row in the NEXT row block
-  auto load_indices = [&](int64_t blk, int (&dst)[8]) {
+  auto row_of = [&](int64_t blk) {                // this lane's row of a row block (+ its tuple's point indices)
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
-    const int32_t* p = ga.gidx + (row < rows ? row : rows - 1) * ga.slots;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dst[q] = q < ga.slots ? p[q] : 0;
+    const int64_t rc = row < rows ? row : rows - 1;
+    RsRow rw;
+    rw.xrow = x + rc * ldx;
+    rw.g0 = rw.g1 = rw.g2 = rw.g3 = rw.g4 = rw.g5 = rw.g6 = rw.g7 = 0;
+    if (GATHER) {
+      const int32_t* p = ga.gidx + rc * ga.slots;
+      rw.g0 = p[0];
+      rw.g1 = ga.slots > 1 ? p[1] : 0; rw.g2 = ga.slots > 2 ? p[2] : 0; rw.g3 = ga.slots > 3 ? p[3] : 0;
+      rw.g4 = ga.slots > 4 ? p[4] : 0; rw.g5 = ga.slots > 5 ? p[5] : 0; rw.g6 = ga.slots > 6 ? p[6] : 0;
+      rw.g7 = ga.slots > 7 ? p[7] : 0;
+    }
+    return rw;
   };
-  auto first_tiles = [&](const float* rowp) {     // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
-    xs.xrow = rowp;
-    xs.issue(0, 0);
-    xs.issue(1, 1);
-    xs.issue(2, 2);
-  };
-  if (blockIdx.x < nblocks) {
-    if (GATHER) load_indices(blockIdx.x, xs.gi);
-    first_tiles(row_ptr(blockIdx.x));
+  RsRow cur = row_of(blockIdx.x < nblocks ? (int64_t)blockIdx.x : 0);
+  if (blockIdx.x < nblocks) {                     // x tiles of K steps 0, 1, 2 of the first row block into slots 0, 1, 2
+    xs.issue(0, 0, cur);
+    xs.issue(1, 1, cur);
+    xs.issue(2, 2, cur);
   }
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
-    const float* xrow = row_ptr(blk);
-    if (GATHER && blk + gridDim.x < nblocks) load_indices(blk + gridDim.x, gnext);      // used after the first product
+    const float* xrow = cur.xrow;
+    const bool more = blk + gridDim.x < nblocks;
+    const RsRow nxt = row_of(more ? blk + gridDim.x : blk);         // (GATHER: its index loads are used after the first product)
     // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a projection layer] ----------------------------
     f32x16 acc[2 * NT];                         // h tiles, then the output tiles
     f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
@@ -535,10 +542,9 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
 #pragma unroll
       for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
-    xs.xrow = xrow;
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
-      rs_product_x<T0, PF>(first, xs, ks1, ws);
+      rs_product_x<T0, PF>(first, xs, cur, ks1, ws);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -550,13 +556,12 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
-    if (blk + gridDim.x < nblocks) {
-      if (GATHER) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xs.gi[q] = gnext[q];
-      }
-      first_tiles(row_ptr(blk + gridDim.x));
+    if (more) {
+      xs.issue(0, 0, nxt);
+      xs.issue(1, 1, nxt);
+      xs.issue(2, 2, nxt);
     }
+    cur = nxt;
     // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
     rs_product_h<NT, NT, PF>(o, h, ws);
     // ---- the identity layers chained behind (same width): y <- y + relu(y W1^T + b1) W2^T with y = the output tiles,

@@ -19,7 +19,8 @@ for i in range(6):
     print("step %d: host %.2f ms, total %.2f ms, segments allocated %d freed %d, reserved %.2f GB, alloc retries %d" % (
         i, 1e3 * (t1 - t0), 1e3 * (t2 - t0), s1["segment.all.allocated"] - s0["segment.all.allocated"],
         s1["segment.all.freed"] - s0["segment.all.freed"], s1["reserved_bytes.all.current"] / 1e9, s1["num_alloc_retries"]), flush=True)
-for timed in (False, True):
+step.prepare_events()
+for timed in (None, 0):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(10):
