@@ -404,7 +404,8 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
                                                       double* __restrict__ sums /* [Ntot][NSUM] */,
                                                       int32_t* __restrict__ nbr_list /* [Ntot][NBR_CAP] */,
                                                       int32_t* __restrict__ nbr_cnt /* [Ntot] */) {
-  __shared__ double s_part[NSUM][64];
+  __shared__ double s_part[NSUM][64 + 1];       // + 1: the columns' rows start in different banks (the serial sums below
+                                                 // read one row per lane group; unpadded, all 19 rows alias: 19-way conflicts)
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const int b = scene_of[qi];
