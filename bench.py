@@ -229,7 +229,7 @@ class Step:
             # (Round 2a ran it on a second stream beside the rotation votes; with the head as two short matrix-core kernels
             # the two orders take the same time -- 0.49 ms for both stages -- so it is in stream order: one stream, no waits.)
             rows = pipe.kept_rows()
-            scales = pipe.scatter_kept(rows, self.model.scale_head(feat[rows]), out=self.scales_buf)
+            scales = pipe.scatter_kept(rows, self.model.scale_head_rows(feat, rows), out=self.scales_buf)
         self._mark("scale_head")
         pipe.assemble(scales)
         self._mark("assemble_pose")

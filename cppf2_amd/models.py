@@ -305,6 +305,19 @@ class BeyondCPPFShot(nn.Module):
             return fused_stack(self.scale_encoder, feat_rows)
         return self.scale_encoder(feat_rows)
 
+    def scale_head_rows(self, feat, rows):
+        """scale_head(feat[rows]) without materialising feat[rows]: the scale head's first layer (a 128-wide projection
+        layer) reads the selected rows of `feat` through the gathering x-tile fetch of cppf_reslayer_split_gather (a table
+        gather with no pair-feature block).  rows: int64 / int32 [n] tuple rows."""
+        first = self.scale_encoder[0]
+        f = feat.shape[1]
+        if not (MLP_ARITH == "split" and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
+                and first.fc0 is not None and first.fc1.out_features == 128 and first.fc1.in_features == f
+                and f >= 8 and f & (f - 1) == 0 and feat.shape[0] < 2 ** 31):
+            return self.scale_head(feat[rows])
+        gidx = rows.to(torch.int32).reshape(-1, 1).contiguous()
+        return fused_stack(self.scale_encoder, None, gather=(feat[:, :0], gidx, feat))
+
     def encode_points(self, shot_feat):
         """shot_encoder over the per-point descriptors (train_shot.py:118)."""
         if not torch.is_grad_enabled() and shot_feat.is_cuda:

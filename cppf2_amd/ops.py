@@ -334,14 +334,15 @@ def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
     """The first ResLayer of the tuple encoder (+ `chain` identity layers) on rows [heads | table[gidx[:, 0]] | ... ] that
     are gathered by the kernel instead of being materialised (cppf_reslayer_split_gather); same arithmetic and results as
     reslayer_split on encode_tuples_shot's rows.  Returns float32 [T, n_out]."""
-    assert heads.is_cuda and heads.dtype == torch.float32 and heads.dim() == 2 and heads.stride(1) == 1
+    assert heads.is_cuda and heads.dtype == torch.float32 and heads.dim() == 2
     assert gidx.dtype == torch.int32 and gidx.is_contiguous() and table.dtype == torch.float32 and table.is_contiguous()
-    rows = heads.shape[0]
+    rows = gidx.shape[0]
     out = torch.empty((rows, n_out), dtype=torch.float32, device=heads.device)
     b1 = b1.contiguous()
     b0 = b0.contiguous()
     assert b1.numel() == (1 + chain) * n_out
-    _lib.check(_L.cppf_reslayer_split_gather(_p(heads), heads.stride(0), heads.shape[1], _p(gidx), gidx.shape[1], _p(table),
+    ld_heads = heads.stride(0) if heads.shape[1] else 0
+    _lib.check(_L.cppf_reslayer_split_gather(_p(heads if heads.shape[1] else table), ld_heads, heads.shape[1], _p(gidx), gidx.shape[1], _p(table),
                                              table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
                                              wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
                "cppf_reslayer_split_gather")

@@ -251,6 +251,9 @@ def test_gathered_first_layer_is_bit_identical_to_the_materialised_rows():
             assert torch.equal(cls_a, cls_b) and torch.equal(sc_a, sc_b)
             cls_c, feat_c = net.heads_from_tuples(pts, idx, feat, nrm, pt_off, tup_off, lazy_scale=True)
             assert torch.equal(cls_c, cls_a) and torch.equal(net.scale_head(feat_c), sc_a)
+            # the scale head on selected rows, gathered by its first layer's kernel instead of feat[rows]
+            pick = torch.randint(0, feat_c.shape[0], (1234,), device=dev)
+            assert torch.equal(net.scale_head_rows(feat_c, pick), net.scale_head(feat_c[pick]))
             models.MLP_ARITH = "native"                      # no gathering kernel there: falls back to the materialised rows
             assert not net.gather_supported(64, 5)
             cls_n, _ = net.heads_from_tuples(pts, idx, feat, nrm, pt_off, tup_off)
