@@ -47,7 +47,9 @@ __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
 
 // measured variants kept as switches: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more),
-// and the MFMA / filler interleave below (1-3 % over the compiler's own order)
+// and the MFMA / filler interleave below (1-3 % over the compiler's own order).  Also measured, not kept: two tiles per
+// region with their MFMA chains alternating between the two accumulators (3-8 % slower), output halves / quarters for the
+// 256-wide layers at two wavefronts per SIMD (equal), register-staged instead of LDS-DMA weight chunks.
 #ifndef RS_DEEP_PREFETCH
 #define RS_DEEP_PREFETCH 0
 #endif
