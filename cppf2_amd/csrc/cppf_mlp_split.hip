@@ -12,6 +12,10 @@
 // the product a float32 FMA chain starts from.  The result is not bit-equal to the f32-input MFMA chain (nor is any
 // re-tiled float32 GEMM); its error against a float64 evaluation is that of the library float32 GEMMs (measured side by
 // side in tests/test_mlp_split.py).  Six bf16 MFMAs replace sixteen f32-input MFMA cycles' worth of work: 2.7x the rate.
+// Non-finite operands: a NaN stays a NaN; an infinite x or weight splits into Inf + NaN, so the rows it touches come out NaN
+// (a float32 GEMM would give +-Inf where no 0 * Inf occurs); magnitudes above the largest bf16 (3.39e38) behave like Inf,
+// and contributions below the float32 normal range may be flushed -- none of which the path's inputs reach (the SHOT
+// descriptors are NaN-cleaned before the point encoder, eval.py:215).
 //
 // Structure (one wavefront = 32 rows of x; a workgroup = 8 wavefronts, two per SIMD with 256 registers each, for widths up
 // to 128, and 4 wavefronts, one per SIMD with 512 registers, for 192 / 256; persistent over row blocks):
