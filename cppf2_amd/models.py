@@ -1,5 +1,6 @@
-"""The tuple MLPs of CPPF++ as plain torch modules (left to PyTorch-ROCm by design), with the
-tuple encode (prepare_tuple_inputs) routed through the HIP kernels.
+"""The tuple MLPs of CPPF++: plain torch modules (training, checkpoints, the reference's state-dict layout) whose inference
+runs through the library's matrix-core kernels (fused_stack), with the tuple encode (prepare_tuple_inputs) and the bin draw
+feeding / draining them in-kernel.
 
 State-dict key layout is the reference's (train_shot.py:19-73, train_dino.py:21-89:
 `shot_encoder.N.fc1.weight`, `tuple_encoder.N.fc0.bias`, `logit_encoder...`, `scale_encoder...`,
@@ -116,19 +117,21 @@ def _fused_plan(seq):
 
 
 def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
-    """Inference-only execution of a stack of ResLayers with the elementwise work folded into GEMM epilogues
-    (same fp32 math, fewer passes over the [T, C] activations, which are 1.3 M rows at bench size):
+    """Inference-only execution of a stack of ResLayers (train_shot.py:19-45) on the matrix cores.
+    MLP_ARITH == "split" (default): every layer whose shape the kernel covers -- widths 64 / 128 / 192 / 256, input columns
+    a multiple of 8 -- runs as ONE cppf_reslayer_split launch together with the identity layers of the same width behind it
+    (the activation stays in registers across the chain); float32-equivalent split-bf16 arithmetic.
+    MLP_ARITH == "native", and layers outside that coverage (the scale head's 64 -> 3 output layer): library GEMMs with the
+    elementwise work folded into their epilogues --
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
       out = x W0^T + (b0 + b2)           one GEMM, bias epilogue          (layers with a projection skip)
       out += h W2^T                      one GEMM, beta = 1, in place
-    128-wide identity-skip layers (4 of the 6 layers of `tuple_encoder` and `shot_encoder`) run as one HIP kernel on the
-    f32 matrix cores (ops.reslayer128_: h never leaves the registers).  Other identity-skip layers accumulate h W2^T into
-    x in place; an identity layer's output bias b2 is not added to the activation
-    but carried as a pending per-channel offset c (true activation = x + c) and folded into the biases of the
-    next GEMMs (b1 + W1 c, b0 + W0 c), which is algebraically the same network.  Every stack of the reference's
-    models ends in a projection layer, which absorbs the pending offset.  An identity first layer overwrites `x`
-    unless keep_input is set.
-    The folded biases depend on the weights only and are computed once per weight version (_fused_plan).
+    -- and 128-wide identity layers as cppf_reslayer128 (f32-input matrix cores, h never leaves the registers).
+    In both modes an identity layer's output bias b2 is not added to the activation but carried as a pending per-channel
+    offset c (true activation = x + c) and folded into the biases of the next layer (b1 + W1 c, b0 + W0 c), which is
+    algebraically the same network; every stack of the reference's models ends in a projection layer, which absorbs the
+    pending offset.  The folded biases (and the packed weight streams of the split kernels) depend on the weights only and
+    are computed once per weight version (_fused_plan).  An identity first layer overwrites `x` unless keep_input is set.
     gather = (heads [T, H], gidx int32 [T, k], table [points, F]) instead of x: the rows [heads | table[gidx[:, 0]] | ...] are
     read by the first layer's kernel itself (ops.reslayer_split_gather; split arithmetic, 128-wide projection first layer).
     decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6] | None): the stack's last layer (the logit head's
