@@ -7,7 +7,8 @@ import pytest
 torch = pytest.importorskip("torch")
 
 SHAPES = [(128, 128, False), (360, 128, True), (128, 256, True), (256, 256, False), (256, 192, True), (352, 128, True),
-          (128, 64, True), (256, 128, True), (64, 64, False), (288, 128, True), (192, 192, False)]
+          (128, 64, True), (256, 128, True), (64, 64, False), (288, 128, True), (192, 192, False),
+          (72, 64, True), (200, 128, True), (40, 256, True)]        # K steps not a multiple of the staged chunk
 
 
 def _layer(k, n, proj, dev, seed=0):
