@@ -492,6 +492,8 @@ def main():
             def layer_flops(k, n, proj):
                 return 2.0 * n * ((k + 15) // 16 * 16) * (2 if proj else 1) + 2.0 * n * n, 2.0 * n * k * (2 if proj else 1) + 2.0 * n * n
             layers = [(360, 128, True)] + [(128, 128, False)] * 4 + [(128, 256, True), (256, 256, False), (256, 256, False), (256, 192, True)]
+            if args.eager_scale_head:           # the scale head's matrix-core layers run inside this stage too (on every tuple)
+                layers += [(256, 128, True), (128, 64, True)]
             executed = 6.0 * sum(layer_flops(*l)[0] for l in layers) * B * T
             algorithmic = sum(layer_flops(*l)[1] for l in layers) * B * T
             mlp_ms_ = stage_ms["tuple_mlp"]
