@@ -166,7 +166,8 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
                 entry[5] = (key, pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
             return ops.reslayer_split_decode(x, entry[5][1], b1, b0, decode[0], prior=decode[1], bins=decode[2])
         if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
-                and x.shape[1] >= w1t.shape[0] and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
+                and x.data_ptr() % 16 == 0 and x.shape[1] >= w1t.shape[0]
+                and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
             # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
             chain = 0
