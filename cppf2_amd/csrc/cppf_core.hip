@@ -560,7 +560,7 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
         for (int j = 1; j < NB; ++j) m = fmaxf(m, e[j]);
         float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { acc += expf(e[j] - m); e[j] = acc; }   // running f32 CDF
+        for (int j = 0; j < NB; ++j) { acc += softmax_exp(e[j] - m); e[j] = acc; }   // running f32 CDF
         const float target = uniforms[t * 6 + c] * acc;
 #pragma unroll
         for (int j = 0; j < NB; ++j) cnt += (e[j] <= target) ? 1 : 0;        // first j with cdf[j] > target
@@ -570,10 +570,10 @@ __global__ __launch_bounds__(DEC_TUPLES * 6) void decode_bins_kernel(
         float m = at(0);
         for (int j = 1; j < nb; ++j) m = fmaxf(m, at(j));
         float acc = 0.0f;
-        for (int j = 0; j < nb; ++j) acc += expf(at(j) - m);
+        for (int j = 0; j < nb; ++j) acc += softmax_exp(at(j) - m);
         const float target = uniforms[t * 6 + c] * acc;
         float run = 0.0f;
-        for (int j = 0; j < nb; ++j) { run += expf(at(j) - m); cnt += (run <= target) ? 1 : 0; }
+        for (int j = 0; j < nb; ++j) { run += softmax_exp(at(j) - m); cnt += (run <= target) ? 1 : 0; }
       }
       bin = cnt < nb - 1 ? cnt : nb - 1;
       if (bins) bins[t * 6 + c] = bin;

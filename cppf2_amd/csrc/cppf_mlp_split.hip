@@ -394,7 +394,7 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
 // The bin draw of eval.py:225-229 as the epilogue of the logit head's output layer (6 coordinates x 32 bins = the 6 output
 // tiles): tile u holds the logits of coordinate u of this lane's row, registers e <-> bins (e & 3) + 8 (e >> 2) + 4 g, the other
 // 16 bins sit in lane ^ 32.  Same arithmetic as decode_bins_kernel<32> (cppf_core.hip), bit for bit: logits (+ prior), max,
-// expf, a float32 running sum IN BIN ORDER -- so the running total alternates between the two lanes every four bins --
+// softmax_exp, a float32 running sum IN BIN ORDER -- so the running total alternates between the two lanes every four bins --
 // target = uniform * total, bin = #{cdf <= target} capped at 31.  The six coordinates' chains are independent and interleave.
 struct RsDecode {
   const float* prior;           // [rows, 192] additive logit prior or NULL
@@ -424,7 +424,7 @@ __device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDeco
     for (int e = 1; e < 16; ++e) m = fmaxf(m, o[u][e]);
     m = fmaxf(m, __shfl_xor(m, 32));
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[u][e] = expf(o[u][e] - m);
+    for (int e = 0; e < 16; ++e) o[u][e] = softmax_exp(o[u][e] - m);
     back[u] = 0.0f;
   }
 #pragma unroll
