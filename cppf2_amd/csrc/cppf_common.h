@@ -163,7 +163,8 @@ __device__ __forceinline__ float softmax_exp(float x) {
   const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011e-8f;      // log2(e) = hi + lo
   const float t = x * l2e_hi;
   const float r = fmaf(x, l2e_lo, fmaf(x, l2e_hi, -t));                                 // what t misses of x * log2(e)
-  return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147182464599609375f, 1.0f);
+  // (x = -inf, a masked logit, would make r = NaN: below the float32 denormal range the result is 0 like expf's)
+  return x < -104.0f ? 0.0f : __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147182464599609375f, 1.0f);
 }
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (CPPF_WAVE - 1); }

@@ -353,3 +353,24 @@ def test_vote_center_rotation_counts_at_the_table_limits(R):
     got = grid.cpu().numpy()[:want.size].astype(np.int64)
     assert np.array_equal(got, want.reshape(-1))
     assert int(pipe.argmax.item()) == int(np.argmax(want)) and np.array_equal(pipe.world.cpu().numpy()[0], cand)
+
+
+@pytest.mark.gpu
+def test_decode_bins_with_masked_logits():
+    """-inf logits (masked bins) take no probability mass: the draw lands in the unmasked bins only, no NaN (eval.py:225-229)."""
+    import torch
+    from cppf2_amd.pipeline import VotingPipeline
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    N, T = 64, 500
+    pts = torch.randn(N, 3, device=dev) * 0.05
+    idx = torch.randint(0, N, (T, 5), device=dev, dtype=torch.int32)
+    logits = torch.randn(T, 6, 32, device=dev)
+    logits[:, :, :10] = float("-inf")
+    logits[:, :, 25:] = float("-inf")
+    u = torch.rand(T, 6, device=dev)
+    pipe = VotingPipeline([N], [T], num_rots=36)
+    pipe.decode(pts, idx, logits, u)
+    b = pipe.bins.cpu().numpy()
+    assert b.min() >= 10 and b.max() <= 24
+    assert bool(torch.isfinite(pipe.tr).all()) and bool(torch.isfinite(pipe.scale).all())
