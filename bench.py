@@ -505,6 +505,9 @@ def main():
                             launch_ms=mlp_ms_, launches=4,
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
+                            # the same launch time against the other two readings of "algorithmic / peak"
+                            frac_algorithmic_of_f32_input_mfma_peak=algorithmic / 1e12 / (mlp_ms_ / 1e3) / F32_MFMA_PEAK_TFLOPS,
+                            frac_algorithmic_of_bf16_peak=algorithmic / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS,
                             algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = 6 bf16 "
                                               "MFMA products per float32 product (3-way exact operand split)" % (B * T),
                             hbm=hbm)
