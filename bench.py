@@ -331,23 +331,71 @@ def cpu_baseline(args, step):
                        "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt)), agree
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started without a launcher environment: run N FRESH rank processes (one per GPU,
+    the environment torch.distributed.run would give them) and exit with their status; rank 0 prints the JSON line on the
+    inherited stdout.  This process never initialises the GPU (device_count() does not) and never re-execs itself."""
+    import socket
+    import subprocess
+    n = args.gpus
+    backend = os.environ.get("CPPF_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if have < n and backend == "nccl":
+        print("bench.py: --gpus %d but %d GPU(s) are visible; one rank per GPU over RCCL needs %d (CPPF_BENCH_BACKEND=gloo "
+              "is the dry-run switch that lets ranks share a GPU)" % (n, have, n), file=sys.stderr)
+        return 2
+    if have < 1:
+        print("bench.py needs a GPU", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd()))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p_ in list(live):
+            r_ = p_.poll()
+            if r_ is None:
+                continue
+            live.remove(p_)
+            if r_ != 0 and rc == 0:
+                rc = r_ if r_ > 0 else 1
+                for q_ in live:          # a failed rank leaves the others waiting in a collective: stop exactly those PIDs
+                    q_.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run --nproc-per-node %d), "
+              "or run `python bench.py --gpus %d` without a launcher environment and it starts the ranks itself"
+              % (args.gpus, world, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL over xGMI; CPPF_BENCH_BACKEND=gloo is a dry-run switch for boxes with fewer GPUs than ranks
+    from cppf2_amd import dist as cdist
+    backend = None
+    if world > 1 or cdist.force_collective():
+        # RCCL over xGMI; CPPF_BENCH_BACKEND=gloo is a dry-run switch for boxes with fewer GPUs than ranks.
+        # CPPF_DIST_FORCE_COLLECTIVE=1 makes a one-rank run create the group and issue the all_gather too.
         backend = os.environ.get("CPPF_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        else:
-            torch.distributed.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+        cdist.init(backend=backend, device=dev if backend == "nccl" else None)
+        assert torch.distributed.get_world_size() == world and torch.distributed.get_rank() == rank
 
     from cppf2_amd import models as _models
     if args.mlp_arith:
@@ -370,7 +418,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -389,7 +437,7 @@ def main():
         sync()
         dt_ = time.perf_counter() - t0
         tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
-        if world > 1:
+        if torch.distributed.is_initialized():
             if torch.distributed.get_backend() == "gloo":
                 tmax = tmax.cpu()
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -561,6 +609,11 @@ def main():
             # the same run with the MLP on the f32-input matrix instruction (no operand splitting)
             "value_f32_input_mfma": (total_scenes / dt_native) if dt_native else None,
             "records_gathered": int(all_rec.shape[0]),
+            # the path's one collective: all_gather of the 160-byte scene records, HIP-event time of the stage
+            "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
+                           "op": "all_gather_into_tensor" if backend == "nccl" else ("all_gather" if backend else None),
+                           "records_gathered": int(all_rec.shape[0]), "bytes_per_rank": int(B * 160),
+                           "gather_us": round(1e3 * stage_ms.get("gather", 0.0), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,
         }
@@ -569,7 +622,7 @@ def main():
             for r in rows:
                 print("%-22s %10.3f %12.1f %10.1f" % r, file=sys.stderr)
         print(json.dumps(line))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

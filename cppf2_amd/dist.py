@@ -26,12 +26,23 @@ def max_shard(num_scenes, world):
     return (int(num_scenes) + int(world) - 1) // int(world)
 
 
+def force_collective():
+    """CPPF_DIST_FORCE_COLLECTIVE=1: run the all_gather even in a one-rank group (exercises the RCCL call on a 1-GPU box)."""
+    return os.environ.get("CPPF_DIST_FORCE_COLLECTIVE", "0") not in ("", "0")
+
+
 def init(backend=None, device=None):
-    """Initialises torch.distributed from the torchrun environment (no-op for a single process)."""
+    """Initialises torch.distributed from the torchrun environment (no-op for a single process unless the collective is
+    forced, see force_collective())."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 or dist.is_initialized():
+    if dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    if world == 1 and not force_collective():
         return world, int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
     if backend == "nccl" and device is not None:
@@ -40,28 +51,51 @@ def init(backend=None, device=None):
     return dist.get_world_size(), dist.get_rank()
 
 
-def gather_results(local_records, num_scenes):
+_GATHER_BUFS = {}
+
+
+def _gather_bufs(world, cap, device):
+    """(send [cap, 160], recv [world, cap, 160]) allocated once per (world, cap, device): the step's only collective does
+    not touch the allocator."""
+    key = (world, cap, str(device))
+    b = _GATHER_BUFS.get(key)
+    if b is None:
+        if len(_GATHER_BUFS) >= 8:
+            _GATHER_BUFS.clear()
+        b = (torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=device),
+             torch.empty((world, cap, RECORD_BYTES), dtype=torch.uint8, device=device))
+        _GATHER_BUFS[key] = b
+    return b
+
+
+def gather_results(local_records, num_scenes, out=None):
     """local_records: uint8 [n_local, 160] (device or CPU).  Returns uint8 [num_scenes, 160] in global scene order
-    on every rank.  Shards are padded to the largest one so the all_gather is a single fixed-size collective."""
+    on every rank (`out`, if given, receives it).  Shards are padded to the largest one so the all_gather is a single
+    fixed-size collective; equal shards (the bench's weak scaling) are returned as a view of the receive buffer."""
     assert local_records.dtype == torch.uint8 and local_records.shape[-1] == RECORD_BYTES
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective()):
         return local_records[:num_scenes]
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world = dist.get_world_size()
     cap = max_shard(num_scenes, world)
     dev = local_records.device
     # gloo (CPU tests, and the one-GPU dry run of the N > 1 bench) gathers host tensors; RCCL gathers in place on the device
     stage = local_records.is_cuda and dist.get_backend() == "gloo"
     src = local_records.cpu() if stage else local_records
-    buf = torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=src.device)
-    buf[:src.shape[0]] = src
-    out = torch.empty((world, cap, RECORD_BYTES), dtype=torch.uint8, device=src.device)
+    buf, recv = _gather_bufs(world, cap, src.device)
+    buf[:src.shape[0]].copy_(src)
     if src.is_cuda:
-        dist.all_gather_into_tensor(out, buf)
+        dist.all_gather_into_tensor(recv, buf)
     else:
-        dist.all_gather(list(out.unbind(0)), buf)
-    parts = []
+        dist.all_gather(list(recv.unbind(0)), buf)
+    if num_scenes == world * cap:
+        res = recv.view(num_scenes, RECORD_BYTES)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.to(dev) if stage else res
+    if out is None:
+        out = torch.empty((num_scenes, RECORD_BYTES), dtype=torch.uint8, device=src.device)
     for r in range(world):
         lo, hi = shard(num_scenes, r, world)
-        parts.append(out[r, :hi - lo])
-    res = torch.cat(parts, 0)
-    return res.to(dev) if stage else res
+        out[lo:hi].copy_(recv[r, :hi - lo])
+    return out.to(dev) if stage else out

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-BENCH2 = {}      # handles of the two-rank bench job started in pytest_configure (GPU runs only)
+BENCH2 = {}      # handles of the bench jobs started in pytest_configure (GPU runs only)
 
 
 def _free_port():
@@ -23,22 +23,36 @@ def _free_port():
     return p
 
 
-def _start_two_rank_bench(tmpdir):
-    """bench.py --gpus 2 as two FRESH child processes sharing GPU 0 (backend gloo: one GPU cannot host two RCCL ranks).
-    Started here, before this process initialises the GPU -- a process that has done so must not fork+exec on this
-    pool -- and collected by tests/test_multi_rank_gpu.py."""
+_LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CPPF_BENCH_BACKEND",
+               "CPPF_DIST_FORCE_COLLECTIVE")
+
+
+def _start_bench(tmpdir, tag, argv, **env_add):
     import subprocess
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), CPPF_BENCH_BACKEND="gloo")
-        out = open(os.path.join(tmpdir, "bench2_rank%d.out" % rank), "w")
-        err = open(os.path.join(tmpdir, "bench2_rank%d.err" % rank), "w")
-        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-                                        "--warmup", "0", "--scenes-per-gpu", "4", "--cpu-scenes", "0"],
-                                       env=env, stdout=out, stderr=err, cwd=ROOT), out.name, err.name))
-    return procs
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
+    env.update(env_add)
+    out = open(os.path.join(tmpdir, tag + ".out"), "w")
+    err = open(os.path.join(tmpdir, tag + ".err"), "w")
+    small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", "4", "--cpu-scenes", "0", "--no-reference-order",
+             "--no-native-arith"]
+    return (subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + argv + small, env=env, stdout=out,
+                             stderr=err, cwd=ROOT), out.name, err.name)
+
+
+def _start_bench_jobs(tmpdir):
+    """FRESH child processes, started here, before this process initialises the GPU -- a process that has done so must not
+    fork+exec on this pool -- and collected by tests/test_multi_rank_gpu.py:
+    * two_ranks: plain `python bench.py --gpus 2` (no launcher environment): bench.py starts its two ranks itself; they share
+      GPU 0, so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks);
+    * rccl_one_rank: `bench.py --gpus 1` with CPPF_DIST_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...) and
+      the path's all_gather (plus the bench's barrier and all_reduce) really run through RCCL, in a one-rank group;
+    * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly."""
+    return {
+        "two_ranks": _start_bench(tmpdir, "two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo"),
+        "rccl_one_rank": _start_bench(tmpdir, "rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1",
+                                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+        "refuse_two_gpus": _start_bench(tmpdir, "refuse_two_gpus", ["--gpus", "2"]),
+    }
 
 
 def pytest_configure(config):
@@ -49,7 +63,8 @@ def pytest_configure(config):
             import tempfile
             import torch
             if torch.cuda.device_count() > 0:            # counting devices does not initialise the GPU
-                BENCH2["procs"] = _start_two_rank_bench(tempfile.mkdtemp(prefix="cppf_bench2_"))
+                BENCH2["jobs"] = _start_bench_jobs(tempfile.mkdtemp(prefix="cppf_bench2_"))
+                BENCH2["gpus"] = torch.cuda.device_count()
         except Exception as e:                            # pragma: no cover
             BENCH2["error"] = repr(e)
 

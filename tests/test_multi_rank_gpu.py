@@ -60,21 +60,51 @@ def test_records_do_not_depend_on_the_world_size():
         assert np.linalg.norm(want["t"][b] - whole.scenes[b]["t"]) < 5e-3
 
 
-def test_bench_two_ranks_on_one_gpu():
+def _job(name):
     from conftest import BENCH2
-    if "procs" not in BENCH2:
-        pytest.skip("two-rank bench job was not started (%s)" % BENCH2.get("error", "not a -m gpu run"))
-    outs = []
-    for proc, out, err in BENCH2["procs"]:
-        rc = proc.wait(timeout=900)
-        assert rc == 0, open(err).read()[-3000:]
-        outs.append(open(out).read())
-    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]     # rank 0 prints the line
+    if "jobs" not in BENCH2:
+        pytest.skip("bench jobs were not started (%s)" % BENCH2.get("error", "not a -m gpu run"))
+    proc, out, err = BENCH2["jobs"][name]
+    rc = proc.wait(timeout=900)
+    return rc, open(out).read(), open(err).read()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """Plain `python bench.py --gpus 2`: bench.py starts both ranks itself (fresh processes, gloo because they share GPU 0)."""
+    rc, out, err = _job("two_ranks")
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints the line, rank 1 nothing
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak" and j["unit"] == "scenes/s"
     assert j["records_gathered"] == 8 and j["config"]["scenes_per_gpu"] == 4
+    assert j["collective"]["backend"] == "gloo" and j["collective"]["world"] == 2 and j["collective"]["records_gathered"] == 8
     assert j["value"] > 0 and abs(j["value"] - 8 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
     assert j["cpu_baseline"] is None                       # rank 0 at N = 1 only
     assert j["roofline"]["frac"] > 0 and "per_kernel" in j["roofline"] and j["roofline"]["pipeline_frac"] > 0
     assert j["pose_5deg5cm_vs_gt"] == 1.0
+
+
+def test_bench_gathers_through_rccl_in_a_one_rank_group():
+    """The `nccl` branch of bench.py / cppf2_amd.dist on the hardware there is: init_process_group("nccl", device_id=...),
+    all_gather_into_tensor of the device-resident records, barrier and all_reduce, world size 1.  bench.py itself asserts
+    that the gathered records are byte-equal to the local ones."""
+    rc, out, err = _job("rccl_one_rank")
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    c = j["collective"]
+    assert c["backend"] == "nccl" and c["op"] == "all_gather_into_tensor" and c["world"] == 1
+    assert c["records_gathered"] == 4 and c["gather_us"] > 0
+    assert j["n_gpus"] == 1 and j["records_gathered"] == 4 and j["pose_5deg5cm_vs_gt"] == 1.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` over RCCL with one visible GPU must not silently measure one rank."""
+    from conftest import BENCH2
+    rc, out, err = _job("refuse_two_gpus")
+    if BENCH2.get("gpus", 1) >= 2:
+        assert rc == 0 and json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])["n_gpus"] == 2
+        return
+    assert rc == 2 and "GPU(s) are visible" in err and not [ln for ln in out.splitlines() if ln.startswith("{")]
