@@ -16,6 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
          "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+# per-file additions.  cppf_mlp_split: no SLP vectorisation -- it pairs adjacent float adds / subs into v_pk_add_f32, each of which
+# holds the matrix pipe for 16 cycles when it sits between two MFMAs (scratch/rs/filler_price.hip: 48.8 instead of 32.2 cycles per MFMA)
+FILE_FLAGS = {"cppf_mlp_split.hip": ["-fno-slp-vectorize"]}
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -35,7 +40,7 @@ def build(force=False, verbose=True):
             continue
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + extra + ["-I", inc, "-I", CSRC, "-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + extra + ["-I", inc, "-I", CSRC, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -51,15 +51,33 @@ __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
 
 // measured variants kept as switches: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more),
-// and the MFMA / filler interleave below (RS_INTERLEAVE 1: 1-3 % over the compiler's own order; 2 = everything in front of
-// each tile's back-to-back MFMA chain: equal).  Also measured, not kept: two tiles per
-// region with their MFMA chains alternating between the two accumulators (3-8 % slower), output halves / quarters for the
-// 256-wide layers at two wavefronts per SIMD (equal), register-staged instead of LDS-DMA weight chunks.
+// and a hand-placed MFMA / filler interleave (RS_INTERLEAVE 1; 2 = everything in front of each tile's back-to-back MFMA chain).
+// Round 3 measurements (scratch/rs/: rs_probe.hip with the RS_DBG switches, filler_price.hip, mfma_chain.hip + PMC): the kernel is
+// bound by the chip's POWER limit, not by issue slots or latency -- dependent MFMA chains issue every 32.2 cycles, up to four plain
+// VALU instructions fit between two MFMAs for free in cycles, and removing the chunk barrier raises the matrix pipe's busy
+// fraction by 5 points while the clock drops by the same factor (same wall time); what moves the time is the work executed
+// beside the MFMAs (each VALU instruction per MFMA costs ~3 % through the clock, a ds_read_b128 ~5 %): without the operand
+// split the 256-wide kernel runs 14 % faster, without the weight stream 9 %, without its global loads / stores 8 %.  Hence
+// RS_INTERLEAVE 0 (the compiler's own order: fewer register moves, 5 % faster on the 256-wide identity kernel, equal elsewhere).
+// Also measured, not kept: two tiles per region with their MFMA chains alternating between the two accumulators (3-8 % slower),
+// output halves / quarters for the 256-wide layers at two wavefronts per SIMD (equal), register-staged instead of LDS-DMA weight
+// chunks, the residual of the 256-wide identity kernel loaded before the first product (RS_EARLY_RESIDUAL: 128 registers too many).
 #ifndef RS_DEEP_PREFETCH
 #define RS_DEEP_PREFETCH 0
 #endif
 #ifndef RS_INTERLEAVE
-#define RS_INTERLEAVE 1
+#define RS_INTERLEAVE 0
+#endif
+// timing probes (scratch/rs/rs_probe.hip; results are wrong with any bit set): 1 no weight pieces, 2 no operand split,
+// 4 no LDS fragment reads, 8 no chunk barrier, 16 no x tiles, 32 no residual load / output store
+#ifndef RS_DBG
+#define RS_DBG 0
+#endif
+#ifndef RS_EXACT_PMAX
+#define RS_EXACT_PMAX 1
+#endif
+#ifndef RS_EARLY_RESIDUAL
+#define RS_EARLY_RESIDUAL 0      // 1: the wide identity kernel then needs 128 registers more than there are (spills)
 #endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -79,15 +97,22 @@ __device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, u
   // PIN: an opaque copy of the inputs keeps the arithmetic where it is written (between two tiles' MFMAs); without it the
   // compiler gathers the splits of a whole chunk in front of the chunk's first MFMA (12 registers per K step, no overlap)
   if (PIN) asm volatile("" : "+v"(v0), "+v"(v1));
+  if (PIN && (RS_DBG & 2)) {
+    h = __builtin_bit_cast(unsigned, v0);
+    m = __builtin_bit_cast(unsigned, v1);
+    l = h ^ m;
+    return;
+  }
+  // scalar float subtractions on purpose (and -fno-slp-vectorize for this file, cppf2_amd/build.py): a v_pk_add_f32 between two
+  // MFMAs costs 16 issue cycles of the matrix pipe (scratch/rs/filler_price.hip), a v_sub_f32 none
   const f32x2 v = {v0, v1};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(unsigned, hb);
-  m = __builtin_bit_cast(unsigned, mb);
-  l = __builtin_bit_cast(unsigned, lb);
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  const f32x2 rv = {r0, r1};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, bf16x2));
+  const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  const f32x2 qv = {q0, q1};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(qv, bf16x2));
   if (PIN) asm volatile("" : "+v"(h), "+v"(m), "+v"(l));      // ... and from sinking the arithmetic down to its first use
 }
 
@@ -126,7 +151,9 @@ __host__ __device__ constexpr int rs_waitcnt(int vm, int lgkm) {
 // All memory waits of the kernel's main loops are COUNTED (the vector-memory queue completes in order): see acquire().
 template <int NT, int T0, int WAVES>
 struct RsStream {
-  static constexpr int PMAX = 48 / WAVES;      // pieces of a chunk per wavefront, at most
+  // pieces of a chunk per wavefront, at most (a chunk = rs_spc(tiles) K steps of `tiles` tiles, three fragments each)
+  static constexpr int P0 = (rs_spc(T0) * T0 * 3 + WAVES - 1) / WAVES, P1 = (rs_spc(NT) * NT * 3 + WAVES - 1) / WAVES;
+  static constexpr int PMAX = RS_EXACT_PMAX ? (P0 > P1 ? P0 : P1) : 48 / WAVES;
   int nseg;                    // 2 + 2 per chained identity layer
   int chunks;                  // chunks per row block
   const char* base;            // packed stream in global memory
@@ -176,6 +203,7 @@ struct RsStream {
   // chunk's last piece it re-issues that one (same bytes to the same place), which also keeps the number of
   // vector-memory operations per chunk the same for every wavefront.
   __device__ __forceinline__ void piece(int q) {
+    if (RS_DBG & 1) return;
     int j = wave + q * WAVES;
     j = j < p_last ? j : p_last;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + j * RS_FRAG_BYTES),
@@ -194,7 +222,7 @@ struct RsStream {
   template <int YOUNGER>
   __device__ __forceinline__ const u32x4* acquire() {
     RS_WAIT(YOUNGER, 0);
-    __builtin_amdgcn_s_barrier();
+    if (!(RS_DBG & 8)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int cur = stage;
     stage ^= 1;
@@ -205,6 +233,7 @@ struct RsStream {
 
 __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
   RsFrag a;
+  if (RS_DBG & 4) tile = 0;
   const u32x4 h = w[(tile * 3 + 0) * 64], m = w[(tile * 3 + 1) * 64], l = w[(tile * 3 + 2) * 64];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -296,6 +325,7 @@ struct RsX {
     return table + ((int64_t)p << fshift) + c;
   }
   __device__ __forceinline__ void issue(int s, int slot, const RsRow rw) const {   // always exactly two vector-memory operations
+    if (RS_DBG & 16) return;
     int f = 16 * s + 8 * g;
     if (f + 8 > k_in) f = 0;                     // past the end (or the zero tail): any valid address, the value is masked
     const float* src = source(f, rw);
@@ -554,9 +584,10 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     f32x16 (&o)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
 #pragma unroll
     for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
-    if (!PROJ && WAVES == 8) {                  // residual of a narrow identity layer: requested before the first product
+    if (!PROJ && (WAVES == 8 || RS_EARLY_RESIDUAL)) {   // residual of an identity layer: requested before the first product (while
+                                                        // the x tiles of the same rows are passing through L2)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
+      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
     }
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
@@ -567,9 +598,9 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
 #pragma unroll
       for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];        // NaN stays NaN like torch.relu
     }
-    if (!PROJ && WAVES == 4) {                  // ... of a wide one: after it (L2-hot), its registers were the first product's
+    if (!PROJ && WAVES == 4 && !RS_EARLY_RESIDUAL) {     // (measured alternative: after it; re-reads 1.2 GB per launch from HBM)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], xrow + 32 * u, g);
+      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
     if (more) {
@@ -597,7 +628,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     }
     if (DECODE) {
       if constexpr (NT == 6) rs_decode_epilogue<NT>(o, dc, in ? row : rows - 1, in, g);
-    } else if (in) {
+    } else if (in && (!(RS_DBG & 32) || o[0][0] == 1.2345e30f)) {
       float* orow = out + row * ldo + 4 * g;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
