@@ -182,7 +182,7 @@ class Step:
         shot = shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot,
                                        nan_to_zero=True)                                   # eval.py:215 folded in
         self._mark("shot352")
-        normal = torch.nan_to_num_(self.normal, nan=0.0)
+        normal = ops.nan_to_zero_(self.normal)                             # eval.py:216
         feat = self.model.encode_points(shot)
         self._mark("shot_encoder")
         eager = self.eager
@@ -228,8 +228,9 @@ class Step:
             # the scale head is read only for the kept pairs (eval.py:272): run it on those rows (~10 % of the tuples).
             # (Round 2a ran it on a second stream beside the rotation votes; with the head as two short matrix-core kernels
             # the two orders take the same time -- 0.49 ms for both stages -- so it is in stream order: one stream, no waits.)
-            rows = pipe.kept_rows()
-            scales = pipe.scatter_kept(rows, self.model.scale_head_rows(feat, rows), out=self.scales_buf)
+            # Every kernel of it is the library's: kept-row list, two gathered / split matrix-core layers, the 64 -> 3 layer with
+            # the scatter into the [T, 3] buffer assemble() reads folded into its store.
+            scales = self.model.scale_head_rows(feat, pipe.kept_rows32(), scatter=(pipe.kept_count, pipe.max_kept, self.scales_buf))
         self._mark("scale_head")
         pipe.assemble(scales)
         self._mark("assemble_pose")

@@ -11,7 +11,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CppfError(RuntimeError):
@@ -72,6 +72,9 @@ SIGNATURES = {
     "cppf_rot_bins2": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
                             _p, _p, _p, _p, _i64, _p]),
     "cppf_kept_rows": (_i, [_i, _p, _p, _p, _i, _p, _p]),
+    "cppf_kept_rows32": (_i, [_i, _p, _p, _p, _i, _p, _p]),
+    "cppf_nan_to_zero": (_i, [_p, _i64, _p]),
+    "cppf_reslayer_tail": (_i, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),
     "cppf_refine_pose": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p]),

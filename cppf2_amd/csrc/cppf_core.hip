@@ -86,6 +86,25 @@ extern "C" int cppf_philox_uniform(int B, const int32_t* tup_off, int max_t, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// x[np.isnan(x)] = 0 in place (eval.py:215-216, on the normals; the descriptors get it inside cppf_shot_describe).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nan_to_zero_kernel(float* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (!(v == v)) x[i] = 0.0f;
+  }
+}
+
+extern "C" int cppf_nan_to_zero(float* x, int64_t n, void* stream) {
+  CPPF_CHECK_ARG((x != nullptr || n == 0) && n >= 0);
+  if (n == 0) return CPPF_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(nan_to_zero_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, n);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // scene bounds (train_dino.py:172-173): one workgroup per scene, min/max over the cloud.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scene_bounds_kernel(const float* __restrict__ pts,

@@ -180,3 +180,84 @@ extern "C" int cppf_reslayer128(float* x, int64_t rows, const float* w1, const f
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The narrow output ResLayer of the scale head (train_shot.py:67-71: ResLayer(64, 3)) -- too narrow for a matrix-core tile --
+// as plain float32 arithmetic, one thread per row, with the scatter of the kept pairs' rows folded into the store:
+//     y[n] = (b0[n] + sum_k x[k] W0[n][k]) + sum_m relu(b1[m] + sum_k x[k] W1[m][k]) W2[n][m]
+// every sum an fmaf chain in index order (a float32 GEMM up to the summation order; results do not depend on the row count or
+// on the row's position, unlike a library GEMM's tiling).  The weights are read through wave-uniform addresses (scalar loads).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void reslayer_tail_kernel(const float* __restrict__ x, int64_t ldx, int k_in, int64_t rows,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w2, const int32_t* __restrict__ scatter_rows,
+                                                            const int32_t* __restrict__ valid_count, int per_group,
+                                                            float* __restrict__ out, int64_t ldo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  int64_t dst = i;
+  if (scatter_rows) {
+    if (valid_count && (int)(i % per_group) >= valid_count[i / per_group]) return;     // a padded entry of its group
+    dst = scatter_rows[i];
+  }
+  const float* xr = x + i * ldx;
+  float h[N], s[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    h[n] = b1[n];
+    s[n] = w0 ? b0[n] : xr[n];
+  }
+  for (int k = 0; k < k_in; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const float* a = w1 + (int64_t)n * k_in + k;
+      h[n] = fmaf(v.w, a[3], fmaf(v.z, a[2], fmaf(v.y, a[1], fmaf(v.x, a[0], h[n]))));
+      if (w0) {
+        const float* c = w0 + (int64_t)n * k_in + k;
+        s[n] = fmaf(v.w, c[3], fmaf(v.z, c[2], fmaf(v.y, c[1], fmaf(v.x, c[0], s[n]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) h[n] = (h[n] < 0.0f) ? 0.0f : h[n];        // NaN stays NaN like torch.relu
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    float y = s[n];
+#pragma unroll
+    for (int m = 0; m < N; ++m) y = fmaf(h[m], w2[n * N + m], y);
+    out[dst * ldo + n] = y;
+  }
+}
+
+// out[r] = skip(x[i]) + relu(x[i] W1^T + b1) W2^T for a ResLayer with n_out <= 8 outputs: x float32 [rows, >= k_in] (row stride
+// ldx, a multiple of 4; 16-byte aligned; k_in a multiple of 4), w1 / w0 float32 [n_out, k_in] and w2 float32 [n_out, n_out] as
+// nn.Linear stores them, b1 / b0 float32 [n_out] (b0 carries fc2's bias too, as everywhere in this library; w0 == b0 == NULL:
+// identity skip, k_in == n_out).  r = i, or scatter_rows[i] when given; with valid_count (int32 [rows / per_group]) entry i
+// is skipped unless (i % per_group) < valid_count[i / per_group] -- the padded tail of each scene's kept-pair list
+// (cppf_kept_rows32): only real pairs are written, each exactly once.
+extern "C" int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out, int64_t rows, const float* w1,
+                                  const float* b1, const float* w0, const float* b0, const float* w2,
+                                  const int32_t* scatter_rows, const int32_t* valid_count, int32_t per_group, float* out,
+                                  int64_t ldo, void* stream) {
+  CPPF_CHECK_ARG(x && w1 && b1 && w2 && out && rows >= 0 && n_out >= 1 && n_out <= 8 && ldo >= n_out);
+  CPPF_CHECK_ARG(k_in > 0 && (k_in & 3) == 0 && ldx >= k_in && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0);
+  CPPF_CHECK_ARG((w0 == nullptr) == (b0 == nullptr) && (w0 != nullptr || k_in == n_out));
+  CPPF_CHECK_ARG(valid_count == nullptr || (scatter_rows != nullptr && per_group > 0 && rows % per_group == 0));
+  if (rows == 0) return CPPF_OK;
+  const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define CPPF_TAIL(N)                                                                                                    \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(reslayer_tail_kernel<N>, grid, block, 0, st, x, ldx, k_in, rows, w1, b1, w0, b0, w2, scatter_rows, \
+                       valid_count, per_group, out, ldo);                                                               \
+    break;
+  switch (n_out) {
+    CPPF_TAIL(1) CPPF_TAIL(2) CPPF_TAIL(3) CPPF_TAIL(4) CPPF_TAIL(5) CPPF_TAIL(6) CPPF_TAIL(7) CPPF_TAIL(8)
+  }
+#undef CPPF_TAIL
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

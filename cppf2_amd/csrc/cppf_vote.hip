@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(256) void kept_rows_kernel(int B, const int32_t* __
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / max_kept), j = (int)(i - (int64_t)b * max_kept);
     const int t0 = tup_off[b];
-    rows[i] = (int64_t)t0 + ((j < kept_count[b]) ? kept_tuple[t0 + j] : 0);
+    rows[i] = (j < kept_count[b]) ? (int64_t)t0 + kept_tuple[t0 + j] : (t0 < tup_off[b + 1] ? (int64_t)t0 : 0);
   }
 }
 
@@ -1876,6 +1876,33 @@ extern "C" int cppf_kept_rows(int B, const int32_t* tup_off, const int32_t* kept
   const int64_t n = (int64_t)B * max_kept;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(kept_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, tup_off, kept_tuple, kept_count,
+                     max_kept, rows);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// The same list as int32 (what the gathering MLP kernel and cppf_reslayer_tail index with); entries past a scene's count
+// hold the scene's first tuple row, or row 0 for a scene without tuples: always a valid row, never written through
+// (cppf_reslayer_tail skips them by kept_count).
+__global__ __launch_bounds__(256) void kept_rows32_kernel(int B, const int32_t* __restrict__ tup_off,
+                                                          const int32_t* __restrict__ kept_tuple,
+                                                          const int32_t* __restrict__ kept_count, int max_kept,
+                                                          int32_t* __restrict__ rows) {
+  const int64_t n = (int64_t)B * max_kept;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / max_kept), j = (int)(i - (int64_t)b * max_kept);
+    const int t0 = tup_off[b], t1 = tup_off[b + 1];
+    rows[i] = (j < kept_count[b]) ? t0 + kept_tuple[t0 + j] : (t0 < t1 ? t0 : 0);
+  }
+}
+
+extern "C" int cppf_kept_rows32(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count,
+                                int max_kept, int32_t* rows, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && tup_off && kept_tuple && kept_count && rows && max_kept >= 0);
+  if (max_kept == 0) return CPPF_OK;
+  const int64_t n = (int64_t)B * max_kept;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(kept_rows32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, tup_off, kept_tuple, kept_count,
                      max_kept, rows);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;

@@ -116,7 +116,7 @@ def _fused_plan(seq):
     return plan, c
 
 
-def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
+def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
     """Inference-only execution of a stack of ResLayers (train_shot.py:19-45) on the matrix cores.
     MLP_ARITH == "split" (default): every layer whose shape the kernel covers -- widths 64 / 128 / 192 / 256, input columns
     a multiple of 8 -- runs as ONE cppf_reslayer_split launch together with the identity layers of the same width behind it
@@ -136,7 +136,10 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
     read by the first layer's kernel itself (ops.reslayer_split_gather; split arithmetic, 128-wide projection first layer).
     decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6] | None): the stack's last layer (the logit head's
     192-wide projection layer) draws the bins in its epilogue instead of writing its logits (ops.reslayer_split_decode); the
-    return value is then the bins.  Use decode_supported(seq, x) first."""
+    return value is then the bins.  Use decode_supported(seq, x) first.
+    tail = (rows int32 [n], counts int32 [n / per_group], per_group, out [T, n_out]): the stack's last layer, when it is a narrow
+    one (n_out <= 8: ops.reslayer_tail), writes row i of its result to out[rows[i]], skipping the padded entries of each
+    group (VotingPipeline.kept_rows32 / kept_count / max_kept); returns `out`.  Use tail_supported(seq) first."""
     plan, c = _fused_plan(seq)
     li = 0
     if gather is not None:
@@ -187,6 +190,21 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
             x = ops.reslayer_split(x, entry[5][1], entry[5][2], b0, n_out, out=out, chain=chain)
             li += 1 + chain
             continue
+        if (MLP_ARITH == "split" and n_out <= 8 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0 and w1t.shape[0] % 4 == 0 and x.shape[1] >= w1t.shape[0]
+                and (w0t is not None or w1t.shape[0] == n_out) and (tail is not None or c is None or li + 1 < len(plan))):
+            # a layer too narrow for a matrix-core tile (the scale head's 64 -> 3): plain float32, one thread per row, in the
+            # library (cppf_reslayer_tail); tail = (rows, counts, per_group, out): its rows are scattered into `out` on the way
+            last = li == len(plan) - 1
+            t_ = tail if (tail is not None and last) else None
+            x = ops.reslayer_tail(x, w1t.t(), b1, None if w0t is None else w0t.t(), b0, w2t.t(),
+                                  out=None if t_ is None else t_[3], scatter_rows=None if t_ is None else t_[0],
+                                  valid_count=None if t_ is None else t_[1], per_group=0 if t_ is None else t_[2])
+            li += 1
+            if t_ is not None:
+                assert c is None
+                return x
+            continue
         li += 1
         if (w0t is None and w1t.shape == (128, 128) and x.shape[1] == 128 and x.dtype == torch.float32 and x.is_contiguous()
                 and not (li == 1 and keep_input)):
@@ -206,6 +224,14 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None):
     if c is not None:
         x = x.add_(c)
     return x
+
+
+def tail_supported(seq):
+    """True when fused_stack(seq, ..., tail=...) can scatter the last layer's rows itself: split arithmetic, inference, a
+    projection layer with at most 8 outputs and a multiple of 4 inputs last."""
+    last = seq[len(seq) - 1]
+    return (MLP_ARITH == "split" and not torch.is_grad_enabled() and last.fc0 is not None and last.fc1.out_features <= 8
+            and last.fc1.in_features % 4 == 0)
 
 
 def decode_supported(seq, x):
@@ -309,18 +335,35 @@ class BeyondCPPFShot(nn.Module):
             return fused_stack(self.scale_encoder, feat_rows)
         return self.scale_encoder(feat_rows)
 
-    def scale_head_rows(self, feat, rows):
+    def scale_head_rows(self, feat, rows, scatter=None):
         """scale_head(feat[rows]) without materialising feat[rows]: the scale head's first layer (a 128-wide projection
         layer) reads the selected rows of `feat` through the gathering x-tile fetch of cppf_reslayer_split_gather (a table
-        gather with no pair-feature block).  rows: int64 / int32 [n] tuple rows."""
+        gather with no pair-feature block).  rows: int32 (or int64) [n] tuple rows.
+        scatter = (counts int32 [n / per_group], per_group, out [T, 3]): the result rows are written to out[rows[i]] by the
+        head's last kernel (padded entries of each group skipped) and `out` is returned -- no index_put, no torch kernel."""
         first = self.scale_encoder[0]
         f = feat.shape[1]
         if not (MLP_ARITH == "split" and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
                 and first.fc0 is not None and first.fc1.out_features == 128 and first.fc1.in_features == f
                 and f >= 8 and f & (f - 1) == 0 and feat.shape[0] < 2 ** 31):
-            return self.scale_head(feat[rows])
-        gidx = rows.to(torch.int32).reshape(-1, 1).contiguous()
-        return fused_stack(self.scale_encoder, None, gather=(feat[:, :0], gidx, feat))
+            vals = self.scale_head(feat[rows.long()])
+            if scatter is None:
+                return vals
+            counts, per_group, out = scatter
+            keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
+            out[rows.long()[keep]] = vals[keep]
+            return out
+        gidx = (rows if rows.dtype == torch.int32 else rows.to(torch.int32)).reshape(-1, 1)
+        tail = None
+        if scatter is not None and tail_supported(self.scale_encoder):
+            tail = (gidx.reshape(-1), scatter[0], scatter[1], scatter[2])
+        vals = fused_stack(self.scale_encoder, None, gather=(feat[:, :0], gidx, feat), tail=tail)
+        if scatter is not None and tail is None:
+            counts, per_group, out = scatter
+            keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
+            out[rows.long()[keep]] = vals[keep]
+            return out
+        return vals
 
     def encode_points(self, shot_feat):
         """shot_encoder over the per-point descriptors (train_shot.py:118)."""

@@ -265,6 +265,39 @@ def reslayer128_(x, w1, b1, w2):
     return x
 
 
+def reslayer_tail(x, w1, b1, w0, b0, w2, out=None, scatter_rows=None, valid_count=None, per_group=0):
+    """skip(x) + relu(x W1^T + b1) W2^T for a ResLayer with at most 8 outputs (the scale head's ResLayer(64, 3)) as one plain
+    float32 kernel (cppf_reslayer_tail).  w1 / w0 [n_out, k_in], w2 [n_out, n_out] as nn.Linear stores them; b0 carries fc2's
+    bias.  scatter_rows int32 [rows]: row i is written to out[scatter_rows[i]]; valid_count int32 [rows / per_group]: only
+    entries (i % per_group) < valid_count[i // per_group] are written (the padded kept-pair lists of
+    VotingPipeline.kept_rows32)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows = x.shape[0]
+    n_out, k_in = w1.shape
+    w1, w2, b1 = w1.contiguous(), w2.contiguous(), b1.contiguous()
+    w0 = None if w0 is None else w0.contiguous()
+    b0 = None if b0 is None else b0.contiguous()
+    if out is None:
+        assert scatter_rows is None, "scatter needs the destination buffer"
+        out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[1] >= n_out
+    if scatter_rows is not None:
+        assert scatter_rows.dtype == torch.int32 and scatter_rows.is_contiguous() and scatter_rows.numel() == rows
+    if valid_count is not None:
+        assert valid_count.dtype == torch.int32 and valid_count.is_contiguous() and valid_count.numel() * per_group == rows
+    _lib.check(_L.cppf_reslayer_tail(_p(x), x.stride(0), int(k_in), int(n_out), rows, _p(w1), _p(b1), _p(w0), _p(b0), _p(w2),
+                                     _p(scatter_rows), _p(valid_count), int(per_group), _p(out), out.stride(0), _stream()),
+               "cppf_reslayer_tail")
+    return out
+
+
+def nan_to_zero_(x):
+    """x[isnan(x)] = 0 in place (eval.py:215-216) as a library kernel; x float32, contiguous, on the device."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    _lib.check(_L.cppf_nan_to_zero(_p(x), x.numel(), _stream()), "cppf_nan_to_zero")
+    return x
+
+
 def reslayer_split_supported(k_in, n_out, proj, chain=0):
     """True when cppf_reslayer_split has a kernel for a ResLayer of these dims (k_in = columns of x it reads) followed by
     `chain` identity layers of the same width."""

@@ -167,11 +167,23 @@ class VotingPipeline:
                                      self.max_kept, ops._p(rows), ops._stream()), "cppf_kept_rows")
         return rows
 
+    def kept_rows32(self):
+        """kept_rows() as int32 [B * max_kept] in a buffer allocated once (what the gathering MLP kernel and
+        ops.reslayer_tail index with); a scene's list is padded to max_kept entries with a valid row that is never written."""
+        if getattr(self, "_rows32", None) is None:
+            self._rows32 = torch.empty((self.B * self.max_kept,), dtype=torch.int32, device=self.dev)
+        _lib.check(_L.cppf_kept_rows32(self.B, ops._p(self.tup_off), ops._p(self.kept_tuple), ops._p(self.kept_count),
+                                       self.max_kept, ops._p(self._rows32), ops._stream()), "cppf_kept_rows32")
+        return self._rows32
+
     def scatter_kept(self, rows, values, out=None):
-        """[T, C] buffer holding `values` at `rows` (what assemble() reads for the kept pairs); other rows are untouched."""
+        """[T, C] buffer holding `values` at `rows` (what assemble() reads for the kept pairs); other rows are untouched.
+        Only the real entries of each scene's list are written (the padded ones repeat a row: an index_put with duplicate
+        indices is order-dependent unless the duplicates carry identical values)."""
         if out is None:
             out = torch.zeros((self.Ttot, values.shape[1]), dtype=values.dtype, device=self.dev)
-        out[rows] = values
+        keep = (torch.arange(self.max_kept, device=self.dev)[None, :] < self.kept_count[:, None]).reshape(-1)
+        out[rows.long()[keep]] = values[keep]
         return out
 
     def pose_tensors(self):

@@ -110,8 +110,8 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in zip(scene_ids, Ns)])
     # eval.py:210-216
     shot_feat, normal = shot.compute_device(pts, pipe.pt_off, cfg.res * 10, cfg.res * 10)
-    shot_feat = torch.nan_to_num_(shot_feat, nan=0.0)
-    normal = torch.nan_to_num_(normal, nan=0.0)
+    shot_feat = ops.nan_to_zero_(shot_feat)
+    normal = ops.nan_to_zero_(normal)
     desc = torch.from_numpy(np.concatenate(descs)).to(dev)
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
     prior = priors(idx, base) if priors is not None else None

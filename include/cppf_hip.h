@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 5
+#define CPPF_ABI_VERSION 6
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -113,6 +113,8 @@ int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off, int64_t to
 int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t total_points, const float* normals,
                        float shot_r, int nan_to_zero, float* out_shot, float* out_rf, void* workspace,
                        int64_t workspace_bytes, void* stream);
+/* x[isnan(x)] = 0 in place, n floats: eval.py:216 on the normals (after the descriptor has read them). */
+int cppf_nan_to_zero(float* x, int64_t n, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                           float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);
@@ -248,6 +250,11 @@ int cppf_rot_bins2(int B, const float* pts, const int32_t* pt_off, const int32_t
  * (e.g. the tuple features the scale head runs on, eval.py:272) without reading kept_count on the host. */
 int cppf_kept_rows(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count, int max_kept,
                    int64_t* rows, void* stream);
+/* The same list as int32[B, max_kept] (what cppf_reslayer_split_gather and cppf_reslayer_tail index with); a scene without
+ * tuples pads with row 0.  Padded entries are valid rows to read and are never written through (cppf_reslayer_tail skips
+ * them by kept_count). */
+int cppf_kept_rows32(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count, int max_kept,
+                     int32_t* rows, void* stream);
 
 /* Stand-alone halves with the reference's own signatures (used by the drop-in wrappers):
  * vote_rotation -> up float32[n_valid, num_rots, 3] (valid pairs compacted in order), valid uint8[T];
@@ -313,6 +320,18 @@ int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t st
  * (it commutes with the residual stream).  One kernel on the f32 matrix cores: both products of a 32-row tile stay in
  * registers.  float32 in, float32 accumulate: results differ from a library GEMM's only by summation order. */
 int cppf_reslayer128(float* x, int64_t rows, const float* w1, const float* b1, const float* w2, void* stream);
+
+/* ---- a ResLayer with at most 8 outputs (the scale head's output layer ResLayer(64, 3), train_shot.py:67-71) in plain float32
+ * (fmaf chains in index order: a float32 GEMM up to the summation order, independent of the row count), one thread per row:
+ *     out[r] = skip(x[i]) + relu(x[i, :k_in] W1^T + b1) W2^T,   skip = x W0^T + b0 (b0 carries fc2's bias), or x when w0 == NULL
+ * x float32 [rows, >= k_in], row stride ldx (multiple of 4, 16-byte aligned base), k_in % 4 == 0; w1, w0 float32 [n_out, k_in],
+ * w2 float32 [n_out, n_out] (nn.Linear layout).  r = i, or scatter_rows[i] (int32) when given; with valid_count (int32
+ * [rows / per_group]) entry i is written only if (i % per_group) < valid_count[i / per_group]: the kept-pair lists of
+ * cppf_kept_rows32 (per_group = max_kept, valid_count = kept_count) scattered into a [total_tuples, n_out] buffer, real pairs
+ * only, each exactly once (eval.py:272 reads the scale head's rows of the kept pairs). */
+int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out, int64_t rows, const float* w1, const float* b1,
+                       const float* w0, const float* b0, const float* w2, const int32_t* scatter_rows,
+                       const int32_t* valid_count, int32_t per_group, float* out, int64_t ldo, void* stream);
 
 /* ---- the ResLayers of the models (train_shot.py:19-45; bn = dropout = False), one or several per kernel, on the bf16
  * matrix cores in float32-equivalent arithmetic (every float32 operand is the exact sum of three bf16 values; six

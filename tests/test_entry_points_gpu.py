@@ -322,6 +322,81 @@ def test_lazy_scale_head_equals_the_full_forward():
         got = pipe.results_to_numpy()
     assert np.allclose(got["scale"], want["scale"], atol=1e-6) and np.array_equal(got["R"], want["R"])
     assert np.array_equal(got["kept"], want["kept"])
+    # the same through library kernels only (what bench.py runs): int32 row list, gathered first layer, the 64 -> 3 layer as
+    # cppf_reslayer_tail with the scatter folded into its store -- only real kept pairs are written, each once
+    with torch.no_grad():
+        rows32 = pipe.kept_rows32()
+        assert rows32.dtype == torch.int32 and np.array_equal(rows32.cpu().numpy(), rows.cpu().numpy())
+        buf = torch.full((sum(Ts), 3), float("nan"), device=dev)
+        out = model.scale_head_rows(feat, rows32, scatter=(pipe.kept_count, pipe.max_kept, buf))
+        assert out.data_ptr() == buf.data_ptr()
+        written = ~torch.isnan(buf[:, 0]).cpu().numpy()
+        for b in range(B):
+            exp = np.zeros(Ts[b], bool)
+            exp[kt[off[b]:off[b] + kept[b]]] = True
+            assert np.array_equal(written[off[b]:off[b + 1]], exp), b
+        assert torch.allclose(buf[rows[torch.from_numpy(np.concatenate([np.arange(pipe.max_kept) < k_ for k_ in kept])).to(dev)]],
+                              scales[rows[torch.from_numpy(np.concatenate([np.arange(pipe.max_kept) < k_ for k_ in kept])).to(dev)]],
+                              atol=2e-6, rtol=1e-5)
+        pipe.assemble(torch.nan_to_num(buf))
+        got2 = pipe.results_to_numpy()
+    assert np.allclose(got2["scale"], want["scale"], atol=2e-6) and np.array_equal(got2["R"], want["R"])
+
+
+def test_reslayer_tail_matches_float64_and_scatters_only_valid_rows():
+    """cppf_reslayer_tail (the scale head's ResLayer(64, 3) and other narrow layers) against a float64 evaluation, plain and
+    with the grouped scatter; rows do not depend on the batch they sit in."""
+    from cppf2_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for k_in, n_out, proj in [(64, 3, True), (128, 8, True), (4, 4, False), (8, 1, True)]:
+        x = torch.randn(1000, k_in + 4, generator=g).to(dev)[:, :k_in]            # a strided view (row stride k_in + 4)
+        w1 = (torch.randn(n_out, k_in, generator=g) / k_in ** 0.5).to(dev)
+        w2 = (torch.randn(n_out, n_out, generator=g) / n_out ** 0.5).to(dev)
+        b1 = torch.randn(n_out, generator=g).to(dev)
+        w0 = (torch.randn(n_out, k_in, generator=g) / k_in ** 0.5).to(dev) if proj else None
+        b0 = torch.randn(n_out, generator=g).to(dev) if proj else None
+        xd = x.double()
+        skip = xd @ w0.double().t() + b0.double() if proj else xd
+        want = skip + torch.relu(xd @ w1.double().t() + b1.double()) @ w2.double().t()
+        got = ops.reslayer_tail(x, w1, b1, w0, b0, w2)
+        assert got.shape == (1000, n_out)
+        assert (got.double() - want).abs().max().item() < 3e-6 * max(1.0, want.abs().max().item()), (k_in, n_out)
+        assert torch.equal(ops.reslayer_tail(x[100:107], w1, b1, w0, b0, w2), got[100:107])
+        # grouped scatter: 4 groups of 250 entries, the first counts[g] of each are real
+        counts = torch.tensor([250, 0, 17, 249], dtype=torch.int32, device=dev)
+        dst = torch.randperm(5000, generator=g)[:1000].to(torch.int32).to(dev)
+        out = torch.full((5000, n_out + 1), -7.0, device=dev)
+        ops.reslayer_tail(x, w1, b1, w0, b0, w2, out=out[:, :n_out], scatter_rows=dst, valid_count=counts, per_group=250)
+        keep = (torch.arange(1000, device=dev) % 250) < counts.repeat_interleave(250)
+        exp = torch.full((5000, n_out + 1), -7.0, device=dev)
+        exp[dst.long()[keep], :n_out] = got[keep]
+        assert torch.equal(out, exp)
+    nan = torch.full((3, 64), float("nan"), device=dev)
+    w = torch.zeros(3, 64, device=dev)
+    assert torch.isnan(ops.reslayer_tail(nan, w, torch.zeros(3, device=dev), w, torch.zeros(3, device=dev), torch.zeros(3, 3, device=dev))).all()
+
+
+def test_nan_to_zero_kernel_and_kept_rows_of_an_empty_scene():
+    from cppf2_amd import _lib, ops
+    dev = torch.device("cuda")
+    x = torch.randn(1000, 3, device=dev)
+    x[::7] = float("nan")
+    x[5, 1] = float("inf")
+    want = x.clone()
+    want[torch.isnan(want)] = 0
+    assert torch.equal(ops.nan_to_zero_(x), want) and torch.isinf(x[5, 1])
+    assert ops.nan_to_zero_(torch.empty(0, device=dev)).numel() == 0
+    # a scene without tuples (tup_off[b] == tup_off[b + 1], possibly == total): its padded rows must stay inside the buffer
+    L = _lib.load()
+    tup_off = torch.tensor([0, 5, 5, 9, 9], dtype=torch.int32, device=dev)
+    kept_tuple = torch.tensor([3, 1, 0, 0, 0, 2, 0, 0, 0], dtype=torch.int32, device=dev)
+    kept_count = torch.tensor([2, 0, 1, 0], dtype=torch.int32, device=dev)
+    r32 = torch.empty(4 * 3, dtype=torch.int32, device=dev)
+    r64 = torch.empty(4 * 3, dtype=torch.int64, device=dev)
+    _lib.check(L.cppf_kept_rows32(4, ops._p(tup_off), ops._p(kept_tuple), ops._p(kept_count), 3, ops._p(r32), ops._stream()), "rows32")
+    _lib.check(L.cppf_kept_rows(4, ops._p(tup_off), ops._p(kept_tuple), ops._p(kept_count), 3, ops._p(r64), ops._stream()), "rows")
+    assert r32.tolist() == [3, 1, 0, 0, 0, 0, 7, 5, 5, 0, 0, 0] and r64.tolist() == r32.tolist()
 
 
 def test_encode_tuples_dino_gather_add_equals_linear_over_concatenation():
