@@ -72,7 +72,7 @@ class Cfg:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes-per-gpu", type=int, default=64)
     ap.add_argument("--points", type=int, default=4096)
@@ -94,6 +94,8 @@ def parse():
                          "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
     ap.add_argument("--no-native-arith", action="store_true",
                     help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
+    ap.add_argument("--no-evidence", action="store_true",
+                    help="skip the untimed accuracy evidence (mlp_error_vs_f64, bin_flip_rate_vs_expf)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -291,17 +293,25 @@ def pmc_traffic(stage):
         return None
 
 
+TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false>#large", "reslayer_split_kernel<8, true, false, false>",
+                     "reslayer_split_kernel<8, false, false, false>", "reslayer_split_kernel<6, true, false, true>")
+
+
 def pmc_traffic_mlp():
-    """HBM bytes per step of all cppf_reslayer_split launches (tuple MLP 4, point encoder 2, scale head 2) from the same
-    committed passes; None if absent."""
+    """HBM bytes per step of the tuple MLP's four cppf_reslayer_split launches (the gathered 360 -> 128 chain, 128 -> 256, the
+    two 256-wide identity layers, 256 -> 192 + bin draw: the launches `launch_ms` times) from the committed PMC passes; the
+    gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under its own
+    key (scratch/pmc_bench.sh splits a kernel's dispatches by duration).  None if absent."""
     try:
         cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
         with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
             d = json.load(f)
-        passes = d["vote_worklist_kernel"]["launches"]
-        tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
-                  for k_, v in d.items() if k_.startswith("reslayer_split_kernel"))
-        return tot / passes if tot > 0 else None
+        if TUPLE_MLP_KERNELS[0] not in d:          # a profile written before the split by duration: all launches of a step
+            passes = d["vote_worklist_kernel"]["launches"]
+            tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
+                      for k_, v in d.items() if k_.startswith("reslayer_split_kernel"))
+            return tot / passes if tot > 0 else None
+        return sum((2.0 * d[k_]["FETCH_SIZE_KB_per_launch"] + d[k_]["WRITE_SIZE_KB_per_launch"]) * 1024.0 for k_ in TUPLE_MLP_KERNELS)
     except Exception:
         return None
 
@@ -330,6 +340,58 @@ def cpu_baseline(args, step):
     return dict(value=args.cpu_scenes / dt, unit="scenes/s", cores=cores, kind="port",
                 sample="%d scene(s) of the same workload (first scenes of rank 0's batch), NumPy oracle + C SHOT "
                        "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt)), agree
+
+
+@torch.no_grad()
+def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
+    """Untimed evidence for the line's `dtype` and parity claims, measured on the bench's own tuples (rank 0, after timing):
+    * mlp_error_vs_f64: the tuple MLP's logits (tuple_encoder + logit_encoder, train_shot.py:56-66) of the first `rows_err`
+      tuples in split arithmetic (what the step runs) and on PyTorch's float32 library GEMMs, each against a float64 evaluation
+      of the same weights and rows; errors relative to the largest |logit|;
+    * bin_flip_rate_vs_expf: the bins the decode kernel draws (softmax_exp: hardware exp2, ~1.5 ulp) against the same draw
+      with torch.exp (libm-accurate expf) in the same float32 running-sum order, over `scenes_flip` scenes x T tuples x 6."""
+    import copy
+    from cppf2_amd import models as M
+    ops, pipe, a, dev = step.ops, step.pipe, step.args, step.dev
+    N, T = step.N, step.T
+    sc = min(scenes_flip, step.B)
+    ids = tuple(range(step.scene0, step.scene0 + sc))
+    idx = ops.sample_tuples(N, T, 5, a.seed, ids, dev)
+    pt_off, tup_off = ops._uniform_offsets(N, sc, dev), ops._uniform_offsets(T, sc, dev)
+    feat = step.model.encode_points(step.shot[:sc * N])
+    x = ops.encode_tuples_shot(step.pts[:sc * N], idx, feat, step.normal[:sc * N], pt_off, tup_off)
+    out = {}
+    if M.MLP_ARITH == "split":
+        xe = x[:rows_err].contiguous()
+        m64 = copy.deepcopy(step.model).double()
+        want = m64.logit_encoder(m64.tuple_encoder(xe.double()))
+        scale = want.abs().max().item()
+        split = M.fused_stack(step.model.logit_encoder, M.fused_stack(step.model.tuple_encoder, xe.clone()))
+        native = step.model.logit_encoder(step.model.tuple_encoder(xe))              # plain nn.Linear: library f32 GEMMs
+
+        def err(t):
+            d = t.double() - want
+            return {"max": d.abs().max().item() / scale, "rms": d.pow(2).mean().sqrt().item() / scale}
+        out["mlp_error_vs_f64"] = {"rows": int(xe.shape[0]), "logit_scale": scale, "split_bf16x3": err(split),
+                                   "library_f32_gemm": err(native),
+                                   "note": "relative to max |logit|; split = the arithmetic the timed step runs"}
+    logits = step.model.heads(x, lazy_scale=True)[0].contiguous()                  # [sc*T, 6, 32]
+    u = ops.philox_uniform(T, 6, a.seed, 1, ids, dev)
+    prior = step.prior[:sc * T]
+    got = ops.decode_bins(logits, u, step.pts[:sc * N], idx, Cfg.up, Cfg.front, Cfg.right, pt_off, tup_off, prior=prior)["bins"]
+    e = logits + prior
+    p = torch.exp(e - e.max(-1, keepdim=True).values)
+    cdf = torch.empty_like(p)
+    run = torch.zeros_like(p[..., 0])
+    for j in range(p.shape[-1]):                                                   # the kernel's float32 running sum, in bin order
+        run = run + p[..., j]
+        cdf[..., j] = run
+    target = u.reshape(-1, 6) * run
+    ref = (cdf <= target[..., None]).sum(-1).clamp(max=p.shape[-1] - 1).to(torch.int32)
+    flips = int((ref != got).sum().item())
+    out["bin_flip_rate_vs_expf"] = {"draws": int(ref.numel()), "flips": flips, "rate": flips / ref.numel(),
+                                    "max_bin_distance": int((ref - got).abs().max().item())}
+    return out
 
 
 def self_launch(args):
@@ -491,9 +553,7 @@ def main():
         G = int(np.mean(res["ncell"]))
         mlp_stages = ("shot_encoder", "tuple_mlp", "scale_head")
         hip_stages = [s for s in Step.STAGES if s not in mlp_stages and s != "gather"]
-        # the rotation-vote stage shares the chip with the PyTorch scale head running on a side stream, so its event time
-        # is not the kernel's own (0.26 ms alone, profiles/): the dominant kernel is picked among the stages that run alone
-        shared = set()
+        shared = set()      # every stage runs alone on the one stream (nothing shares the chip with another stage)
         # the HBM roofline object describes the longest of the kernels that ARE bandwidth-bound (section 4 of DESIGN.md); the
         # voting and descriptor kernels (VALU / LDS bound) have their fractions in per_kernel
         hbm_bound = ("decode_bins", "encode_tuples", "sample_tuples")
@@ -551,7 +611,8 @@ def main():
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
-                            launch_ms=mlp_ms_, launches=4,
+                            launch_ms=mlp_ms_, launches=4, frac_kind="executed_bf16_mfma",
+                            traffic_covers="the same 4 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             # the same launch time against the other two readings of "algorithmic / peak"
@@ -586,6 +647,7 @@ def main():
                          centre_argmax_equal=int(sum(int(res["argmax"][b]) == o["argmax"] for b, o in enumerate(outs))),
                          up_bin_equal=int(sum(int(res["up_idx"][b]) == o["up_idx"] for b, o in enumerate(outs))),
                          right_bin_equal=int(sum(int(res["right_idx"][b]) == o["right_idx"] for b, o in enumerate(outs))))
+        evidence = arithmetic_evidence(step) if world == 1 and not args.no_evidence else {}
         total_scenes = B * world * args.steps
         line = {
             "metric": "scenes/sec (1/2/4/8 GPU) at 4096 pts x 20k tuples; 5deg5cm match vs ref",
@@ -618,6 +680,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,
         }
+        line.update(evidence)
         if args.breakdown:
             print("%-22s %10s %12s %10s" % ("stage", "ms/launch", "alg MB", "GB/s"), file=sys.stderr)
             for r in rows:

@@ -72,6 +72,7 @@ SIGNATURES = {
     "cppf_rot_bins2": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _f, _i, _p, _i, _i,
                             _p, _p, _p, _p, _i64, _p]),
     "cppf_kept_rows": (_i, [_i, _p, _p, _p, _i, _p, _p]),
+    "cppf_reslayer_split_debug_grid": (_i, [_i32]),
     "cppf_kept_rows32": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_nan_to_zero": (_i, [_p, _i64, _p]),
     "cppf_reslayer_tail": (_i, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),

@@ -37,6 +37,7 @@
 //     the queue while tiles are in flight.
 // HBM traffic per row: dim_in + dim_out floats per kernel (+ the residual re-read of an identity first layer: L2 / MALL).
 #include "cppf_common.h"
+#include <atomic>
 #include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -649,6 +650,13 @@ extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out,
   return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * RS_TILE_BYTES;
 }
 
+// test hook (tests/test_mlp_split.py race screen): > 0 forces the number of persistent workgroups of every launch
+static std::atomic<int> g_rs_debug_cus{0};
+extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
+  g_rs_debug_cus.store(workgroups > 0 ? workgroups : 0);
+  return CPPF_OK;
+}
+
 template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
@@ -656,6 +664,8 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  const int forced = g_rs_debug_cus.load();
+  if (forced > 0) cus = forced;
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
   {
     // more than 64 KiB of dynamic LDS: declared once per kernel and device

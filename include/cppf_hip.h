@@ -379,6 +379,11 @@ int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, 
                           const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
                           float* scaled, float* scale, float* tr, float* rot, void* stream);
 
+/* Test hook: workgroups > 0 forces the number of persistent workgroups of every later cppf_reslayer_split* launch of this
+ * process (the kernels' results do not depend on it; tests/test_mlp_split.py runs the counted-wait protocol at 1, 7 and all
+ * CUs beside a saturating copy stream); 0 restores one workgroup per CU. */
+int cppf_reslayer_split_debug_grid(int32_t workgroups);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """Writes profiles/<round>_summary.md from the committed rocprofv3 kernel stats, PMC traffic passes and bench line.
 usage: python scratch/profile_table.py [r2]"""
 import csv, json, os, sys
-RND = sys.argv[1] if len(sys.argv) > 1 else "r2"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
 stats = list(csv.DictReader(open(os.path.join(P, RND + "_kernel_stats.csv"))))
@@ -9,12 +9,19 @@ pmc = json.load(open(os.path.join(P, RND + "_pmc_traffic.json")))
 bench = json.load(open(os.path.join(P, RND + "_bench_n1.json")))
 # passes of the step under rocprofv3 = launches of a kernel that runs exactly once per pass (priming + warm-up + timed)
 steps = next(int(r["Calls"]) for r in stats if r["Name"].startswith("vote_worklist_kernel") or "vote_worklist_kernel" in r["Name"])
-rows, gemm_ns, elt_ns = [], 0.0, 0.0
+rows, gemm_ns, elt_ns, setup = [], 0.0, 0.0, []
 for r in stats:
     n = r["Name"]
+    calls = int(r["Calls"])
+    torchy = n.startswith("Cijk") or "rocblas" in n or "at::native" in n or "elementwise" in n or "rocclr" in n
+    if torchy and (calls % steps != 0 or calls < steps):
+        # not launched once (or k times) per pass: one-time work of the priming pass (weight packing: bf16 casts, cat; the
+        # teacher prior; uploads), not part of a steady-state step
+        setup.append((n.split("(")[0].replace("void ", "")[:90], calls, float(r["TotalDurationNs"]) / 1e6))
+        continue
     if n.startswith("Cijk") or "rocblas" in n:
         gemm_ns += float(r["TotalDurationNs"]); continue
-    if "at::native" in n or "elementwise" in n or "rocclr" in n:
+    if torchy:
         elt_ns += float(r["TotalDurationNs"]); continue
     key = n.split("(")[0].replace("void ", "")
     t = pmc.get(key, {})
@@ -46,7 +53,12 @@ with open(os.path.join(P, RND + "_summary.md"), "w") as f:
         f.write("| `%s` | %.0f | %.1f | %.3f | %s | %s |\n" % (k, c, us, c * us / 1e3, "%.1f" % (hbm / 1e6) if hbm else "-",
                                                             "%.0f" % (hbm / 1e9 / (us / 1e6)) if hbm else "-"))
     f.write("| **all HIP kernels** | | | **%.3f** | | |\n" % tot)
-    f.write("| hipBLASLt / rocBLAS GEMMs (PyTorch: the 64 -> 3 output layer of the scale head) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
-    f.write("| PyTorch elementwise / copies | | | %.3f | | |\n" % (elt_ns / steps / 1e6))
+    f.write("| hipBLASLt / rocBLAS GEMMs launched every pass (PyTorch) | | | %.3f | | |\n" % (gemm_ns / steps / 1e6))
+    f.write("| PyTorch elementwise / copy kernels launched every pass | | | %.3f | | |\n" % (elt_ns / steps / 1e6))
+    f.write("\nSetup only (PyTorch / runtime kernels whose call count is not a multiple of the %d passes: weight packing of the "
+            "priming pass, the teacher prior, uploads; not part of a step): %d kernels, %.3f ms in total over the whole run.\n"
+            % (steps, len(setup), sum(x[2] for x in setup)))
+    for nme, calls, ms in sorted(setup, key=lambda x: -x[2])[:8]:
+        f.write("  * `%s` x %d: %.3f ms\n" % (nme, calls, ms))
     f.write("\nPer-stage HIP-event times of the bench (ms per step): `%s`\n" % json.dumps(bench["roofline"]["per_stage_ms"]))
 print(open(os.path.join(P, RND + "_summary.md")).read())

@@ -300,3 +300,62 @@ def test_bin_draw_fused_into_the_output_layer_equals_decode_bins():
             assert not models.decode_supported(net.logit_encoder, feat)
     finally:
         models.MLP_ARITH = prev
+
+
+@pytest.mark.gpu
+def test_counted_wait_protocol_race_screen():
+    """The split kernels keep LDS-DMA tiles in flight across raw s_barriers and wait on hand-computed vmcnt immediates: a slip
+    there is a race that shows up only under memory pressure or at another grid size.  Every instantiation (widths 64 / 128 /
+    192 / 256, identity and projection first layer, the gathering and the bin-drawing kernels; chains 0 / 1 / 4) is run 30 times
+    beside a saturating copy stream with the number of persistent workgroups forced to 1, 7 and one per CU: every output must be
+    bit-identical to the solo run at the default grid (rows do not depend on which workgroup computes them)."""
+    import torch
+    from cppf2_amd import _lib, models, ops
+    L = _lib.load()
+    dev = torch.device("cuda")
+    hog_a = torch.empty(192 << 20, dtype=torch.uint8, device=dev)
+    hog_b = torch.empty_like(hog_a)
+    side = torch.cuda.Stream()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+    def layer(k, n, proj, chain):
+        w1, w2 = mk(n, k) / k ** 0.5, mk(n, n) / n ** 0.5
+        w0 = mk(n, k) / k ** 0.5 if proj else None
+        rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(chain)]
+        return models.pack_split(w1, w0, w2, k, chain=rest), mk((1 + chain) * n) * 0.1, (mk(n) * 0.1 if proj else None)
+
+    cases = []
+    for n in (64, 128, 192, 256):
+        for proj in (False, True):
+            for chain in (0, 1, 4):
+                k = n if not proj else {64: 72, 128: 360, 192: 256, 256: 128}[n]
+                wq, b1, b0 = layer(k, n, proj, chain)
+                cases.append(("n%d proj%d chain%d" % (n, proj, chain),
+                              lambda x, wq=wq, b1=b1, b0=b0, n=n, chain=chain: ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=chain), k))
+    # the gathering first layer (heads 40 + 5 x 64 table columns) with its chain, and the output layer with the bin draw
+    wq_g, b1_g, b0_g = layer(360, 128, True, 4)
+    table = mk(5000, 64)
+    wq_d, b1_d, b0_d = layer(256, 192, True, 0)
+    try:
+        for grid, rows, reps in ((1, 6001, 10), (7, 20011, 30), (0, 150001, 30)):
+            gidx = torch.randint(0, 5000, (rows, 5), generator=g).to(torch.int32).to(dev)
+            uni = torch.rand(rows, 6, generator=g).to(dev)
+            prior = mk(rows, 192)
+            extra = [("gather chain4", lambda x: ops.reslayer_split_gather(x, gidx, table, wq_g, b1_g, b0_g, 128, chain=4), 40),
+                     ("decode", lambda x: ops.reslayer_split_decode(x, wq_d, b1_d, b0_d, uni, prior=prior), 256)]
+            for name, fn, k in cases + extra:
+                x = mk(rows, k)
+                _lib.check(L.cppf_reslayer_split_debug_grid(0), "grid")
+                ref = fn(x)
+                torch.cuda.synchronize()
+                _lib.check(L.cppf_reslayer_split_debug_grid(grid), "grid")
+                for rep in range(reps):
+                    with torch.cuda.stream(side):
+                        hog_b.copy_(hog_a)
+                        hog_a.copy_(hog_b)
+                    got = fn(x)
+                    assert torch.equal(got, ref), (name, "workgroups", grid or "one per CU", "repetition", rep)
+                torch.cuda.synchronize()
+    finally:
+        L.cppf_reslayer_split_debug_grid(0)
