@@ -45,8 +45,9 @@ def _merge(dst, src):
     return dst
 
 
-def load_config(config_dir="config", config_name="config", overrides=()):
-    """Resolves `defaults:` groups and applies `a.b=value` overrides.  Returns a Cfg."""
+def load_config(config_dir="config", config_name="config", overrides=(), with_hydra=False):
+    """Resolves `defaults:` groups and applies `a.b=value` overrides.  Returns a Cfg; with_hydra=True returns (cfg, hydra
+    node) -- the `hydra:` block (run.dir etc., config/config.yaml:16-22) is not part of the cfg the code sees, as with hydra."""
     with open(os.path.join(config_dir, config_name + ".yaml")) as f:
         raw = yaml.safe_load(f) or {}
     groups = {}
@@ -71,8 +72,43 @@ def load_config(config_dir="config", config_name="config", overrides=()):
         for p in parts[:-1]:
             node = node.setdefault(p, {})
         node[parts[-1]] = yaml.safe_load(v)
-    cfg.pop("hydra", None)
+    hydra = cfg.pop("hydra", None) or {}
+    if with_hydra:
+        return _wrap(cfg), _wrap(hydra)
     return _wrap(cfg)
+
+
+def _plain(x):
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    return x
+
+
+def run_dir(cfg, hydra_node=None, default="checkpoints/${cat_name}"):
+    """hydra.run.dir with its ${key} interpolations resolved against the cfg (config/config.yaml:17-18:
+    checkpoints/${cat_name}): the directory the reference's trainers write into."""
+    import re
+    d = default
+    if hydra_node and isinstance(hydra_node.get("run"), dict) and hydra_node["run"].get("dir"):
+        d = str(hydra_node["run"]["dir"])
+
+    def sub(m):
+        node = cfg
+        for part in m.group(1).split("."):
+            node = node[part]
+        return str(node)
+    return re.sub(r"\$\{([^}]+)\}", sub, d)
+
+
+def save_run_config(cfg, directory):
+    """<run dir>/.hydra/config.yaml: the resolved cfg, where eval.py:92,97 (omegaconf.OmegaConf.load) looks for it."""
+    os.makedirs(os.path.join(directory, ".hydra"), exist_ok=True)
+    path = os.path.join(directory, ".hydra", "config.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(_plain(cfg), f, default_flow_style=None, sort_keys=False)
+    return path
 
 
 def load_checkpoint_config(path):

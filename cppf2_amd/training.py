@@ -55,6 +55,46 @@ class SyntheticObjects:
         return item
 
 
+class ExportedItems:
+    """The reference's dumped training items (dataset.py:341-364 reads them, :380-412 writes them): `<data_dir>/{:06d}.pkl`,
+    each a dict with pc [n,3], pc_canon [n,3], desc [n,1024], bound [3], shot [n,352], normal [n,3] (float32; n = 100).
+    The reference draws a file at random per item (dataset.py:357); here the draw is seeded (seed, item index) so that runs
+    are reproducible.  `data_dir=<dir>` on the trainers' command line selects this instead of SyntheticObjects."""
+
+    KEYS = ("pc", "pc_canon", "desc", "bound", "shot", "normal")
+
+    def __init__(self, data_dir, length=200, seed=0):
+        import glob
+        self.files = sorted(glob.glob(os.path.join(data_dir, "*.pkl")))
+        if not self.files:
+            raise FileNotFoundError("no *.pkl training items under %r (dataset.py:344 layout: data/category_training_data/<category>/)" % data_dir)
+        self.length, self.seed = int(length), int(seed)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        import pickle
+        pick = int(np.random.RandomState((self.seed * 1000003 + int(i)) % (2 ** 32)).randint(len(self.files)))
+        with open(self.files[pick], "rb") as f:
+            d = pickle.load(f)
+        return {k: torch.from_numpy(np.ascontiguousarray(np.asarray(d[k], dtype=np.float32))) for k in self.KEYS if k in d}
+
+
+def make_dataset(cfg, with_desc=False):
+    """SyntheticObjects, or the reference's exported items when the command line gives data_dir=<dir>."""
+    length = int(cfg.get("iters_per_epoch", 200))                   # dataset.py:363: 200 items per epoch
+    if cfg.get("data_dir"):
+        return ExportedItems(str(cfg.data_dir), length=length, seed=int(cfg.get("seed", 0)))
+    return SyntheticObjects(cfg, length=length, with_desc=with_desc)
+
+
+def checkpoint_dir(run_directory):
+    """Where Lightning's ModelCheckpoint under TensorBoardLogger(save_dir=<run dir>) puts its files (train_shot.py:136-142),
+    and where eval.py:93,98 reads last.ckpt from."""
+    return os.path.join(run_directory, "lightning_logs", "version_0", "checkpoints")
+
+
 def save_checkpoint(model, path, epoch):
     """Lightning-style container: weights under 'state_dict' with the reference's key names."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)

@@ -50,6 +50,19 @@ def _flag(v):
     return v
 
 
+def load_custom(ckpt_shot=None, ckpt_dino=None, config_dir="config", device=None):
+    """The instance-level setup of the reference's demo (config/custom.yaml: no category group): (cfg, dino, shot)."""
+    dev = device or ops._dev()
+    cfg = load_config(config_dir, "custom", [])
+    dino_model = BeyondCPPFDino(cfg).to(dev).eval()
+    shot_model = BeyondCPPFShot(cfg).to(dev).eval()
+    if ckpt_dino:
+        load_reference_checkpoint(dino_model, ckpt_dino)
+    if ckpt_shot:
+        load_reference_checkpoint(shot_model, ckpt_shot)
+    return cfg, dino_model, shot_model
+
+
 def load_category(cat_name, ckpt_dir=None, ckpt_shot=None, ckpt_dino=None, config_dir="config", device=None):
     """eval.py:87-101 for one category: (cfg, dino_model, shot_model).  With a checkpoint directory each model is built
     from the cfg saved next to its weights (`.hydra/config.yaml`) and the loop keeps the SHOT run's cfg (the last
@@ -174,6 +187,189 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL275 instance loop of the reference (eval.py:103-201, 364-412): detection results -> per-instance clouds -> poses ->
+# one result record per image -> mAP.
+# ---------------------------------------------------------------------------------------------------------------------
+REAL_INTRINSICS = [[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]]           # eval.py:82
+
+
+def load_result_list(log_dir):
+    """eval.py:103-127: every results_*.pkl under log_dir (SAR-Net / Mask-RCNN detections: image_path, pred_bboxes,
+    pred_masks [H,W,n], pred_class_ids, pred_scores, gt_*), a dict or a list of dicts each, flattened in file order."""
+    import glob
+    import pickle
+    paths = sorted(glob.glob(os.path.join(log_dir, "results_*.pkl")))
+    assert len(paths), "no results_*.pkl under %r" % log_dir
+    final_results = []
+    for path in paths:
+        with open(path, "rb") as f:
+            result = pickle.load(f)
+        items = result if isinstance(result, list) else [result]
+        assert all(isinstance(r, dict) for r in items)
+        for r in items:
+            if "gt_handle_visibility" not in r:
+                r["gt_handle_visibility"] = np.ones_like(r["gt_class_ids"])
+            else:
+                assert len(r["gt_handle_visibility"]) == len(r["gt_class_ids"])
+        final_results += items
+    return final_results
+
+
+def crop_transform(bbox, padding=0.0, out_size=256):
+    """The 3x3 crop-frame -> image-frame transform of resize_crop (dataset.py:322-337) for a PIL bbox (left, upper, right,
+    lower): key points of the crop are `inv(transform) @ (x, y, 1)` (eval.py:203)."""
+    width, height = bbox[2] - bbox[0], bbox[3] - bbox[1]
+    size = max(height, width) * (1 + padding)
+    cx, cy = (bbox[2] + bbox[0]) / 2, (bbox[3] + bbox[1]) / 2
+    return (np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.]])
+            @ np.array([[size / out_size, 0, 0], [0, size / out_size, 0], [0, 0, 1]])
+            @ np.array([[1, 0, -out_size / 2], [0, 1, -out_size / 2], [0, 0, 1.]]))
+
+
+def _read_depth(path):
+    from PIL import Image
+    return np.array(Image.open(path)).astype(np.float64)             # cv2.imread(path, -1) of a 16-bit PNG (eval.py:139)
+
+
+def image_instances(res, data_root, cfgs, seed, image_index, intrinsics=REAL_INTRINSICS, token_maps=None):
+    """eval.py:133-203 for one image: yields one dict per detection that reaches the voting path -- instance index i, category,
+    cloud pc float32 [n,3] (back-projected through the mask, flipped, voxel down-sampled at cfg.res, capped at 50 000 points)
+    and desc float32 [n,1024] or None.  Detections of other classes and clouds wider than 1000 cells are skipped like the
+    reference does (their pred_RTs stay the identity)."""
+    from PIL import Image
+    image_path = res["image_path"].replace("data/real/test", data_root)                    # eval.py:133
+    depth = _read_depth(image_path + "_depth.png")
+    masks = np.asarray(res["pred_masks"])
+    rgb = None
+    if os.path.exists(image_path + "_color.png"):
+        rgb = np.array(Image.open(image_path + "_color.png").convert("RGB"))
+    K = np.asarray(intrinsics, dtype=np.float64).reshape(3, 3)
+    for i in range(len(res["pred_bboxes"])):
+        cls_id = int(res["pred_class_ids"][i])
+        cat = id2category.get(cls_id)
+        if cat not in cfgs:                                                                # eval.py:163-165 (whitelist)
+            continue
+        cfg = cfgs[cat]
+        mask = masks[:, :, i] != 0
+        pc, (rr, cc) = ops.backproject(depth / 1000., K, mask, return_device=True)         # eval.py:185-189
+        if pc.shape[0] == 0:
+            continue
+        inst_seed = (seed * 1000003 + image_index * 131 + i) & 0x7FFFFFFF
+        keep = ops.downsample(pc, cfg.res, inst_seed, return_device=True)                   # eval.py:191-193
+        pc, rr, cc = pc[keep], rr[keep.long()], cc[keep.long()]
+        pc = pc.cpu().numpy()
+        idxs = np.stack([rr.cpu().numpy(), cc.cpu().numpy()], -1).astype(np.int64)         # K x 2 (row, col)
+        if pc.shape[0] > 50000:                                                            # eval.py:194-197
+            sub = np.random.RandomState(inst_seed).randint(pc.shape[0], size=(50000,))
+            pc, idxs = pc[sub], idxs[sub]
+        if ((pc.max(0) - pc.min(0)).max() / cfg.res) > 1000:                               # eval.py:199-200
+            continue
+        desc = None
+        tok = None if token_maps is None else token_maps.get("%d_%d" % (image_index, i))
+        if tok is not None:
+            # eval.py:177-183,202-205: crop frame of the masked RGB (its non-zero bounding box; the mask's when the colour
+            # image is absent), key points = pixel (col, row) mapped into the 256 x 256 crop, descriptors = the ViT patch
+            # tokens of the crop (an INPUT of the path: DINOv2 weights are not part of it) sampled there, stride 4 (dataset.py:63)
+            if rgb is not None:
+                masked = np.zeros_like(rgb)
+                masked[mask] = rgb[mask]
+                bbox = Image.fromarray(masked).getbbox()
+            else:
+                bbox = Image.fromarray(mask.astype(np.uint8) * 255).getbbox()
+            transform = crop_transform(bbox, padding=0, out_size=256)
+            kp = np.flip(idxs, -1).astype(np.float64)
+            kp_local = (np.linalg.inv(transform) @ np.concatenate([kp, np.ones((kp.shape[0], 1))], -1).T).T[:, :2]
+            tok = np.asarray(tok, dtype=np.float32)
+            desc = ops.interpolate_features(torch.from_numpy(tok)[None], kp_local.astype(np.float32)[None], strides=4)[0].T
+            desc = desc.contiguous().cpu().numpy()
+        yield dict(i=i, cat=cat, pc=pc, desc=desc, pixels=idxs)
+
+
+def main_nocs(setups, log_dir, data_root="NOCS/real_test", out_dir=None, desc_npz=None, angle_tol=1., imp_wt_margin=0.01,
+              backproj_ratio=.1, num_pairs=50000, num_rots=180, opt=True, geo_branch=True, visual_branch=True, seed=0,
+              batch_instances=16, intrinsics=None, max_images=None, debug=False, out=None):
+    """eval.py:103-412 on a directory in the reference's layout: `log_dir`/results_*.pkl (detections + ground truth per image)
+    and `data_root`/<scene>/<frame>_{depth,color}.png.  Instances are collected image by image exactly as the reference
+    filters them, evaluated in batches per category on the GPU (run_ensemble), and written back into their image's record
+    (pred_RTs, pred_scales: eval.py:143-147, 370-372); every record is pickled under out_dir with the reference's file name
+    (eval.py:134, 399) and the list is scored with degree_cm_mAP (eval.py:400-412).
+    desc_npz: optional .npz of DINOv2 patch-token maps float32 [1024, 64, 64] keyed "<image index>_<instance index>" (the
+    crop of eval.py:177-183 at stride 4); without it seeded unit vectors stand in (the DINO branch then votes on noise)."""
+    import pickle
+    from cppf2_amd import metrics
+    dev = ops._dev()
+    final_results = load_result_list(log_dir)
+    if max_images:
+        final_results = final_results[:int(max_images)]
+    token_maps = np.load(desc_npz) if desc_npz else None
+    cfgs = {c: s[0] for c, s in setups.items()}
+    K = REAL_INTRINSICS if intrinsics is None else intrinsics
+    todo = {c: [] for c in setups}                      # category -> [(image index, instance index, global instance id, pc, desc)]
+    gid = 0
+    for n_img, res in enumerate(final_results):
+        nb = len(res["pred_bboxes"])
+        res["pred_RTs"] = np.stack([np.eye(4) for _ in range(nb)]) if nb else np.zeros((0, 4, 4))      # eval.py:143
+        res["pred_scales"] = np.stack([np.ones((3,)) for _ in range(nb)]) if nb else np.zeros((0, 3))  # eval.py:144
+        for inst in image_instances(res, data_root, cfgs, seed, n_img, K, token_maps):
+            todo[inst["cat"]].append((n_img, inst["i"], gid + inst["i"], inst["pc"], inst["desc"]))
+        gid += nb
+    evaluated = skipped = 0
+    picks = {"dino": 0, "shot": 0, "none": 0}
+    for cat, items in todo.items():
+        cfg, dino_model, shot_model = setups[cat]
+        for lo in range(0, len(items), int(batch_instances)):
+            chunk = items[lo:lo + int(batch_instances)]
+            descs = []
+            for (_, _, g_, pc, desc) in chunk:
+                if desc is None:
+                    gen = torch.Generator(device="cpu").manual_seed(seed * 7919 + g_ + 1)
+                    desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen), dim=-1).numpy()
+                descs.append(desc)
+            r = run_ensemble(cfg, dino_model, shot_model, [c_[3] for c_ in chunk], descs, seed, [c_[2] for c_ in chunk],
+                             num_pairs, num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch,
+                             visual_branch, cat in UP_SYM)
+            for b, (n_img, i, _, _, _) in enumerate(chunk):
+                evaluated += 1
+                if r["pick"][b] < 0:
+                    picks["none"] += 1
+                    continue
+                picks[["dino", "shot"][r["pick"][b]]] += 1
+                rec = r["records"][r["pick"][b]][b]
+                res = final_results[n_img]
+                res["pred_RTs"][i][:3, :3] = rec["R"] * r["scale_norm"][b]                 # eval.py:370
+                res["pred_RTs"][i][:3, -1] = rec["t"]                                      # eval.py:371
+                if r["scale_norm"][b] > 0:
+                    res["pred_scales"][i] = r["scale"][b] / r["scale_norm"][b]              # eval.py:372
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        for res in final_results:
+            image_path = res["image_path"].replace("data/real/test", data_root)
+            with open(os.path.join(out_dir, "_".join(image_path.split("/")[1:]) + ".pkl"), "wb") as f:     # eval.py:134,399
+                pickle.dump(res, f)
+    total = sum(len(r_["pred_bboxes"]) for r_ in final_results)
+    iou_aps, aps = metrics.degree_cm_mAP(final_results, metrics.SYNSET_NAMES, (5, 10, 15), (5, 10, 15),
+                                         np.linspace(0, 1, 101), 0.1, True)                # eval.py:400-411
+    cats = [c for c in setups if todo[c]]
+
+    def mean_over(fn):
+        v = [fn(category2id[c]) for c in cats]
+        v = [x for x in v if np.isfinite(x)]
+        return float(np.mean(v)) if v else None
+    report = dict(data="nocs", images=len(final_results), detections=total, evaluated=evaluated, skipped=total - evaluated,
+                  picked=picks, categories=cats, descriptors="token maps from %s" % desc_npz if desc_npz else "seeded unit vectors (no DINOv2 tokens given)",
+                  pose_AP={"%ddeg_%dcm" % (d_, s_): mean_over(lambda c, i_=i_, j_=j_: aps[c, i_, j_])
+                           for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))},
+                  iou_AP={"IoU%d" % t_: mean_over(lambda c, t_=t_: iou_aps[c, t_]) for t_ in (25, 50, 75)})
+    print(json.dumps(report))
+    if out:
+        with open(out, "w") as f:
+            json.dump(report, f)
+    report["final_results"] = final_results
+    return report
+
+
+
 def _teacher_prior(canon, dev):
     canon = torch.from_numpy(canon).to(dev)
     kb = torch.arange(32, device=dev, dtype=torch.float32)
@@ -188,28 +384,39 @@ def _teacher_prior(canon, dev):
 def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, num_rots=180, opt=True, debug=False,
          use_grounded_sam=False, geo_branch=True, visual_branch=True, data="synthetic", num_scenes=8, num_points=4096,
          category=None, categories=None, seed=0, ckpt_dir=None, ckpt_shot=None, ckpt_dino=None, depth=None, mask=None,
-         intrinsics=None, depth_scale=1000.0, out=None, out_pkl=None):
+         intrinsics=None, depth_scale=1000.0, out=None, out_pkl=None, log_dir=None, data_root="NOCS/real_test", out_dir=None,
+         desc_npz=None, batch_instances=16, max_images=None):
+    custom = False
     if categories is None:
         if category:
             categories = [category]
         elif data == "depth":
-            categories = ["bottle"]                       # a single depth + mask pair is one instance of one category
+            # a single depth + mask pair is one instance; without --category it is an instance-level object like the
+            # reference's example (a YCB object: config/custom.yaml, no category group, full rotation)
+            categories, custom = ["custom"], True
         else:
             categories = [id2category[i] for i in range(1, 7)]                             # eval.py:87-90
     elif isinstance(categories, str):
         categories = [c for c in categories.replace(" ", "").split(",") if c]
-    categories = [c for c in categories if c in WHITELIST]
+    categories = [c for c in categories if c in WHITELIST or custom]
     dev = ops._dev()
     torch.manual_seed(seed)
     # eval.py:84-101: models and cfgs of every category up front
-    setups = {c: load_category(c, ckpt_dir, ckpt_shot, ckpt_dino, device=dev) for c in categories}
+    if custom:
+        setups = {"custom": load_custom(ckpt_shot, ckpt_dino, device=dev)}
+    else:
+        setups = {c: load_category(c, ckpt_dir, ckpt_shot, ckpt_dino, device=dev) for c in categories}
+    if data == "nocs":
+        assert log_dir, "--data=nocs needs --log_dir (the directory of results_*.pkl, eval.py:72-76)"
+        return main_nocs(setups, log_dir, data_root, out_dir, desc_npz, angle_tol, imp_wt_margin, backproj_ratio, num_pairs,
+                         num_rots, opt, geo_branch, visual_branch, seed, batch_instances, intrinsics, max_images, debug, out)
 
     from cppf2_amd import metrics
     summary, all_cls, all_RT, all_scale, all_gt, all_gt_scale = [], [], [], [], [], []
     inst = 0
     for ci, cat in enumerate(categories):
         cfg, dino_model, shot_model = setups[cat]
-        up_sym = cat in UP_SYM
+        up_sym = cat in UP_SYM or bool(cfg.get("up_sym", False))
         # ---- instances ---------------------------------------------------------------------------
         if data == "depth":
             from PIL import Image
@@ -225,11 +432,14 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
             scenes = [dict(pc=pc, pc_canon=None, R=None, t=None)]
         else:
             scenes = [synth.make_scene(seed, inst + s, num_points) for s in range(num_scenes)]
+        made = len(scenes)
+        keep_ids = [inst + j for j, s in enumerate(scenes) if ((s["pc"].max(0) - s["pc"].min(0)).max() / cfg.res) <= 1000]
         scenes = [s for s in scenes if ((s["pc"].max(0) - s["pc"].min(0)).max() / cfg.res) <= 1000]     # eval.py:200
         B = len(scenes)
         if B == 0:
+            inst += made
             continue
-        scene_ids = list(range(inst, inst + B))
+        scene_ids = keep_ids          # a dropped instance does not shift the others' seeds (tuple / uniform streams = scene seed)
         # DINOv2 features are inputs to the path (weights absent): seeded unit vectors stand in for them
         g = torch.Generator(device="cpu").manual_seed(seed + 1 + ci)
         descs = [torch.nn.functional.normalize(torch.randn((s["pc"].shape[0], 1024), generator=g), dim=-1).numpy()
@@ -241,10 +451,10 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         r = run_ensemble(cfg, dino_model, shot_model, [s["pc"] for s in scenes], descs, seed, scene_ids, num_pairs,
                          num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch, visual_branch,
                          up_sym, priors, scale_priors=scale_priors)
-        cls_id = category2id[cat]
+        cls_id = category2id.get(cat, 0)
         for b in range(B):
             RT, sc = np.eye(4), np.ones(3)                                      # eval.py:143-144 defaults
-            item = dict(scene=inst + b, category=cat, model=None)
+            item = dict(scene=scene_ids[b], category=cat, model=None)
             if r["pick"][b] >= 0:                                               # eval.py:367-372
                 rec = r["records"][r["pick"][b]][b]
                 RT[:3, :3] = rec["R"] * r["scale_norm"][b]
@@ -266,7 +476,7 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
                 gt[:3, :3], gt[:3, 3] = scenes[b]["R"] * scenes[b]["diag"], scenes[b]["t"]
                 all_gt.append(gt)
                 all_gt_scale.append(scenes[b]["extent"] / scenes[b]["diag"])
-        inst += B
+        inst += made
 
     report = dict(categories=categories, instances=len(summary),
                   opt_refinement="100 Adam steps (cppf_refine_pose)" if opt else "off", results=summary)
@@ -290,13 +500,17 @@ def main(angle_tol=1., imp_wt_margin=0.01, backproj_ratio=.1, num_pairs=50000, n
         # eval.py:400-411: degree / cm AP over the instances matched at 3-D IoU > 0.1, and the 3-D IoU AP itself
         thr = np.linspace(0, 1, 101)
         iou_aps, aps = metrics.degree_cm_mAP([record], metrics.SYNSET_NAMES, (5, 10, 15), (5, 10, 15), thr, 0.1, True)
-        report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): float(np.mean([aps[category2id[c], i_, j_] for c in categories]))
+        scored_cats = sorted({s_["category"] for s_ in summary if s_["category"] in category2id})
+
+        def _mean(vals):                      # categories without a scored instance have NaN APs: they do not enter the mean
+            vals = [v for v in vals if np.isfinite(v)]
+            return float(np.mean(vals)) if vals else None
+        report["pose_AP"] = {"%ddeg_%dcm" % (d_, s_): _mean([aps[category2id[c], i_, j_] for c in scored_cats])
                              for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
         report["pose_AP_per_category"] = {c: {"%ddeg_%dcm" % (d_, s_): float(aps[category2id[c], i_, j_])
                                               for i_, d_ in enumerate((5, 10, 15)) for j_, s_ in enumerate((5, 10, 15))}
-                                          for c in categories}
-        report["iou_AP"] = {"IoU%d" % t_: float(np.mean([iou_aps[category2id[c], t_] for c in categories]))
-                            for t_ in (25, 50, 75)}
+                                          for c in scored_cats}
+        report["iou_AP"] = {"IoU%d" % t_: _mean([iou_aps[category2id[c], t_] for c in scored_cats]) for t_ in (25, 50, 75)}
     if out_pkl:
         import pickle
         with open(out_pkl, "wb") as f:

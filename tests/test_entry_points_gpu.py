@@ -102,22 +102,160 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     assert rep2["results"][0]["model"] == "shot"
 
 
-def test_train_entry_points_run(tmp_path, monkeypatch):
+def test_train_entry_points_write_the_run_dir_eval_loads(tmp_path, monkeypatch):
+    """train_shot / train_dino -> the reference's run directory (config/config.yaml:16-22 + train_shot.py:136-142:
+    <run dir>/.hydra/config.yaml and lightning_logs/version_0/checkpoints/{epoch=N,last}.ckpt) -> eval.main(ckpt_dir=...)
+    finds cfg and weights of both models through load_category (eval.py:91-99) and evaluates with them."""
     monkeypatch.chdir(tmp_path)
     os.symlink(os.path.join(ROOT, "config"), tmp_path / "config")
     sys.path.insert(0, ROOT)
-    from cppf2_amd.config import load_config
+    from cppf2_amd.config import load_config, load_checkpoint_config
+    import eval as ev
     import train_dino
     import train_shot
-    cfg = load_config("config", "config", ["category=bottle", "max_epochs=1", "iters_per_epoch=3"])
-    m = train_shot.train(cfg)
-    assert all(torch.isfinite(p).all() for p in m.parameters())
-    ck = torch.load(tmp_path / "checkpoints" / "bottle" / "last.ckpt", weights_only=False)
-    assert set(ck["state_dict"]) == set(m.state_dict())
-    m2 = train_dino.train(cfg)
-    assert all(torch.isfinite(p).all() for p in m2.parameters())
+    models = {}
+    for name, mod in (("shot", train_shot), ("dino", train_dino)):
+        cfg, hy = load_config("config", "config", ["category=bottle", "max_epochs=1", "iters_per_epoch=3", "opt.lr=2e-3",
+                                                   "hydra.run.dir=ckpts/%s/${cat_name}-num_more-3" % name], with_hydra=True)
+        m = mod.train(cfg, hy)
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+        run = tmp_path / "ckpts" / name / "bottle-num_more-3"
+        saved = load_checkpoint_config(run / ".hydra" / "config.yaml")
+        assert saved.cat_name == "bottle" and saved.category == 1 and saved.up_sym is True and saved.num_more == 3
+        assert saved.opt.lr == 2e-3 and saved.res == 2e-3 and list(saved.up) == [0, 1, 0] and "hydra" not in saved
+        cdir = run / "lightning_logs" / "version_0" / "checkpoints"
+        assert sorted(os.listdir(cdir)) == ["epoch=0.ckpt", "last.ckpt"]
+        ck = torch.load(cdir / "last.ckpt", weights_only=False)
+        assert set(ck["state_dict"]) == set(m.state_dict())
+        models[name] = m
+    # without an override the run dir is hydra's default, checkpoints/${cat_name}
+    cfg, hy = load_config("config", "config", ["category=mug", "max_epochs=1", "iters_per_epoch=1"], with_hydra=True)
+    train_shot.train(cfg, hy)
+    assert (tmp_path / "checkpoints" / "mug" / ".hydra" / "config.yaml").exists()
+    assert (tmp_path / "checkpoints" / "mug" / "lightning_logs" / "version_0" / "checkpoints" / "last.ckpt").exists()
+    # eval loads exactly those weights
+    cfg_l, dino_l, shot_l = ev.load_category("bottle", ckpt_dir=str(tmp_path / "ckpts"))
+    assert cfg_l.opt.lr == 2e-3
+    for got, want in ((shot_l, models["shot"]), (dino_l, models["dino"])):
+        for (k1, a), (k2, b) in zip(sorted(got.state_dict().items()), sorted(want.state_dict().items())):
+            assert k1 == k2 and torch.equal(a.cpu(), b.cpu()), k1
+    rep = ev.main(num_pairs=4000, num_rots=36, num_scenes=2, num_points=768, opt=False, category="bottle",
+                  ckpt_dir=str(tmp_path / "ckpts"), debug=True)
+    assert rep["instances"] == 2 and all(r["model"] in ("dino", "shot") for r in rep["results"])
     # the reference imports the voting callables from train_dino (eval.py:16)
     assert callable(train_dino.vote_center) and callable(train_dino.vote_rotation) and callable(train_dino.generate_target_pairs)
+
+
+def test_trainers_read_the_reference_exported_items(tmp_path, monkeypatch):
+    """data_dir=<dir>: the {:06d}.pkl items the reference's export writes (dataset.py:404-412) and ShapeNetExportDataset
+    reads (dataset.py:341-364): pc, pc_canon, desc, bound, shot, normal of 100 points."""
+    import pickle
+    monkeypatch.chdir(tmp_path)
+    os.symlink(os.path.join(ROOT, "config"), tmp_path / "config")
+    sys.path.insert(0, ROOT)
+    from cppf2_amd import synth
+    from cppf2_amd.config import load_config
+    from cppf2_amd.training import ExportedItems, make_dataset
+    import train_dino
+    import train_shot
+    rng = np.random.RandomState(0)
+    os.makedirs(tmp_path / "data" / "1")
+    for i in range(4):
+        sc = synth.make_scene(5, i, 100, max_tilt_deg=180.0)
+        desc = rng.randn(100, 1024).astype(np.float32)
+        shot_ = np.abs(rng.randn(100, 352)).astype(np.float32)
+        shot_[3] = np.nan                                             # isolated points come out NaN (src_shot/shot.cpp)
+        item = {"pc": sc["pc"], "pc_canon": sc["pc_canon"], "desc": desc / np.linalg.norm(desc, axis=1, keepdims=True),
+                "bound": np.array([0.2, 0.5, 0.2], np.float32), "shot": shot_,
+                "normal": sc["normal"] if "normal" in sc else np.tile(np.float32([0, 0, 1]), (100, 1))}
+        with open(tmp_path / "data" / "1" / ("%06d.pkl" % (i * 100)), "wb") as f:
+            pickle.dump(item, f)
+    ds = ExportedItems(str(tmp_path / "data" / "1"), length=5, seed=1)
+    it = ds[0]
+    assert set(it) == set(ExportedItems.KEYS) and it["pc"].shape == (100, 3) and it["desc"].shape == (100, 1024)
+    assert it["shot"].dtype == torch.float32 and torch.equal(ds[0]["pc"], it["pc"])             # seeded draw
+    with pytest.raises(FileNotFoundError):
+        ExportedItems(str(tmp_path / "nothing"))
+    cfg, hy = load_config("config", "config", ["category=bottle", "max_epochs=1", "iters_per_epoch=2",
+                                               "data_dir=%s" % (tmp_path / "data" / "1")], with_hydra=True)
+    assert isinstance(make_dataset(cfg), ExportedItems)
+    for mod in (train_shot, train_dino):
+        m = mod.train(cfg, hy)
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def _write_nocs_fixture(root):
+    """Two images / three detections in the reference's REAL275 layout, built from the reference's example frame
+    (tests/golden/example_data: data, not code): <root>/real_test/scene_1/000{0,1}_depth.png (millimetres) and
+    <root>/log/results_*.pkl with the keys eval.py:103-151 reads."""
+    import pickle
+    from PIL import Image
+    d = np.array(Image.open(os.path.join(GOLDEN, "example_data", "depth.png")))
+    m = np.array(Image.open(os.path.join(GOLDEN, "example_data", "mask.png")))
+    m = (m[..., 0] if m.ndim == 3 else m) > 0
+    depth_mm = (d.astype(np.float64) / 10.0).round().astype(np.uint16)           # the example stores 1e-4 m, NOCS 1e-3 m
+    os.makedirs(os.path.join(root, "real_test", "scene_1"))
+    os.makedirs(os.path.join(root, "log"))
+    rows, cols = np.nonzero(m)
+    left = m & (np.arange(m.shape[1])[None, :] < np.median(cols))                 # a second, smaller "detection"
+    for frame in range(2):
+        Image.fromarray(depth_mm).save(os.path.join(root, "real_test", "scene_1", "%04d_depth.png" % frame))
+    bbox = lambda mm: np.array([np.nonzero(mm)[0].min(), np.nonzero(mm)[1].min(), np.nonzero(mm)[0].max(), np.nonzero(mm)[1].max()])
+    gt = np.eye(4)
+    gt[:3, :3] *= 0.25
+    gt[:3, 3] = [0.0, 0.0, 1.0]
+    recs = [dict(image_path="data/real/test/scene_1/0000", pred_bboxes=np.stack([bbox(m), bbox(left), bbox(m)]),
+                 pred_masks=np.stack([m, left, m], -1), pred_class_ids=np.array([1, 6, 0]), pred_scores=np.array([0.9, 0.8, 0.7]),
+                 gt_class_ids=np.array([1, 6]), gt_RTs=np.stack([gt, gt]), gt_scales=np.ones((2, 3)) * 0.5,
+                 gt_bboxes=np.stack([bbox(m), bbox(left)])),
+            dict(image_path="data/real/test/scene_1/0001", pred_bboxes=np.stack([bbox(m)]), pred_masks=m[..., None],
+                 pred_class_ids=np.array([4]), pred_scores=np.array([0.95]), gt_class_ids=np.array([4]), gt_RTs=gt[None],
+                 gt_scales=np.ones((1, 3)) * 0.5, gt_bboxes=bbox(m)[None], gt_handle_visibility=np.array([1]))]
+    with open(os.path.join(root, "log", "results_real_test_scene_1_0000.pkl"), "wb") as f:
+        pickle.dump(recs[0], f)                                       # a dict ...
+    with open(os.path.join(root, "log", "results_real_test_scene_1_0001.pkl"), "wb") as f:
+        pickle.dump([recs[1]], f)                                     # ... or a list of dicts (eval.py:120-125)
+    return recs
+
+
+def test_eval_main_nocs_layout_instance_loop(tmp_path, monkeypatch):
+    """eval.py --data=nocs: the reference's REAL275 loop (eval.py:103-201, 364-412) on a two-image fixture in its layout:
+    results_*.pkl list -> per instance mask -> backproject -> down-sample -> (skip rules) -> both models -> one record per
+    image with pred_RTs / pred_scales filled for the evaluated instances -> pickles under out_dir -> degree_cm_mAP."""
+    import pickle
+    monkeypatch.chdir(ROOT)
+    sys.path.insert(0, ROOT)
+    import eval as ev
+    _write_nocs_fixture(str(tmp_path))
+    rep = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), out_dir=str(tmp_path / "out"),
+                  num_pairs=5000, num_rots=36, opt=False, batch_instances=2)
+    assert rep["images"] == 2 and rep["detections"] == 4
+    assert rep["evaluated"] == 3 and rep["skipped"] == 1                 # class id 0 is not on the whitelist (eval.py:163-165)
+    assert sorted(rep["categories"]) == ["bottle", "can", "mug"] and sum(rep["picked"].values()) == 3
+    res0, res1 = rep["final_results"]
+    assert res0["pred_RTs"].shape == (3, 4, 4) and res0["pred_scales"].shape == (3, 3)
+    assert np.array_equal(res0["pred_RTs"][2], np.eye(4)) and np.array_equal(res0["pred_scales"][2], np.ones(3))   # skipped: defaults
+    for RT in (res0["pred_RTs"][0], res0["pred_RTs"][1], res1["pred_RTs"][0]):
+        assert np.all(np.isfinite(RT)) and 0.8 < RT[2, 3] < 1.2 and not np.array_equal(RT, np.eye(4))
+        assert np.allclose(RT[3], [0, 0, 0, 1])
+    assert "gt_handle_visibility" in res0 and np.array_equal(res0["gt_handle_visibility"], [1, 1])               # eval.py:113-114
+    # one pickle per image under the reference's file name (eval.py:134,399), holding the same record
+    names = sorted(os.listdir(tmp_path / "out"))
+    assert len(names) == 2 and names[0].endswith("scene_1_0000.pkl") and names[1].endswith("scene_1_0001.pkl")
+    back = pickle.load(open(tmp_path / "out" / names[0], "rb"))
+    assert np.array_equal(back["pred_RTs"], res0["pred_RTs"]) and back["image_path"] == "data/real/test/scene_1/0000"
+    assert set(rep["pose_AP"]) == {"%ddeg_%dcm" % (a, b) for a in (5, 10, 15) for b in (5, 10, 15)}
+    assert all(v is None or 0.0 <= v <= 1.0 for v in rep["pose_AP"].values())
+    # the same instance under the same seed gives the same pose whatever batch it sits in (global instance id keys the RNG)
+    rep2 = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), num_pairs=5000, num_rots=36,
+                   opt=False, batch_instances=16)
+    assert np.array_equal(rep2["final_results"][0]["pred_RTs"], res0["pred_RTs"])
+    # DINOv2 patch tokens as an injected input: a [1024, 64, 64] map per instance, sampled at the crop's key points
+    tok = np.random.RandomState(1).randn(1024, 64, 64).astype(np.float32)
+    np.savez(tmp_path / "tok.npz", **{"0_0": tok, "1_0": tok})
+    rep3 = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), num_pairs=3000, num_rots=36,
+                   opt=False, desc_npz=str(tmp_path / "tok.npz"), geo_branch=True, visual_branch=False)
+    assert rep3["evaluated"] == 3 and rep3["picked"]["shot"] == 0
 
 
 def test_eval_main_on_reference_example_depth(monkeypatch):
@@ -132,8 +270,13 @@ def test_eval_main_on_reference_example_depth(monkeypatch):
                   mask=os.path.join(GOLDEN, "example_data", "mask.png"), depth_scale=e["depth_scale"],
                   intrinsics=e["K"], num_pairs=5000, num_rots=36, opt=False, debug=True)
     assert rep["instances"] == 1 and len(rep["results"]) == 1
+    assert rep["categories"] == ["custom"]             # an instance-level object (config/custom.yaml), like the reference's demo
     RT = np.array(rep["results"][0]["pred_RT"])
     assert np.all(np.isfinite(RT)) and 0.8 < RT[2, 3] < 1.2          # the object sits ~1 m in front of the camera
+    rep = ev.main(data="depth", depth=os.path.join(GOLDEN, "example_data", "depth.png"), category="mug",
+                  mask=os.path.join(GOLDEN, "example_data", "mask.png"), depth_scale=e["depth_scale"],
+                  intrinsics=e["K"], num_pairs=3000, num_rots=36, opt=False, debug=True)
+    assert rep["categories"] == ["mug"] and rep["results"][0]["category"] == "mug"
 
 
 def test_hip_graph_replay_of_the_vote_pipeline():

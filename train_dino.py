@@ -12,20 +12,25 @@ import sys
 import torch
 
 from cppf2_amd import ops
-from cppf2_amd.config import load_config
+from cppf2_amd.config import load_config, run_dir, save_run_config
 from cppf2_amd.models import BeyondCPPFDino as BeyondCPPF  # noqa: F401  (name used by the reference's eval.py:17)
 from cppf2_amd.ops import generate_target_pairs, vote_center, vote_rotation  # noqa: F401
-from cppf2_amd.training import SyntheticObjects, cppf_losses, save_checkpoint
+from cppf2_amd.training import checkpoint_dir, cppf_losses, make_dataset, save_checkpoint
 
 
-def train(cfg):
+def train(cfg, hydra_node=None):
     dev = ops._dev()
     model = BeyondCPPF(cfg).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=cfg.opt.lr, weight_decay=cfg.opt.weight_decay)
     sched = torch.optim.lr_scheduler.StepLR(opt, 25, 0.5)
-    ds = SyntheticObjects(cfg, length=int(cfg.get("iters_per_epoch", 200)), with_desc=True)
+    ds = make_dataset(cfg, with_desc=True)
     k = cfg.num_more + 2
-    out_dir = "checkpoints/%s" % cfg.get("cat_name", "custom")
+    # the reference's run directory (config/config.yaml:16-22: hydra.run.dir = checkpoints/${cat_name}): the resolved cfg under
+    # .hydra/config.yaml, the weights under lightning_logs/version_0/checkpoints/{epoch=N,last}.ckpt (train_shot.py:136-142) --
+    # the layout eval.py:91-99 loads a category from
+    run = run_dir(cfg, hydra_node)
+    save_run_config(cfg, run)
+    out_dir = checkpoint_dir(run)
     step = 0
     for epoch in range(int(cfg.get("max_epochs", 101))):
         for i in range(len(ds)):
@@ -49,4 +54,4 @@ def train(cfg):
 
 
 if __name__ == "__main__":
-    train(load_config("config", "config", sys.argv[1:]))
+    train(*load_config("config", "config", sys.argv[1:], with_hydra=True))
