@@ -1303,14 +1303,17 @@ __global__ __launch_bounds__(RB_THREADS) void rot_bins_dense_kernel(
 // float64 accumulator set per voted axis in LDS, and it votes BOTH axes (eval.py:277-293: the up and the right vote
 // share the pair frames and differ only in the angle column) from the same per-pair frames.  The accumulators
 // leave with plain coalesced stores and rot_bins_fold_kernel adds the sub-block sums of a chunk in a fixed order:
-// no global atomics, run-to-run reproducible.
+// no global atomics.  Within a workgroup the votes arrive in thread-scheduling order, so the LDS accumulators are 64-bit
+// FIXED-POINT sums (integer adds commute: run-to-run identical bits, which a float64 atomic sum is not): the scale is the
+// largest power of two that keeps rows_per_block x (largest 1 / weight of the block's pairs) below 2^62, i.e. a resolution of
+// ~2^-62 of the largest possible sum -- at least as fine as the float64 rounding of the sums it replaces.
 #define RW_THREADS 256
 #define RL_K 8             // table slots per cell (int16 bin ids, -1 = empty)
 struct RwFrame {
   float xx, xy, xz, yx, yy, yz, ux, uy, uz;   // in-plane axes, pair direction
   float tn[2];                                // tan of the predicted angle to each voted axis
   int row0;                                   // first row of the pair in vote_rotation's compacted candidate list
-  double inv_wt;
+  double inv_wt;                              // 1 / pair weight; phase 1b overwrites it with its fixed-point image (uint64 bits)
 };
 
 template <int NAX>
@@ -1324,11 +1327,12 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     int bmm_size, double* __restrict__ partial /* [B][gridDim.x][NAX][S] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* s_sph = (float4*)smem;                                     // [S] (x, y, z, -)
-  double* s_acc = (double*)(smem + (size_t)S * 16);                  // [NAX][S]
+  unsigned long long* s_acc = (unsigned long long*)(smem + (size_t)S * 16);   // [NAX][S] fixed-point sums
   float2* s_trig = (float2*)(s_acc + (size_t)NAX * S);               // [num_rots] (cos, sin)
   RwFrame* s_fr = (RwFrame*)(s_trig + num_rots);                     // [max_pairs]
   int* s_list = (int*)(s_fr + max_pairs);                            // [max_pairs] kept-list positions of the block's pairs
   __shared__ int s_n;
+  __shared__ unsigned long long s_maxw;      // bits of the largest 1 / weight of the block's pairs (positive doubles order like integers)
   const int b = blockIdx.y;
   const int chunk = blockIdx.x / sub_blocks, sub = blockIdx.x - chunk * sub_blocks;
   const int64_t lo64 = (int64_t)chunk * bmm_size + (int64_t)sub * rows_per_block;
@@ -1336,7 +1340,10 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
   const int kept = kept_count[b];
   const int t0 = tup_off[b];
   double* out = partial + ((int64_t)b * gridDim.x + blockIdx.x) * NAX * S;
-  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x == 0) {
+    s_n = 0;
+    s_maxw = 0;
+  }
   __syncthreads();
   // pairs with a candidate row in [lo, hi): row0 is increasing over the valid kept pairs, -1 for degenerate ones
   if (lo64 < (int64_t)kept * num_rots) {
@@ -1359,7 +1366,7 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
   const float* p = pts + 3 * (int64_t)pt_off[b];
   for (int i = threadIdx.x; i < S; i += RW_THREADS)
     s_sph[i] = make_float4(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2], 0.0f);
-  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) s_acc[i] = 0.0;
+  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) s_acc[i] = 0ull;
   for (int i = threadIdx.x; i < num_rots; i += RW_THREADS) s_trig[i] = make_float2(cos_tab[i], sin_tab[i]);
   // phase 1: one thread per pair -- frame of the pair (train_dino.py:219-232), tan of its angles, weight
   for (int i = threadIdx.x; i < npairs; i += RW_THREADS) {
@@ -1378,6 +1385,22 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     fr.row0 = kept_row0[t0 + j];
     fr.inv_wt = 1.0 / kept_wt[t0 + j];
     s_fr[i] = fr;
+    if (fr.inv_wt > 0.0 && fr.inv_wt < 1e300) atomicMax(&s_maxw, (unsigned long long)__double_as_longlong(fr.inv_wt));
+  }
+  __syncthreads();
+  // phase 1b: the block's fixed-point scale 2^e with rows_per_block * max(1 / weight) * 2^e < 2^62, and every pair's addend
+  // round(inv_wt * 2^e) (a non-positive / non-finite weight, which the reference would turn into inf / NaN counts, adds 0)
+  int fx_e;
+  {
+    const double bound = (double)rows_per_block * fmax(__longlong_as_double((long long)s_maxw), 1e-300);
+    int eb;
+    frexp(bound, &eb);                        // bound < 2^eb
+    fx_e = 62 - eb;
+  }
+  for (int i = threadIdx.x; i < npairs; i += RW_THREADS) {
+    const double w = s_fr[i].inv_wt;
+    const unsigned long long q = (w > 0.0 && w < 1e300) ? (unsigned long long)__double2ll_rn(ldexp(w, fx_e)) : 0ull;
+    s_fr[i].inv_wt = __longlong_as_double((long long)q);
   }
   __syncthreads();
   const float row_scale = 0.5f * (float)lut_rows, col_scale = (float)lut_cols * 0.15915494309189535f;
@@ -1419,14 +1442,14 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
           if (s >= 0) {
             const float4 q = s_sph[s];
             const float d = fmaf(z, q.z, fmaf(y, q.y, x * q.x));
-            if (d > cos_thr) atomicAdd(&s_acc[a * S + s], fr.inv_wt);
+            if (d > cos_thr) atomicAdd(&s_acc[a * S + s], (unsigned long long)__double_as_longlong(fr.inv_wt));
           }
         }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) out[i] = s_acc[i];
+  for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) out[i] = ldexp((double)s_acc[i], -fx_e);
 }
 
 // float32 counts of one (scene, axis): per chunk, the float64 sum of its sub-block partials in sub-block order, one

@@ -116,6 +116,14 @@ def _fused_plan(seq):
     return plan, c
 
 
+def _entry_cache(entry):
+    """Per-layer cache of packed weight streams and chain lengths, one slot per launch shape (input width, chain | "decode"):
+    alternating callers (with / without the fused bin draw, different input widths) do not evict each other's streams."""
+    if entry[5] is None:
+        entry[5] = {}
+    return entry[5]
+
+
 def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
     """Inference-only execution of a stack of ResLayers (train_shot.py:19-45) on the matrix cores.
     MLP_ARITH == "split" (default): every layer whose shape the kernel covers -- widths 64 / 128 / 192 / 256, input columns
@@ -148,15 +156,19 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         w1t, b1, w0t, b0, w2t = entry[:5]
         k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
         assert MLP_ARITH == "split" and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
-        chain = 0
-        while (1 + chain < len(plan) and plan[1 + chain][2] is None and chain < 15 and plan[1 + chain][0].shape == (128, 128)):
-            chain += 1
+        cache = _entry_cache(entry)
+        chain = cache.get(("gather-chain", k_in))
+        if chain is None:
+            chain = 0
+            while (1 + chain < len(plan) and plan[1 + chain][2] is None and chain < 15 and plan[1 + chain][0].shape == (128, 128)):
+                chain += 1
+            cache[("gather-chain", k_in)] = chain
         key = (k_in, chain)
-        if entry[5] is None or entry[5][0] != key:
+        if key not in cache:
             rest = plan[1:1 + chain]
             wq = pack_split(w1t.t(), w0t.t(), w2t.t(), k_in, chain=[(e[0].t(), e[4].t()) for e in rest])
-            entry[5] = (key, wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
-        x = ops.reslayer_split_gather(heads, gidx, table, entry[5][1], entry[5][2], b0, 128, chain=chain)
+            cache[key] = (wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
+        x = ops.reslayer_split_gather(heads, gidx, table, cache[key][0], cache[key][1], b0, 128, chain=chain)
         li = 1 + chain
     while li < len(plan):
         entry = plan[li]
@@ -164,30 +176,35 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         n_out = w1t.shape[1]
         if (decode is not None and li == len(plan) - 1):
             assert c is None and decode_supported(seq, x), "fused bin draw: see decode_supported"
+            cache = _entry_cache(entry)
             key = (x.shape[1], "decode")
-            if entry[5] is None or entry[5][0] != key:
-                entry[5] = (key, pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
-            return ops.reslayer_split_decode(x, entry[5][1], b1, b0, decode[0], prior=decode[1], bins=decode[2])
+            if key not in cache:
+                cache[key] = (pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
+            return ops.reslayer_split_decode(x, cache[key][0], b1, b0, decode[0], prior=decode[1], bins=decode[2])
         if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.data_ptr() % 16 == 0 and x.shape[1] >= w1t.shape[0]
                 and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
             # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
-            chain = 0
-            while (li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None and chain < 15
-                   and plan[li + 1 + chain][0].shape == (n_out, n_out)
-                   and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, chain + 1)):
-                chain += 1
+            cache = _entry_cache(entry)
+            chain = cache.get(("chain", x.shape[1]))
+            if chain is None:                             # (one library call per candidate layer: looked up once per shape)
+                chain = 0
+                while (li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None and chain < 15
+                       and plan[li + 1 + chain][0].shape == (n_out, n_out)
+                       and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, chain + 1)):
+                    chain += 1
+                cache[("chain", x.shape[1])] = chain
             key = (x.shape[1], chain)
-            if entry[5] is None or entry[5][0] != key:
+            if key not in cache:
                 rest = plan[li + 1:li + 1 + chain]
                 wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1],
                                 chain=[(e[0].t(), e[4].t()) for e in rest])
-                entry[5] = (key, wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
+                cache[key] = (wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
             out = None
             if w0t is None and li == 0 and keep_input:
                 out = torch.empty_like(x)
-            x = ops.reslayer_split(x, entry[5][1], entry[5][2], b0, n_out, out=out, chain=chain)
+            x = ops.reslayer_split(x, cache[key][0], cache[key][1], b0, n_out, out=out, chain=chain)
             li += 1 + chain
             continue
         if (MLP_ARITH == "split" and n_out <= 8 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0

@@ -23,20 +23,31 @@ _WS = {}          # (device, stream) -> scratch buffer
 _PREPARED = {}    # (device, stream) -> (B, n, pts pointer) of the last prepare_device, checked by describe_device
 
 
+WS_CACHE_MAX = 8        # (device, stream) pairs whose scratch buffer stays alive; the least recently used one goes first
+
+
 def _key(dev):
-    return (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+    dev = torch.device(dev)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()     # "cuda" and "cuda:0" are one device
+    return (int(index), int(torch.cuda.current_stream(dev).cuda_stream))
 
 
 def _workspace(B, n, dev):
-    """One cached scratch buffer per (device, stream): grown on demand and reused by every call issued on that stream,
-    so calls on different streams (or threads using their own streams) never share scratch memory."""
+    """One cached scratch buffer per (device index, stream): grown on demand and reused by every call issued on that stream,
+    so calls on different streams (or threads using their own streams) never share scratch memory.  At most WS_CACHE_MAX
+    buffers are kept (least recently used evicted: a process that keeps creating streams does not pin a workspace per
+    stream for its lifetime)."""
     need = _L.cppf_shot352_workspace_bytes(B, n)
     key = _key(dev)
-    ws = _WS.get(key)
+    ws = _WS.pop(key, None)
     if ws is None or ws.numel() < need:
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-        _WS[key] = ws
         _PREPARED.pop(key, None)          # a new buffer holds no prepared state
+    _WS[key] = ws                         # (re-)inserted last: dicts keep insertion order, the first key is the oldest
+    while len(_WS) > WS_CACHE_MAX:
+        old = next(iter(_WS))
+        del _WS[old]
+        _PREPARED.pop(old, None)
     return ws
 
 
