@@ -195,17 +195,14 @@ class Step:
             # train_shot.py:75-83 without its 1.8 GB of rows: pair features + global indices, the first ResLayer gathers
             heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
             self._mark("encode_tuples")
-            tf = fused_stack(self.model.tuple_encoder, None, gather=(heads, gidx, feat))
-            if eager:
-                feat = fused_stack(self.model.scale_encoder, tf)         # the scale head on every tuple
-            drawn = decode_supported(self.model.logit_encoder, tf)
-            if drawn:
-                # eval.py:225-229 as the epilogue of the logit head's output layer: the logits are never written
-                fused_stack(self.model.logit_encoder, tf, keep_input=not eager, decode=(u, self.prior, pipe.bins))
-            else:
-                logits = fused_stack(self.model.logit_encoder, tf, keep_input=not eager).reshape(tf.shape[0], 6, -1)
-            if not eager:
-                feat = tf
+            # tuple encoder + logit head: [gathered 360 -> 128 + 4 x 128] [128 -> 256 (tapped: the tuple features) + 2 x 256]
+            # [256 -> 192 + bin draw]; eval.py:225-229 is the epilogue of the last kernel, the logits are never written
+            drawn = decode_supported(self.model.logit_encoder, feat)
+            res, tf = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), None, gather=(heads, gidx, feat),
+                                  decode=(u, self.prior, pipe.bins) if drawn else None)
+            if not drawn:
+                logits = res.reshape(tf.shape[0], 6, -1)
+            feat = fused_stack(self.model.scale_encoder, tf) if eager else tf       # eager: the scale head on every tuple
         else:
             x = ops.encode_tuples_shot(self.pts, idx, feat, normal, pipe.pt_off, pipe.tup_off)
             self._mark("encode_tuples")
@@ -294,12 +291,12 @@ def pmc_traffic(stage):
 
 
 TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false>#large", "reslayer_split_kernel<8, true, false, false>",
-                     "reslayer_split_kernel<8, false, false, false>", "reslayer_split_kernel<6, true, false, true>")
+                     "reslayer_split_kernel<6, true, false, true>")
 
 
 def pmc_traffic_mlp():
-    """HBM bytes per step of the tuple MLP's four cppf_reslayer_split launches (the gathered 360 -> 128 chain, 128 -> 256, the
-    two 256-wide identity layers, 256 -> 192 + bin draw: the launches `launch_ms` times) from the committed PMC passes; the
+    """HBM bytes per step of the tuple MLP's three cppf_reslayer_split launches (the gathered 360 -> 128 chain; 128 -> 256 with
+    the two 256-wide identity layers behind it; 256 -> 192 + bin draw: the launches `launch_ms` times) from the committed PMC passes; the
     gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under its own
     key (scratch/pmc_bench.sh splits a kernel's dispatches by duration).  None if absent."""
     try:
@@ -311,6 +308,8 @@ def pmc_traffic_mlp():
             tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
                       for k_, v in d.items() if k_.startswith("reslayer_split_kernel"))
             return tot / passes if tot > 0 else None
+        if "reslayer_split_kernel<8, false, false, false>" in d:      # a profile of the four-launch form (rounds 2 - 3a)
+            return None
         return sum((2.0 * d[k_]["FETCH_SIZE_KB_per_launch"] + d[k_]["WRITE_SIZE_KB_per_launch"]) * 1024.0 for k_ in TUPLE_MLP_KERNELS)
     except Exception:
         return None
@@ -594,7 +593,7 @@ def main():
                         per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
         if _models.MLP_ARITH == "split":
-            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 4 launches back to back: the stage
+            # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 3 launches back to back: the stage
             # time is their sum): matrix-core bound.  `achieved` = the bf16 MFMA work it executes (6 exact-product MFMAs per
             # float32 product, K padded to 16) over the stage's HIP-event time, against the dense bf16 peak; the
             # float32-equivalent rate (2 M K N of the layers) is next to it.  The HBM-bound kernel's roofline stays under "hbm".
@@ -611,8 +610,8 @@ def main():
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
-                            launch_ms=mlp_ms_, launches=4, frac_kind="executed_bf16_mfma",
-                            traffic_covers="the same 4 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
+                            launch_ms=mlp_ms_, launches=3, frac_kind="executed_bf16_mfma",
+                            traffic_covers="the same 3 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             # the same launch time against the other two readings of "algorithmic / peak"

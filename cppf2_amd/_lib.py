@@ -86,6 +86,7 @@ SIGNATURES = {
     "cppf_reslayer128": (_i, [_p, _i64, _p, _p, _p, _p]),
     "cppf_reslayer_split_stream_bytes": (_i64, [_i, _i, _i, _i]),
     "cppf_reslayer_split": (_i, [_p, _i64, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
+    "cppf_reslayer_split_tap": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
     "cppf_reslayer_split_decode": (_i, [_p, _i64, _i, _i64, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_decode_from_bins": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_encode_tuples_shot_heads": (_i, [_i, _p, _p, _p, _i, _p, _p, _i64, _p, _i, _p, _p]),

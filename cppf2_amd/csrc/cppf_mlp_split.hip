@@ -497,6 +497,11 @@ __device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDeco
   }
 }
 
+struct RsTap {                  // optional second output: the activation after the FIRST layer of a chained launch
+  float* out;                   // [rows, >= n_out] or NULL
+  int64_t ld;
+};
+
 struct RsGather {               // GATHER launches: see RsX
   const int32_t* gidx;          // [rows, slots] global point indices
   const float* table;           // [points, 1 << fshift]
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
                                                                               const char* __restrict__ wq,
                                                                               const float* __restrict__ b1,
                                                                               const float* __restrict__ b0, int chain,
-                                                                              RsGather ga, RsDecode dc) {
+                                                                              RsGather ga, RsDecode dc, RsTap tap) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
@@ -612,6 +617,18 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     cur = nxt;
     // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
     rs_product_h<NT, NT, PF>(o, h, ws);
+    if (tap.out && in) {                        // the first layer's output is needed in memory as well (the tuple features)
+      float* trow = tap.out + row * tap.ld + 4 * g;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          v.x = o[u][4 * q + 0]; v.y = o[u][4 * q + 1]; v.z = o[u][4 * q + 2]; v.w = o[u][4 * q + 3];
+          *reinterpret_cast<f32x4*>(trow + 32 * u + 8 * q) = v;
+        }
+      }
+    }
     // ---- the identity layers chained behind (same width): y <- y + relu(y W1^T + b1) W2^T with y = the output tiles,
     // never leaving the registers; their W1 is packed in accumulator feature order like every W2
 #pragma unroll 1
@@ -660,7 +677,7 @@ extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
 template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
-                     RsDecode dc = RsDecode()) {
+                     RsDecode dc = RsDecode(), RsTap tap = RsTap()) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -681,7 +698,7 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
     }
   }
   hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx,
-                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc);
+                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc, tap);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
@@ -693,16 +710,18 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
 // 192, 256}.  wq = the layers' weights as the packed split stream (cppf_reslayer_split_stream_bytes bytes;
 // cppf2_amd.models.pack_split documents the order); b1 = float32[(1 + chain) * n_out], the first-layer biases of L_0,
 // L_1, ...  The second-layer biases are the caller's (carried as a pending offset by cppf2_amd.models.fused_stack).
-extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out,
-                                   int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
-                                   int32_t chain, void* stream) {
-  CPPF_CHECK_ARG(x && out && wq && b1 && rows >= 0);
-  CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out);
-  CPPF_CHECK_ARG(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256);
-  CPPF_CHECK_ARG(b0 != nullptr || k_in == n_out);
-  CPPF_CHECK_ARG(chain >= 0 && chain <= 15);
-  CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
-  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr, chain));
+static int rs_dispatch(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
+                       const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, RsTap tap,
+                       void* stream, const char* fn) {
+  if (!(x && out && wq && b1 && rows >= 0) || !(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out) ||
+      !(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256) || !(b0 != nullptr || k_in == n_out) ||
+      !(chain >= 0 && chain <= 15) || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq | (uintptr_t)tap.out) & 15) != 0 ||
+      (tap.out && ((tap.ld & 3) != 0 || tap.ld < n_out)) ||
+      wq_bytes != cppf_reslayer_split_stream_bytes(k_in, n_out, b0 != nullptr, chain)) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: invalid argument (pointers, 16-byte alignment, k_in %% 8, strides %% 4, n_out in "
+             "{64,128,192,256}, chain <= 15, stream size)", fn);
+    return CPPF_EINVAL;
+  }
   if (rows == 0) return CPPF_OK;
   static std::mutex mu;
   static int cus[64] = {0};
@@ -720,16 +739,41 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
   const char* w = static_cast<const char*>(wq);
   hipStream_t st = (hipStream_t)stream;
   const bool proj = b0 != nullptr;
+  const RsGather ga = RsGather();
+  const RsDecode dc = RsDecode();
   switch (n_out / 32) {
-    case 2: return proj ? rs_launch<2, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
-                        : rs_launch<2, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
-    case 4: return proj ? rs_launch<4, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
-                        : rs_launch<4, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
-    case 6: return proj ? rs_launch<6, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
-                        : rs_launch<6, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
-    default: return proj ? rs_launch<8, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st)
-                         : rs_launch<8, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st);
+    case 2: return proj ? rs_launch<2, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap)
+                        : rs_launch<2, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap);
+    case 4: return proj ? rs_launch<4, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap)
+                        : rs_launch<4, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap);
+    case 6: return proj ? rs_launch<6, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap)
+                        : rs_launch<6, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap);
+    default: return proj ? rs_launch<8, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap)
+                         : rs_launch<8, false>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap);
   }
+}
+
+extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out,
+                                   int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
+                                   int32_t chain, void* stream) {
+  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, RsTap(), stream, __func__);
+}
+
+// cppf_reslayer_split with a second output: first_out [rows, >= n_out] (row stride ld_first) receives the activation after the
+// FIRST layer, out the one after the whole chain -- the first layer's result is needed in memory (the tuple features the scale
+// head reads, train_shot.py:112-114) while the identity layers behind it (the logit head's, train_shot.py:62-64) go on in
+// registers: the chain's input is never re-read.  first_out may not alias x or out.
+extern "C" int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in, float* first_out, int64_t ld_first, float* out,
+                                       int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes,
+                                       const float* b1, const float* b0, int32_t chain, void* stream) {
+  if (!first_out || first_out == out || first_out == x) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: first_out must be a buffer of its own", __func__);
+    return CPPF_EINVAL;
+  }
+  RsTap tap;
+  tap.out = first_out;
+  tap.ld = ld_first;
+  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, tap, stream, __func__);
 }
 
 // The first ResLayer of the SHOT model's tuple encoder fed by the tuple encode itself (train_shot.py:75-83 never materialised):

@@ -145,10 +145,34 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
     decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6] | None): the stack's last layer (the logit head's
     192-wide projection layer) draws the bins in its epilogue instead of writing its logits (ops.reslayer_split_decode); the
     return value is then the bins.  Use decode_supported(seq, x) first.
+    seq = (stack_a, stack_b): the two stacks run as one, returning (output of stack_b, output of stack_a): stack_a's last layer
+    (a projection layer) and the identity layers that open stack_b share one kernel whose first layer's result is written to a
+    buffer of its own (ops.reslayer_split(tap=...)) -- the tuple encoder into the logit head, whose input also feeds the scale
+    head (train_shot.py:112-114): the 256-wide features are written once and not read back by the logit head.
     tail = (rows int32 [n], counts int32 [n / per_group], per_group, out [T, n_out]): the stack's last layer, when it is a narrow
     one (n_out <= 8: ops.reslayer_tail), writes row i of its result to out[rows[i]], skipping the padded entries of each
     group (VotingPipeline.kept_rows32 / kept_count / max_kept); returns `out`.  Use tail_supported(seq) first."""
-    plan, c = _fused_plan(seq)
+    tap_at, cross = None, None
+    if isinstance(seq, (tuple, list)):
+        # two stacks run as one: the first one's output is tapped (returned as well) while the identity layers that open the
+        # second continue in the same kernel.  The first stack must end in a projection layer (nothing pending).
+        seq_a, seq_b = seq
+        plan_a, c_a = _fused_plan(seq_a)
+        assert c_a is None, "the first stack must end in a projection layer"
+        plan_b, c = _fused_plan(seq_b)
+        plan = plan_a + plan_b
+        tap_at = len(plan_a) - 1
+        cross = seq_b._fused_plan_cache[0]          # weight versions of the second stack: part of every cross-stack cache key
+        seq = seq_b
+    else:
+        plan, c = _fused_plan(seq)
+    tapped = None
+
+    def cut(li_, chain_):
+        """chain length of a launch starting at layer li_ so that it does not run past the tapped layer unless it starts there"""
+        if tap_at is not None and li_ < tap_at <= li_ + chain_:
+            return tap_at - li_
+        return chain_
     li = 0
     if gather is not None:
         heads, gidx, table = gather
@@ -157,19 +181,24 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
         assert MLP_ARITH == "split" and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
         cache = _entry_cache(entry)
-        chain = cache.get(("gather-chain", k_in))
+        chain = cache.get(("gather-chain", k_in, tap_at, cross))
         if chain is None:
             chain = 0
             while (1 + chain < len(plan) and plan[1 + chain][2] is None and chain < 15 and plan[1 + chain][0].shape == (128, 128)):
                 chain += 1
-            cache[("gather-chain", k_in)] = chain
-        key = (k_in, chain)
+            chain = cut(0, chain)
+            if tap_at == 0:
+                chain = 0                       # (the gathering launch has no second output)
+            cache[("gather-chain", k_in, tap_at, cross)] = chain
+        key = (k_in, chain, cross if tap_at is not None and chain > tap_at else None)
         if key not in cache:
             rest = plan[1:1 + chain]
             wq = pack_split(w1t.t(), w0t.t(), w2t.t(), k_in, chain=[(e[0].t(), e[4].t()) for e in rest])
             cache[key] = (wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
         x = ops.reslayer_split_gather(heads, gidx, table, cache[key][0], cache[key][1], b0, 128, chain=chain)
         li = 1 + chain
+        if tap_at is not None and li - 1 == tap_at:
+            tapped = x
     while li < len(plan):
         entry = plan[li]
         w1t, b1, w0t, b0, w2t = entry[:5]
@@ -180,22 +209,26 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
             key = (x.shape[1], "decode")
             if key not in cache:
                 cache[key] = (pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
-            return ops.reslayer_split_decode(x, cache[key][0], b1, b0, decode[0], prior=decode[1], bins=decode[2])
+            bins = ops.reslayer_split_decode(x, cache[key][0], b1, b0, decode[0], prior=decode[1], bins=decode[2])
+            return bins if tap_at is None else (bins, tapped)
         if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.data_ptr() % 16 == 0 and x.shape[1] >= w1t.shape[0]
                 and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
             # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
             cache = _entry_cache(entry)
-            chain = cache.get(("chain", x.shape[1]))
+            ck = ("chain", x.shape[1], tap_at if tap_at is not None and tap_at >= li else None, cross if tap_at is not None and tap_at >= li else None)
+            chain = cache.get(ck)
             if chain is None:                             # (one library call per candidate layer: looked up once per shape)
                 chain = 0
                 while (li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None and chain < 15
                        and plan[li + 1 + chain][0].shape == (n_out, n_out)
                        and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, chain + 1)):
                     chain += 1
-                cache[("chain", x.shape[1])] = chain
-            key = (x.shape[1], chain)
+                chain = cut(li, chain)
+                cache[ck] = chain
+            crossing = tap_at is not None and li <= tap_at < li + chain           # the launch runs from one stack into the other
+            key = (x.shape[1], chain, cross if crossing else None)
             if key not in cache:
                 rest = plan[li + 1:li + 1 + chain]
                 wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1],
@@ -204,7 +237,17 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
             out = None
             if w0t is None and li == 0 and keep_input:
                 out = torch.empty_like(x)
-            x = ops.reslayer_split(x, cache[key][0], cache[key][1], b0, n_out, out=out, chain=chain)
+            if w0t is None and out is None and tapped is not None and x.data_ptr() == tapped.data_ptr():
+                out = torch.empty_like(x)                 # an in-place identity layer must not overwrite the tapped activation
+            tap_buf = None
+            if tap_at == li and chain > 0:
+                # the tapped layer opens this launch: its output goes to a buffer of its own, the chain's to another
+                tap_buf = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=x.device)
+                if w0t is None and out is None:
+                    out = torch.empty_like(x)
+            x = ops.reslayer_split(x, cache[key][0], cache[key][1], b0, n_out, out=out, chain=chain, tap=tap_buf)
+            if tap_at is not None and li <= tap_at <= li + chain:
+                tapped = tap_buf if tap_buf is not None else x
             li += 1 + chain
             continue
         if (MLP_ARITH == "split" and n_out <= 8 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
@@ -223,6 +266,9 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                 return x
             continue
         li += 1
+        if tap_at is not None and li - 2 == tap_at and tapped is None:
+            tapped = x                                     # (library-GEMM path: layer by layer; the next layer must not overwrite it)
+            x = x.clone() if plan[li - 1][2] is None else x
         if (w0t is None and w1t.shape == (128, 128) and x.shape[1] == 128 and x.dtype == torch.float32 and x.is_contiguous()
                 and not (li == 1 and keep_input)):
             # 128-wide identity-skip layer: both GEMMs, the bias, the ReLU and the residual add in one matrix-core kernel
@@ -240,7 +286,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         x = x.addmm_(h, w2t)
     if c is not None:
         x = x.add_(c)
-    return x
+    return x if tap_at is None else (x, tapped)
 
 
 def tail_supported(seq):
@@ -307,12 +353,11 @@ class BeyondCPPFShot(nn.Module):
         output is only ever read for the pairs that survive the back-vote filter (eval.py:272, ~10 % of the tuples), so a
         caller can run scale_head() on just those rows of `feat` later -- same rows through the same layers."""
         if not torch.is_grad_enabled() and inputs.is_cuda:
-            feat = fused_stack(self.tuple_encoder, inputs)
+            # tuple encoder and logit head as one chain of launches; `feat` (the tuple encoder's output) is tapped for the scale head
+            preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), inputs)
             if lazy_scale:
-                preds_cls = fused_stack(self.logit_encoder, feat, keep_input=True)
                 return preds_cls.reshape(feat.shape[0], 6, -1), feat
             preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
-            preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
             return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
         feat = self.tuple_encoder(inputs)
         preds_scale = self.scale_encoder(feat)
@@ -338,12 +383,12 @@ class BeyondCPPFShot(nn.Module):
         if not (points.is_cuda and self.gather_supported(feat.shape[1], idx.shape[1])):
             return self.heads(ops.encode_tuples_shot(points, idx, feat, normal, pt_off, tup_off), lazy_scale=lazy_scale)
         heads, gidx = ops.encode_tuples_shot_heads(points, idx, normal, pt_off, tup_off)
-        feat = fused_stack(self.tuple_encoder, None, gather=(heads, gidx, feat.contiguous()))
+        draw = decode if (decode is not None and decode_supported(self.logit_encoder, feat)) else None
+        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=(heads, gidx, feat.contiguous()),
+                                      decode=draw)
         second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
-        if decode is not None and decode_supported(self.logit_encoder, feat):
-            fused_stack(self.logit_encoder, feat, keep_input=lazy_scale, decode=decode)
+        if draw is not None:
             return None, second
-        preds_cls = fused_stack(self.logit_encoder, feat, keep_input=lazy_scale)
         return preds_cls.reshape(feat.shape[0], 6, -1), second
 
     def scale_head(self, feat_rows):
@@ -439,12 +484,11 @@ class BeyondCPPFDino(nn.Module):
         runs the stacks as matrix-core kernels (fused_stack), like the SHOT model.  decode: see
         BeyondCPPFShot.heads_from_tuples (None is returned in place of the logits when the bins were drawn)."""
         if not torch.is_grad_enabled() and inputs.is_cuda:
-            feat = fused_stack(self.tuple_encoder, inputs)
+            draw = decode if (decode is not None and decode_supported(self.logit_encoder, inputs)) else None
+            preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), inputs, decode=draw)
             preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
-            if decode is not None and decode_supported(self.logit_encoder, feat):
-                fused_stack(self.logit_encoder, feat, decode=decode)
+            if draw is not None:
                 return None, preds_scale
-            preds_cls = fused_stack(self.logit_encoder, feat)        # identity first layer: overwrites feat
             return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
         feat = self.tuple_encoder(inputs)
         preds_scale = self.scale_encoder(feat)

@@ -304,11 +304,13 @@ def reslayer_split_supported(k_in, n_out, proj, chain=0):
     return k_in % 8 == 0 and _L.cppf_reslayer_split_stream_bytes(int(k_in), int(n_out), int(bool(proj)), int(chain)) > 0
 
 
-def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0):
+def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0, tap=None):
     """out = skip(x) + relu(x W1^T + b1) W2^T, then `chain` identity ResLayers of the same width on the result, on the
     bf16 matrix cores in float32-equivalent split arithmetic (cppf_reslayer_split).  x float32 [rows, k_in] (device; row
     stride a multiple of 4 elements), wq the packed split weight stream (models.pack_split), b1 [(1 + chain) * n_out] (the
-    layers' first biases), b0 [n_out] or None for an identity skip (then out defaults to x: in place).  Returns out."""
+    layers' first biases), b0 [n_out] or None for an identity skip (then out defaults to x: in place).  Returns out.
+    tap: float32 [rows, n_out] buffer that also receives the activation after the FIRST layer (cppf_reslayer_split_tap): the
+    chain behind it continues in registers, its input is never re-read."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     rows, k_in = x.shape
     if out is None:
@@ -317,6 +319,12 @@ def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0):
     b1 = b1.contiguous()
     assert b1.numel() == (1 + chain) * n_out
     b0 = None if b0 is None else b0.contiguous()
+    if tap is not None:
+        assert tap.dtype == torch.float32 and tap.shape == (rows, n_out) and tap.stride(1) == 1
+        _lib.check(_L.cppf_reslayer_split_tap(_p(x), x.stride(0), k_in, _p(tap), tap.stride(0), _p(out), out.stride(0), n_out,
+                                              rows, _p(wq), wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                   "cppf_reslayer_split_tap")
+        return out
     _lib.check(_L.cppf_reslayer_split(_p(x), x.stride(0), k_in, _p(out), out.stride(0), n_out, rows, _p(wq),
                                       wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
                "cppf_reslayer_split")

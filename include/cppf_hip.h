@@ -348,6 +348,13 @@ int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out,
 int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                         const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, void* stream);
+/* The same with a second output: first_out float32 [rows, >= n_out] (row stride ld_first, a multiple of 4; 16-byte aligned; a
+ * buffer of its own) receives the activation after the FIRST layer, out the one after the whole chain -- for a stack whose
+ * intermediate result is read elsewhere (the SHOT / DINO models' 256-wide tuple features feed the scale head,
+ * train_shot.py:112-114) while the identity layers behind it continue in registers. */
+int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in, float* first_out, int64_t ld_first, float* out,
+                            int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
+                            const float* b0, int32_t chain, void* stream);
 
 /* ---- the tuple encode feeding the tuple MLP without materialising its rows (train_shot.py:75-83 -> :100-111): the pair
  * features alone and the tuples' global point indices ...

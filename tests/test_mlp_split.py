@@ -359,3 +359,44 @@ def test_counted_wait_protocol_race_screen():
                 torch.cuda.synchronize()
     finally:
         L.cppf_reslayer_split_debug_grid(0)
+
+
+@pytest.mark.gpu
+def test_tapped_first_layer_equals_the_separate_launches():
+    """cppf_reslayer_split_tap: the first layer's output (the tuple features) and the chain's output are bit-identical to what the
+    two separate launches write (128 -> 256 projection, then two 256-wide identity layers in place); the models' two-stack
+    forward (tuple encoder into logit head) returns both."""
+    from cppf2_amd import models, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(21)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    for k, n, chain in ((128, 256, 2), (360, 128, 4), (72, 64, 1)):
+        w1, w0, w2 = mk(n, k) / k ** 0.5, mk(n, k) / k ** 0.5, mk(n, n) / n ** 0.5
+        rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(chain)]
+        b1, b0 = mk((1 + chain) * n) * 0.1, mk(n) * 0.1
+        x = mk(3001, k)
+        first = ops.reslayer_split(x, models.pack_split(w1, w0, w2, k), b1[:n].contiguous(), b0, n)
+        if chain:
+            wq_rest = models.pack_split(rest[0][0], None, rest[0][1], n, chain=rest[1:])
+            want = ops.reslayer_split(first.clone(), wq_rest, b1[n:].contiguous(), None, n, chain=chain - 1)
+        tap = torch.full((3001, n), float("nan"), device=dev)
+        got = ops.reslayer_split(x, models.pack_split(w1, w0, w2, k, chain=rest), b1, b0, n, chain=chain, tap=tap)
+        assert torch.equal(tap, first) and torch.equal(got, want), (k, n, chain)
+    with pytest.raises(Exception):
+        ops.reslayer_split(x, models.pack_split(w1, w0, w2, k, chain=rest), b1, b0, n, out=tap, chain=chain, tap=tap)
+    # the models: heads() through the two-stack form == the stacks one after the other
+    class Cfg:
+        num_more = 3
+    torch.manual_seed(2)
+    net = models.BeyondCPPFShot(Cfg()).to(dev).eval()
+    xin = mk(5000, 360) * 0.3
+    with torch.no_grad():
+        cls, feat = net.heads(xin.clone(), lazy_scale=True)
+        feat_want = models.fused_stack(net.tuple_encoder, xin.clone())
+        cls_want = models.fused_stack(net.logit_encoder, feat_want.clone())
+        assert torch.equal(feat, feat_want) and torch.equal(cls.reshape(5000, -1), cls_want)
+        # the logit head's weights change: the cross-stack weight stream is rebuilt (cache keyed by both stacks' versions)
+        net.logit_encoder[0].fc1.weight.mul_(1.5)
+        cls2, _ = net.heads(xin.clone(), lazy_scale=True)
+        assert torch.equal(cls2.reshape(5000, -1), models.fused_stack(net.logit_encoder, feat_want.clone()))
+        assert not torch.equal(cls2, cls)
