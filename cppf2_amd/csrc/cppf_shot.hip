@@ -404,8 +404,14 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
                                                       double* __restrict__ sums /* [Ntot][NSUM] */,
                                                       int32_t* __restrict__ nbr_list /* [Ntot][NBR_CAP] */,
                                                       int32_t* __restrict__ nbr_cnt /* [Ntot] */) {
-  __shared__ double s_part[NSUM][64 + 1];       // + 1: the columns' rows start in different banks (the serial sums below
-                                                 // read one row per lane group; unpadded, all 19 rows alias: 19-way conflicts)
+  // The reduction buffer holds 32 partials per column (the two lane halves are added through a cross-lane exchange first), rows
+  // padded by one entry so that the columns start in different banks.  The same LDS first holds the compacted neighbours.
+  // 5 KiB per wavefront: eight wavefronts per SIMD fit (at 9.9 KiB -- 64 partials per column -- it was four, and this kernel
+  // spends 40 % of its cycles waiting for its gathers: throughput follows occupancy).
+  constexpr int COV_LIST = NSUM * (32 + 1) * 8 / 16;           // neighbours the LDS list holds (313); beyond: direct sums
+  __shared__ __attribute__((aligned(16))) double s_raw[NSUM * (32 + 1)];
+  double (*s_part)[32 + 1] = reinterpret_cast<double (*)[32 + 1]>(s_raw);
+  float4* s_nb = reinterpret_cast<float4*>(s_raw);
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   const int b = scene_of[qi];
@@ -421,8 +427,10 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
   // The 9 runs are walked as ONE flat candidate range (no partly filled wavefront per run), the next 64 candidates are
-  // requested before the current 64 are processed, and the covariance sums are accumulated in the same sweep (the
-  // in-radius tests live in cov_accumulate); the compacted list only serves shot_hist.
+  // requested before the current 64 are tested.  Only about a fifth of the candidates lie inside the larger radius: the sweep
+  // just tests them in float32 and compacts the hits (ballot + prefix popcount) into LDS -- and into the workspace for
+  // shot_hist, which needs the same neighbours -- and the float64 covariance sums then run over the dense list (two wavefront
+  // passes for the usual ~90 neighbours instead of seven over the candidates: the kernel is bound by its float64 VALU work).
   int base[10];
   base[0] = 0;
 #pragma unroll
@@ -435,43 +443,59 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
     return j;
   };
   int m = 0;
-  int jn = (lane < C) ? cand(lane) : 0;
-  float4 qn = sp[jn];
-  for (int fb = 0; fb < C; fb += 64) {
-    const float4 qv = qn;
-    const int j = jn;
-    const bool valid = fb + lane < C;
-    const int fnext = fb + 64 + lane;
-    if (fb + 64 < C) {
-      jn = (fnext < C) ? cand(fnext) : 0;
-      qn = sp[jn];
+  {
+    int jn = (lane < C) ? cand(lane) : 0;
+    float4 qn = sp[jn];
+    for (int fb = 0; fb < C; fb += 64) {
+      const float4 qv = qn;
+      const int j = jn;
+      const bool valid = fb + lane < C;
+      const int fnext = fb + 64 + lane;
+      if (fb + 64 < C) {
+        jn = (fnext < C) ? cand(fnext) : 0;
+        qn = sp[jn];
+      }
+      const bool in = valid && sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < COV_LIST) s_nb[pos] = qv;
+        if (pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
+      }
+      m += __popcll(mask);
     }
-    bool in = false;
-    if (valid) {
-      in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
-      cov_accumulate(qv, px, py, pz, rn2, rs2, rs, a);
-    }
-    const unsigned long long mask = __ballot(in);
-    if (in) {
-      const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
-    }
-    m += __popcll(mask);
   }
+  __syncthreads();
+  if (m <= COV_LIST) {
+    for (int c = lane; c < m; c += 64) cov_accumulate(s_nb[c], px, py, pz, rn2, rs2, rs, a);
+  } else {
+    // more neighbours than the list holds (a support radius far above the cloud's resolution): the sums straight from the runs
+    for (int fb = 0; fb < C; fb += 64)
+      if (fb + lane < C) cov_accumulate(sp[cand(fb + lane)], px, py, pz, rn2, rs2, rs, a);
+  }
+  __syncthreads();                                 // the list is dead: its LDS becomes the reduction buffer
   if (nbr_cnt && lane == 0) {
     nbr_cnt[qi] = m;
     if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
   }
 #pragma unroll
-  for (int c = 0; c < NSUM; ++c) s_part[c][lane] = a[c];
+  for (int c = 0; c < NSUM; ++c) {
+    a[c] += __shfl_xor(a[c], 32);                  // lane l < 32: its own partial + lane l + 32's
+    if (lane < 32) s_part[c][lane] = a[c];
+  }
   __syncthreads();
-  // column sums in a fixed order (run-to-run reproducible): three lanes per column add a third of the 64 partials each,
-  // the first of them adds the three thirds
+  // column sums in a fixed order (run-to-run reproducible): three lanes per column add a third of the 32 partials each,
+  // the first of them adds the three thirds.  All partials of a lane are requested first, then added in index order (as a
+  // load-add loop every addition waits out one LDS round trip); entries past the end add an exact 0.0.
   {
     const int c = min(lane / 3, NSUM - 1), part = lane - 3 * (lane / 3);
-    const int lo = part * 22, hi = min(64, lo + 22);
+    const int lo = part * 11, hi = min(32, lo + 11);
+    double v[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) v[i] = s_part[c][min(lo + i, 31)];
     double t = 0.0;
-    for (int l = lo; l < hi; ++l) t += s_part[c][l];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) t += (lo + i < hi) ? v[i] : 0.0;
     const double t1 = __shfl_down(t, 1), t2 = __shfl_down(t, 2);
     if (lane < 3 * NSUM && part == 0) sums[(int64_t)qi * NSUM + c] = (t + t1) + t2;
   }

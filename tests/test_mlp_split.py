@@ -363,9 +363,10 @@ def test_counted_wait_protocol_race_screen():
 
 @pytest.mark.gpu
 def test_tapped_first_layer_equals_the_separate_launches():
-    """cppf_reslayer_split_tap: the first layer's output (the tuple features) and the chain's output are bit-identical to what the
-    two separate launches write (128 -> 256 projection, then two 256-wide identity layers in place); the models' two-stack
-    forward (tuple encoder into logit head) returns both."""
+    """cppf_reslayer_split_tap: the first layer's output (the tuple features) is bit-identical to what that layer's own launch
+    writes; the chain's output equals the separate launches' (128 -> 256 projection, then two 256-wide identity layers) up to
+    the summation order -- a layer fed from memory contracts its K steps in another feature order than one fed from the
+    accumulators --, i.e. to float32 rounding; the models' two-stack forward (tuple encoder into logit head) returns both."""
     from cppf2_amd import models, ops
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(21)
@@ -381,7 +382,10 @@ def test_tapped_first_layer_equals_the_separate_launches():
             want = ops.reslayer_split(first.clone(), wq_rest, b1[n:].contiguous(), None, n, chain=chain - 1)
         tap = torch.full((3001, n), float("nan"), device=dev)
         got = ops.reslayer_split(x, models.pack_split(w1, w0, w2, k, chain=rest), b1, b0, n, chain=chain, tap=tap)
-        assert torch.equal(tap, first) and torch.equal(got, want), (k, n, chain)
+        assert torch.equal(tap, first), (k, n, chain)
+        assert (got - want).abs().max().item() < 4e-6 * max(1.0, want.abs().max().item()), (k, n, chain)
+        again = ops.reslayer_split(x, models.pack_split(w1, w0, w2, k, chain=rest), b1, b0, n, chain=chain)     # no tap: same chain
+        assert torch.equal(got, again)
     with pytest.raises(Exception):
         ops.reslayer_split(x, models.pack_split(w1, w0, w2, k, chain=rest), b1, b0, n, out=tap, chain=chain, tap=tap)
     # the models: heads() through the two-stack form == the stacks one after the other
@@ -394,9 +398,11 @@ def test_tapped_first_layer_equals_the_separate_launches():
         cls, feat = net.heads(xin.clone(), lazy_scale=True)
         feat_want = models.fused_stack(net.tuple_encoder, xin.clone())
         cls_want = models.fused_stack(net.logit_encoder, feat_want.clone())
-        assert torch.equal(feat, feat_want) and torch.equal(cls.reshape(5000, -1), cls_want)
+        assert torch.equal(feat, feat_want)
+        assert (cls.reshape(5000, -1) - cls_want).abs().max().item() < 4e-6 * max(1.0, cls_want.abs().max().item())
         # the logit head's weights change: the cross-stack weight stream is rebuilt (cache keyed by both stacks' versions)
         net.logit_encoder[0].fc1.weight.mul_(1.5)
         cls2, _ = net.heads(xin.clone(), lazy_scale=True)
-        assert torch.equal(cls2.reshape(5000, -1), models.fused_stack(net.logit_encoder, feat_want.clone()))
-        assert not torch.equal(cls2, cls)
+        cls2_want = models.fused_stack(net.logit_encoder, feat_want.clone())
+        assert (cls2.reshape(5000, -1) - cls2_want).abs().max().item() < 4e-6 * max(1.0, cls2_want.abs().max().item())
+        assert (cls2 - cls).abs().max().item() > 1e-3
