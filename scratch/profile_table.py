@@ -26,10 +26,16 @@ for r in stats:
     key = n.split("(")[0].replace("void ", "")
     t = pmc.get(key, {})
     hbm = (2 * t.get("FETCH_SIZE_KB_per_launch", 0) + t.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 if t else None
+    if not t and key + "#large" in pmc:
+        # the PMC passes split this kernel's dispatches by duration (the gathering MLP kernel: tuple encoder + scale head):
+        # launch-weighted mean over both classes, like the stats row's average
+        parts = [pmc[key + sfx] for sfx in ("#large", "#small") if key + sfx in pmc]
+        nl = sum(p_["launches"] for p_ in parts)
+        hbm = sum((2 * p_["FETCH_SIZE_KB_per_launch"] + p_["WRITE_SIZE_KB_per_launch"]) * 1024 * p_["launches"] for p_ in parts) / nl
     rows.append((key, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, hbm))
 rows.sort(key=lambda x: -x[1] * x[2])
 with open(os.path.join(P, RND + "_summary.md"), "w") as f:
-    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith`, %d passes incl. priming)\n\n" % (RND, steps))
+    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence`, %d passes incl. priming)\n\n" % (RND, steps))
     f.write("Sources: `%s_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `%s_pmc_traffic.json` = "
             "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (KB per launch; HBM bytes = "
             "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `%s_bench_n1.json` = the bench line of the same build. "
