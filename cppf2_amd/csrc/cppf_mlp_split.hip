@@ -659,6 +659,12 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       }
     }
   }
+  // Nothing may be in flight when the wavefront ends: the pieces issued during the last chunk (plan() past the end: a re-read of
+  // the stream's first KiB, kept so that every chunk issues the same number of operations) are LDS-DMA loads, and an LDS-DMA
+  // load that lands after s_endpgm writes into LDS that may already belong to ANOTHER workgroup (observed: a rotation-vote
+  // workgroup starting on the CU while the last wavefronts of a 512-register MLP workgroup were leaving had the first KiB of
+  // its LDS -- sphere bins 0..62 -- overwritten by weight bytes, scratch/rot_race_probe3.py).
+  RS_WAIT(0, 15);
 }
 
 extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
