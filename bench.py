@@ -94,6 +94,8 @@ def parse():
                          "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
     ap.add_argument("--no-native-arith", action="store_true",
                     help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time the steps alternating between two HIP streams (experimental; reported under two_streams)")
     ap.add_argument("--no-evidence", action="store_true",
                     help="skip the untimed accuracy evidence (mlp_error_vs_f64, bin_flip_rate_vs_expf)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
@@ -533,6 +535,36 @@ def main():
         dt_native, _ = timed_loop(args.steps, sample=False)
         _models.MLP_ARITH = "split"
 
+    # Experimental, not the headline: consecutive steps (independent scene batches) alternating between TWO HIP streams, each
+    # with its own buffers, so that one step's descriptor / voting kernels run beside the other's matrix-core kernels.  Same loop
+    # protocol; both pipelines process the same scenes, and their records must be byte-identical to the single-stream ones.
+    two = None
+    if args.two_streams and world == 1:
+        step.run()
+        torch.cuda.synchronize()
+        ref_rec = step.pipe.results.clone()
+        step_b = Step(args, rank, world, dev)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pair = [step, step_b]
+        for s_, st_ in zip(pair, streams):
+            with torch.cuda.stream(st_):
+                s_.run()
+                s_.run()
+        k2 = args.steps
+        sync()
+        t0 = time.perf_counter()
+        for i_ in range(k2):
+            with torch.cuda.stream(streams[i_ & 1]):
+                pair[i_ & 1].run()
+        sync()
+        dt2 = time.perf_counter() - t0
+        same = bool(torch.equal(step.pipe.results, ref_rec) and torch.equal(step_b.pipe.results, ref_rec))
+        two = {"value": step.B * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+               "records_identical_to_single_stream": same,
+               "note": "experimental: steps alternate between two HIP streams (double-buffered); the library is validated for one "
+                       "stream per process (DESIGN.md section 11)"}
+        del step_b
+
     if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
         for i_, ev in enumerate(evs):
             row = {n1: round(e0.elapsed_time(e1), 3) for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:])}
@@ -670,6 +702,8 @@ def main():
                 (total_scenes / dt_other) if dt_other else None,
             # the same run with the MLP on the f32-input matrix instruction (no operand splitting)
             "value_f32_input_mfma": (total_scenes / dt_native) if dt_native else None,
+            # experimental: the same steps alternating between two HIP streams (not the headline; see the note inside)
+            "two_streams": two,
             "records_gathered": int(all_rec.shape[0]),
             # the path's one collective: all_gather of the 160-byte scene records, HIP-event time of the stage
             "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
