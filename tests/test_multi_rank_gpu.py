@@ -60,6 +60,28 @@ def test_records_do_not_depend_on_the_world_size():
         assert np.linalg.norm(want["t"][b] - whole.scenes[b]["t"]) < 5e-3
 
 
+def test_two_streams_give_the_single_stream_records():
+    """Consecutive steps alternating between two HIP streams (bench.py --two-streams), each pipeline with its own buffers: the
+    records of both must be byte-identical to a sequential run -- the library keeps no global device state, every entry point
+    takes its stream, the SHOT scratch buffer is per (device, stream).  (Regression guard for DESIGN.md section 11: the
+    rotation-vote kernel once produced different votes when it shared a CU with the MLP workgroups of the other stream.)"""
+    import bench
+    dev = torch.device("cuda")
+    a = _args(16, points=4096, tuples=20000, rots=180)
+    steps = [bench.Step(a, 0, 1, dev) for _ in range(2)]
+    steps[0].run()
+    torch.cuda.synchronize()
+    want = steps[0].pipe.results.clone()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for trial in range(3):
+        for i in range(6):
+            with torch.cuda.stream(streams[i & 1]):
+                steps[i & 1].run()
+        torch.cuda.synchronize()
+        for s in steps:
+            assert torch.equal(s.pipe.results, want), trial
+
+
 def _job(name):
     from conftest import BENCH2
     if "jobs" not in BENCH2:
