@@ -8,22 +8,43 @@ thread_local char g_cppf_err[256];
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __device__ __forceinline__ unsigned hashu(unsigned a) { a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16; return a; }
-// barrier victim: every wavefront publishes a value, __syncthreads(), every thread checks the other wavefronts' values
+// mixed victim (the rotation-vote kernel's phase 2): random-index 16-byte and 8-byte LDS reads, each checked, interleaved with
+// 64-bit LDS atomics to another region from every wavefront; the atomic totals are checked at the end
 __global__ __launch_bounds__(256) void victim_kernel(unsigned* bad, unsigned* first_off, unsigned* first_val, int spins) {
-  extern __shared__ unsigned v_tab[];                    // padding to 32 KiB so that the placement equals the rotation kernel's
-  for (int s = 0; s < spins * 40; ++s) {
-    v_tab[threadIdx.x] = hashu(blockIdx.x * 7919u + s * 257u + threadIdx.x);
-    __syncthreads();
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const unsigned t = (threadIdx.x + 64 * k) & 255u;
-      const unsigned got = v_tab[t], want = hashu(blockIdx.x * 7919u + s * 257u + t);
-      if (got != want) {
-        if (atomicAdd(bad, 1u) == 0) { *first_off = s; *first_val = got; }
-      }
+  extern __shared__ uint4 v_tab[];                       // 1280 entries = 20 KiB, then 1440 x 8 B of accumulators (11.25 KiB)
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(v_tab + 1280);
+  for (int i = threadIdx.x; i < 1280; i += 256) v_tab[i] = make_uint4(0xA5000000u ^ i, 0x5A000000u ^ i, 0x3C000000u ^ i, 0xC3000000u ^ i);
+  for (int i = threadIdx.x; i < 1440; i += 256) acc[i] = 0ull;
+  __syncthreads();
+  const unsigned long long* v64 = reinterpret_cast<const unsigned long long*>(v_tab);
+  unsigned long long mine = 0;
+  for (int s = 0; s < spins * 16; ++s) {
+    const unsigned h = hashu(blockIdx.x * 7919u + threadIdx.x * 131u + s);
+    const unsigned i = h % 1280u, j = (h >> 11) % 2560u;
+    const uint4 q = v_tab[i];
+    const unsigned long long w = v64[j];
+    const unsigned long long want = (j & 1) ? (((unsigned long long)(0xC3000000u ^ (j >> 1)) << 32) | (0x3C000000u ^ (j >> 1)))
+                                            : (((unsigned long long)(0x5A000000u ^ (j >> 1)) << 32) | (0xA5000000u ^ (j >> 1)));
+    if (q.x != (0xA5000000u ^ i) || q.y != (0x5A000000u ^ i) || q.z != (0x3C000000u ^ i) || q.w != (0xC3000000u ^ i) || w != want) {
+      if (atomicAdd(bad, 1u) == 0) { *first_off = i * 16; *first_val = q.x; }
     }
-    __syncthreads();
-    if ((threadIdx.x >> 6) == (unsigned)(s & 3)) __builtin_amdgcn_s_sleep(8);      // skew the wavefronts
+    if (h & 0x30000000u) {
+      const unsigned long long v = 1 + (h >> 30);
+      atomicAdd(&acc[(h >> 4) % 1440u], v);
+      mine += v;
+    }
+  }
+  // total of the accumulators == total of what the threads added
+  __shared__ unsigned long long s_tot[2];
+  if (threadIdx.x == 0) { s_tot[0] = 0; s_tot[1] = 0; }
+  __syncthreads();
+  atomicAdd(&s_tot[0], mine);
+  unsigned long long part = 0;
+  for (int i = threadIdx.x; i < 1440; i += 256) part += acc[i];
+  atomicAdd(&s_tot[1], part);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_tot[0] != s_tot[1]) {
+    if (atomicAdd(bad, 1u) == 0) { *first_off = 0xffffffffu; *first_val = (unsigned)(s_tot[1] - s_tot[0]); }
   }
 }
 
