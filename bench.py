@@ -2,25 +2,29 @@
 """Throughput benchmark of the CPPF++ voting hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # no launcher environment: starts its 8 rank processes itself (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One *step* = one pass of the whole path over a batch of synthetic scenes resident in HBM:
   sampler -> normals + SHOT352 -> shot_encoder (MLP) -> tuple encode (pair features; the descriptor gather happens inside the
-  first MLP kernel) -> tuple MLP -> bin decode + vote parameters -> centre vote + argmax -> back-vote filter -> both rotation
-  votes (one kernel) -> scale head on the kept pairs (MLP) -> pose assembly -> one RCCL all_gather of the 160-byte scene
-  records (N > 1).  Every stage is a HIP kernel of libcppf_hip.so; the MLPs are PyTorch modules whose ResLayers run as
-  matrix-core kernels (cppf_reslayer_split: float32-equivalent split-bf16 arithmetic; --mlp-arith native = library GEMMs on the
-  f32-input matrix cores, also timed in every run as value_f32_input_mfma).  (--eager-scale-head runs the scale head inside the
-  tuple MLP on every tuple, the order of the reference's forward; its output is read only for the kept pairs, eval.py:272.)
+  first MLP kernel) -> tuple MLP (3 launches: gathered 360 -> 128 chain | 128 -> 256 + the logit head's 256-wide layers, tuple
+  features tapped | 256 -> 192 + bin draw) -> vote parameters -> centre vote + argmax -> back-vote filter -> both rotation votes
+  (one kernel) -> scale head on the kept pairs (MLP) -> pose assembly -> one RCCL all_gather of the 160-byte scene records
+  (N > 1).  Every launch of a step is a kernel of libcppf_hip.so (30 per step, profiles/r3_step_trace.txt); the MLPs are PyTorch
+  modules whose ResLayers run as matrix-core kernels (cppf_reslayer_split: float32-equivalent split-bf16 arithmetic;
+  --mlp-arith native = library GEMMs on the f32-input matrix cores, also timed in every run as value_f32_input_mfma).
+  (--eager-scale-head runs the scale head on every tuple, the order of the reference's forward; its output is read only for the
+  kept pairs, eval.py:272.)
 Workload = BASELINE.json configs[1]: SHOT model, 4096 points x 20 000 tuples per scene, 180 rotations, 720 sphere
 bins, res 2 mm ('bottle' axes), scenes = seeded synthetic bottle-like clouds (cppf2_amd.synth); weights are
 random-init (no checkpoints ship with the reference) plus a fixed teacher logit prior so that votes cluster the
 way trained weights make them.  Scenes are sharded over ranks (weak scaling: --scenes-per-gpu each).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (the dominant kernel -- the tuple MLP, matrix-core
-bound; the longest bandwidth-bound kernel under `roofline.hbm`; HIP-event timed inside the timed region) + `cpu_baseline` (the
-oracle timed on the host cores, bounded sample).
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (the dominant kernel -- the tuple MLP, matrix-core /
+power bound; the longest bandwidth-bound kernel under `roofline.hbm`; HIP-event timed inside the timed region) + `cpu_baseline`
+(the oracle timed on the host cores, bounded sample) + `collective` + untimed accuracy evidence measured on the bench's own tuples
+(`mlp_error_vs_f64`, `bin_flip_rate_vs_expf`).
 """
 import argparse
 import json
