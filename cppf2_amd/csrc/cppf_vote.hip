@@ -1612,13 +1612,13 @@ static int rot_bins_impl(int nax, int B, const float* pts, const int32_t* pt_off
   const RwPlan pl = rw_plan(B, max_kept, num_rots, bmm_size);
   const size_t lut_need = (size_t)S * 16 + (size_t)nax * S * 8 + (size_t)num_rots * 8 +
                           (size_t)pl.max_pairs * (sizeof(RwFrame) + 4);
-  // At least 40 KiB are requested (four workgroups per CU either way).  Round 3 observation, unexplained: with a second HIP
+  // At least 39 KiB are requested (four workgroups per CU either way: 4 x (39 KiB + 16 B static, in 512-byte granules) fit 160 KiB).  Round 3 observation, unexplained: with a second HIP
   // stream running the 448-register MLP kernels (125 KiB of LDS per CU), workgroups of this kernel that were placed on the
   // same CU -- possible only while they need < 38 KiB -- produced different votes for a few pairs per launch (inputs, LDS
   // tables and frames verified identical; LDS, register, atomic, barrier and arithmetic probe kernels beside the same MLP
   // kernel stayed clean: scratch/rot_race_probe3.py, scratch/rs/*_victim.hip).  The library is validated for one stream per
   // process; the larger request keeps this kernel off such CUs for callers that use several.
-  const size_t lut_lds = lut_need < 40960 ? 40960 : lut_need;
+  const size_t lut_lds = lut_need < 39936 ? 39936 : lut_need;
   if (bin_lut && lut_need <= 64000 && max_kept > 0) {
     double* partial = (double*)workspace;
     if (nax == 2)
