@@ -208,8 +208,11 @@ def _write_nocs_fixture(root):
                  pred_masks=np.stack([m, left, m], -1), pred_class_ids=np.array([1, 6, 0]), pred_scores=np.array([0.9, 0.8, 0.7]),
                  gt_class_ids=np.array([1, 6]), gt_RTs=np.stack([gt, gt]), gt_scales=np.ones((2, 3)) * 0.5,
                  gt_bboxes=np.stack([bbox(m), bbox(left)])),
-            dict(image_path="data/real/test/scene_1/0001", pred_bboxes=np.stack([bbox(m)]), pred_masks=m[..., None],
-                 pred_class_ids=np.array([4]), pred_scores=np.array([0.95]), gt_class_ids=np.array([4]), gt_RTs=gt[None],
+            # second image: the object, a "detection" covering the whole frame (floor to far wall: wider than 1000 cells of 2 mm,
+            # eval.py:199-200 skips it) and one whose mask has no valid depth at all
+            dict(image_path="data/real/test/scene_1/0001", pred_bboxes=np.stack([bbox(m), bbox(d > 0), bbox(m)]),
+                 pred_masks=np.stack([m, d > 0, (d == 0) & (np.arange(d.shape[0])[:, None] < 4)], -1),
+                 pred_class_ids=np.array([4, 2, 5]), pred_scores=np.array([0.95, 0.5, 0.4]), gt_class_ids=np.array([4]), gt_RTs=gt[None],
                  gt_scales=np.ones((1, 3)) * 0.5, gt_bboxes=bbox(m)[None], gt_handle_visibility=np.array([1]))]
     with open(os.path.join(root, "log", "results_real_test_scene_1_0000.pkl"), "wb") as f:
         pickle.dump(recs[0], f)                                       # a dict ...
@@ -229,12 +232,17 @@ def test_eval_main_nocs_layout_instance_loop(tmp_path, monkeypatch):
     _write_nocs_fixture(str(tmp_path))
     rep = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), out_dir=str(tmp_path / "out"),
                   num_pairs=5000, num_rots=36, opt=False, batch_instances=2)
-    assert rep["images"] == 2 and rep["detections"] == 4
-    assert rep["evaluated"] == 3 and rep["skipped"] == 1                 # class id 0 is not on the whitelist (eval.py:163-165)
+    assert rep["images"] == 2 and rep["detections"] == 6
+    # skipped: class id 0 (not on the whitelist, eval.py:163-165), the frame-wide mask (> 1000 cells, eval.py:199-200), the
+    # mask without a valid depth pixel
+    assert rep["evaluated"] == 3 and rep["skipped"] == 3
     assert sorted(rep["categories"]) == ["bottle", "can", "mug"] and sum(rep["picked"].values()) == 3
     res0, res1 = rep["final_results"]
     assert res0["pred_RTs"].shape == (3, 4, 4) and res0["pred_scales"].shape == (3, 3)
     assert np.array_equal(res0["pred_RTs"][2], np.eye(4)) and np.array_equal(res0["pred_scales"][2], np.ones(3))   # skipped: defaults
+    assert res1["pred_RTs"].shape == (3, 4, 4)
+    for j in (1, 2):
+        assert np.array_equal(res1["pred_RTs"][j], np.eye(4)) and np.array_equal(res1["pred_scales"][j], np.ones(3))
     for RT in (res0["pred_RTs"][0], res0["pred_RTs"][1], res1["pred_RTs"][0]):
         assert np.all(np.isfinite(RT)) and 0.8 < RT[2, 3] < 1.2 and not np.array_equal(RT, np.eye(4))
         assert np.allclose(RT[3], [0, 0, 0, 1])
