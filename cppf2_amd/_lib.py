@@ -11,7 +11,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CppfError(RuntimeError):
@@ -26,6 +26,18 @@ class SceneResult(C.Structure):
     _fields_ = [("argmax", C.c_int64), ("t", C.c_double * 3), ("R", C.c_double * 9), ("scale", C.c_float * 3),
                 ("peak", C.c_uint32), ("up_idx", C.c_int32), ("right_idx", C.c_int32), ("kept", C.c_int32),
                 ("up_count", C.c_float), ("right_count", C.c_float), ("flags", C.c_int32), ("ncell", C.c_int32), ("pad_", C.c_int32 * 3)]
+
+
+class ReslayerSplit16Args(C.Structure):
+    """CppfReslayerSplit16Args (include/cppf_hip.h): one struct for every launch form of the f16x2 ResLayer kernels."""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("k_in", C.c_int32),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("n_out", C.c_int32), ("rows", C.c_int64),
+                ("wq", C.c_void_p), ("wq_bytes", C.c_int64), ("b1", C.c_void_p), ("b0", C.c_void_p), ("chain", C.c_int32),
+                ("weight_scale", C.c_float),
+                ("first_out", C.c_void_p), ("ld_first", C.c_int64),
+                ("gidx", C.c_void_p), ("slots", C.c_int32), ("table", C.c_void_p), ("fdim", C.c_int32),
+                ("logit_prior", C.c_void_p), ("uniforms", C.c_void_p), ("bins", C.c_void_p),
+                ("stream", C.c_void_p)]
 
 
 assert C.sizeof(SceneGrid) == 32
@@ -73,6 +85,8 @@ SIGNATURES = {
                             _p, _p, _p, _p, _i64, _p]),
     "cppf_kept_rows": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_reslayer_split_debug_grid": (_i, [_i32]),
+    "cppf_reslayer_split16_stream_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "cppf_reslayer_split16": (_i, [_p]),
     "cppf_kept_rows32": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_nan_to_zero": (_i, [_p, _i64, _p]),
     "cppf_reslayer_tail": (_i, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),

@@ -48,8 +48,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // both accumulator sets of a 192- / 256-wide layer at once) above
 __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
-#define RS_TILE_BYTES (3 * RS_FRAG_BYTES)       // hi, mid, lo
-#define RS_STAGE_BYTES (16 * RS_TILE_BYTES)     // one staged chunk: up to 16 tile-steps (48 KiB)
+#define RS_STAGE_BYTES (16 * 3 * RS_FRAG_BYTES) // one staged chunk: up to 16 tile-steps of three fragments (48 KiB)
+// PC = operand pieces: 3 = bf16 (hi, mid, lo: exact, six products per K step), 2 = fp16 (hi, lo: 22-23 significant bits per
+// operand, three products per K step; see the f16x2 section below)
+__host__ __device__ constexpr int rs_tile_bytes(int pc) { return pc * RS_FRAG_BYTES; }
 
 // measured variants kept as switches: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more),
 // and a hand-placed MFMA / filler interleave (RS_INTERLEAVE 1; 2 = everything in front of each tile's back-to-back MFMA chain).
@@ -93,7 +95,10 @@ struct RsFrag {                                  // one operand fragment per sli
 
 // exact three-way split of two floats into packed bf16 pairs (each step rounds to nearest even; the remainders are
 // exact in float32): dword p of a fragment's (hi, mid, lo)
-template <bool PIN = false>
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int PC, bool PIN = false>
 __device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
   // PIN: an opaque copy of the inputs keeps the arithmetic where it is written (between two tiles' MFMAs); without it the
   // compiler gathers the splits of a whole chunk in front of the chunk's first MFMA (12 registers per K step, no overlap)
@@ -102,6 +107,19 @@ __device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, u
     h = __builtin_bit_cast(unsigned, v0);
     m = __builtin_bit_cast(unsigned, v1);
     l = h ^ m;
+    return;
+  }
+  if (PC == 2) {
+    // fp16 pair: hi = RNE(v) (11 significant bits), lo = RNE(v - hi) (the next 11-12): v_cvt_pk_f16_f32, two v_fma_mix_f32 /
+    // v_cvt_f32_f16 + v_sub_f32, v_cvt_pk_f16_f32; subnormal results are kept (the matrix core honours them)
+    const f32x2 v = {v0, v1};
+    const f16x2 hb = __builtin_convertvector(v, f16x2);
+    const float r0 = v0 - (float)hb[0], r1 = v1 - (float)hb[1];
+    const f32x2 rv = {r0, r1};
+    h = __builtin_bit_cast(unsigned, hb);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2));
+    m = 0;
+    if (PIN) asm volatile("" : "+v"(h), "+v"(l));
     return;
   }
   // scalar float subtractions on purpose (and -fno-slp-vectorize for this file, cppf2_amd/build.py): a v_pk_add_f32 between two
@@ -117,26 +135,33 @@ __device__ __forceinline__ void rs_split_pair(float v0, float v1, unsigned& h, u
   if (PIN) asm volatile("" : "+v"(h), "+v"(m), "+v"(l));      // ... and from sinking the arithmetic down to its first use
 }
 
+template <int PC>
 __device__ __forceinline__ RsFrag rs_split(const float (&v)[8]) {
   RsFrag f;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) rs_split_pair(v[2 * p], v[2 * p + 1], f.h[p], f.m[p], f.l[p]);
+  for (int p = 0; p < 4; ++p) rs_split_pair<PC>(v[2 * p], v[2 * p + 1], f.h[p], f.m[p], f.l[p]);
   return f;
 }
 
+template <int PC>
 __device__ __forceinline__ f32x16 rs_mfma(const unsigned (&a)[4], const unsigned (&b)[4], const f32x16& c) {
   const u32x4 av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+  if (PC == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 
-// acc += A B over one K step of 16 with both operands split: six exact-product MFMAs, smallest terms first
-__device__ __forceinline__ void rs_mma6(f32x16& acc, const RsFrag& a, const RsFrag& b) {
-  acc = rs_mfma(a.l, b.h, acc);
-  acc = rs_mfma(a.h, b.l, acc);
-  acc = rs_mfma(a.m, b.m, acc);
-  acc = rs_mfma(a.m, b.h, acc);
-  acc = rs_mfma(a.h, b.m, acc);
-  acc = rs_mfma(a.h, b.h, acc);
+// acc += A B over one K step of 16 with both operands split, smallest terms first: six exact-product MFMAs (bf16 triples), or
+// the three products hi lo + lo hi + hi hi of the fp16 pairs (lo lo is below 2^-22 of the product and dropped)
+template <int PC>
+__device__ __forceinline__ void rs_mma(f32x16& acc, const RsFrag& a, const RsFrag& b) {
+  acc = rs_mfma<PC>(a.l, b.h, acc);
+  acc = rs_mfma<PC>(a.h, b.l, acc);
+  if (PC == 3) {
+    acc = rs_mfma<PC>(a.m, b.m, acc);
+    acc = rs_mfma<PC>(a.m, b.h, acc);
+    acc = rs_mfma<PC>(a.h, b.m, acc);
+  }
+  acc = rs_mfma<PC>(a.h, b.h, acc);
 }
 
 // s_waitcnt immediate (gfx9 encoding): vmcnt (6 bits, split 4 + 2), lgkmcnt (4 bits); expcnt not waited on
@@ -150,10 +175,10 @@ __host__ __device__ constexpr int rs_waitcnt(int vm, int lgkm) {
 // tiles), then W1, W2 of each chained layer (2 NT steps of NT tiles each).  It moves through a two-stage LDS ring by LDS-DMA in chunks of up to rs_spc(tiles) K steps of one segment: the
 // pieces of chunk c + 1 (1 KiB per wavefront instruction) are issued between the MFMAs of the first K step of chunk c.
 // All memory waits of the kernel's main loops are COUNTED (the vector-memory queue completes in order): see acquire().
-template <int NT, int T0, int WAVES>
+template <int NT, int T0, int WAVES, int PC>
 struct RsStream {
   // pieces of a chunk per wavefront, at most (a chunk = rs_spc(tiles) K steps of `tiles` tiles, three fragments each)
-  static constexpr int P0 = (rs_spc(T0) * T0 * 3 + WAVES - 1) / WAVES, P1 = (rs_spc(NT) * NT * 3 + WAVES - 1) / WAVES;
+  static constexpr int P0 = (rs_spc(T0) * T0 * PC + WAVES - 1) / WAVES, P1 = (rs_spc(NT) * NT * PC + WAVES - 1) / WAVES;
   static constexpr int PMAX = RS_EXACT_PMAX ? (P0 > P1 ? P0 : P1) : 48 / WAVES;
   int nseg;                    // 2 + 2 per chained identity layer
   int chunks;                  // chunks per row block
@@ -186,7 +211,7 @@ struct RsStream {
     const int spc = first ? rs_spc(T0) : rs_spc(NT);
     const int steps = first ? ks1 : 2 * NT;
     const int ns = steps - pos < spc ? steps - pos : spc;
-    const int pieces = ns * tiles * 3;
+    const int pieces = ns * tiles * PC;
     p_src = base + off + lane * 16;
     p_last = pieces - 1;
     off += (int64_t)pieces * RS_FRAG_BYTES;
@@ -232,10 +257,12 @@ struct RsStream {
   }
 };
 
+template <int PC>
 __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
   RsFrag a;
   if (RS_DBG & 4) tile = 0;
-  const u32x4 h = w[(tile * 3 + 0) * 64], m = w[(tile * 3 + 1) * 64], l = w[(tile * 3 + 2) * 64];
+  const u32x4 h = w[(tile * PC + 0) * 64], l = w[(tile * PC + PC - 1) * 64];
+  const u32x4 m = (PC == 3) ? w[(tile * PC + 1) * 64] : h;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     a.h[p] = h[p];
@@ -250,25 +277,25 @@ __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
 // of the NEXT step's B operand, a quarter per call) and `dma(q)`, q < PMAX, the LDS-DMA issue of one piece of the next
 // weight chunk: both are placed in front of a tile's MFMAs so that they issue in their shadow; the scheduling barrier
 // per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
-template <int NTILES, bool PREFETCH, int PMAX, class F, class D>
+template <int NTILES, bool PREFETCH, int PMAX, int PC, class F, class D>
 __device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler, D&& dma) {
   // PREFETCH: fragments are requested two tiles ahead (one wavefront per SIMD: nobody else covers the LDS latency);
   // otherwise one tile ahead
-  RsFrag a0 = rs_read(w, 0), a1 = a0;
-  if (PREFETCH && NTILES > 1) a1 = rs_read(w, 1);
+  RsFrag a0 = rs_read<PC>(w, 0), a1 = a0;
+  if (PREFETCH && NTILES > 1) a1 = rs_read<PC>(w, 1);
 #pragma unroll
   for (int u = 0; u < NTILES; ++u) {
     RsFrag a2 = a1;
     if (PREFETCH) {
-      if (u + 2 < NTILES) a2 = rs_read(w, u + 2);
+      if (u + 2 < NTILES) a2 = rs_read<PC>(w, u + 2);
     } else {
-      if (u + 1 < NTILES) a1 = rs_read(w, u + 1);
+      if (u + 1 < NTILES) a1 = rs_read<PC>(w, u + 1);
     }
 #pragma unroll
     for (int q = (u * PMAX + NTILES - 1) / NTILES; q < ((u + 1) * PMAX + NTILES - 1) / NTILES; ++q) dma(q);
 #pragma unroll
     for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
-    rs_mma6(acc[u], a0, b);
+    rs_mma<PC>(acc[u], a0, b);
 #if RS_INTERLEAVE == 1
     // issue order within the tile: one MFMA, then a few of the independent instructions (the three LDS reads, a DMA piece,
     // a slice of the split) that fit its 32-cycle shadow -- not all of them behind the first MFMA
@@ -350,14 +377,14 @@ struct RsX {
 // weight pieces.  Step s: wait for tile s + 1 (two tiles younger: vmcnt(4) before, vmcnt(2) after the issue of tile
 // s + 3 -- the wait comes first), read it, issue tile s + 3 into the slot tile s left, split tile s + 1 in the shadow of
 // step s's MFMAs.
-template <int NTILES, bool PREFETCH, class X, class Stream>
+template <int NTILES, bool PREFETCH, int PC, class X, class Stream>
 __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, const RsRow rw, int ks1, Stream& ws) {
   constexpr int SPC = rs_spc(NTILES);
   float xv[8];
   RS_WAIT(4, 15);                                    // tile 0 has landed (tiles 1, 2 may be in flight)
   __builtin_amdgcn_sched_barrier(0);
   xs.read(xv, 0, 0);
-  RsFrag b = rs_split(xv);
+  RsFrag b = rs_split<PC>(xv);
   int slot = 1;                                      // slot of tile s + 1
   bool whole = true;                                 // the previous chunk had SPC steps (counted wait) or this is the first
   for (int s0 = 0; s0 < ks1; s0 += SPC) {
@@ -374,8 +401,8 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, 
         xs.issue(s0 + i + 3, slot == 0 ? 2 : slot - 1, rw);
         slot = slot == 2 ? 0 : slot + 1;
         RsFrag bn;
-        rs_step<NTILES, PREFETCH, Stream::PMAX>(acc, w + i * NTILES * 3 * 64, b,
-                                  [&](int p) { rs_split_pair<true>(xv[2 * p], xv[2 * p + 1], bn.h[p], bn.m[p], bn.l[p]); },
+        rs_step<NTILES, PREFETCH, Stream::PMAX, PC>(acc, w + i * NTILES * PC * 64, b,
+                                  [&](int p) { rs_split_pair<PC, true>(xv[2 * p], xv[2 * p + 1], bn.h[p], bn.m[p], bn.l[p]); },
                                   [&](int q) { if (i == 0) ws.piece(q); });
         b = bn;
       }
@@ -387,13 +414,15 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, 
 // product): step (t, sp) contracts over the lane's registers 8 sp .. 8 sp + 7 of src tile t -- the weights are packed in
 // that feature order.  The split of step + 1 runs in the shadow of step's MFMAs (pinned there, which also keeps CSE from
 // keeping a once-computed split alive across products at 24 registers per tile).
-template <int NS, int NTILES, bool PREFETCH, class Stream>
-__device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16 (&src)[NS], Stream& ws) {
+// (bs: the factor the source tiles carry and the B operand must not -- 1 for the bf16 triples, 1 / weight scale for the fp16 pairs)
+template <int NS, int NTILES, bool PREFETCH, int PC, class Stream>
+__device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16 (&src)[NS], Stream& ws, float bs) {
   constexpr int SPC = rs_spc(NTILES);
   static_assert((2 * NS) % SPC == 0, "whole chunks");
   RsFrag b;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) rs_split_pair(src[0][2 * p], src[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
+  for (int p = 0; p < 4; ++p)
+    rs_split_pair<PC>(PC == 2 ? src[0][2 * p] * bs : src[0][2 * p], PC == 2 ? src[0][2 * p + 1] * bs : src[0][2 * p + 1], b.h[p], b.m[p], b.l[p]);
 #pragma unroll
   for (int c = 0; c < 2 * NS / SPC; ++c) {
     const u32x4* w = ws.template acquire<0>();        // no x tiles in flight here (or old ones: harmless)
@@ -401,11 +430,12 @@ __device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16
     for (int i = 0; i < SPC; ++i) {
       const int step = c * SPC + i, nx = (step + 1 < 2 * NS) ? step + 1 : step;
       RsFrag bn = b;
-      rs_step<NTILES, PREFETCH, Stream::PMAX>(dst, w + i * NTILES * 3 * 64, b,
+      rs_step<NTILES, PREFETCH, Stream::PMAX, PC>(dst, w + i * NTILES * PC * 64, b,
                                 [&](int p) {
-                                  if (step + 1 < 2 * NS)
-                                    rs_split_pair<true>(src[nx >> 1][8 * (nx & 1) + 2 * p], src[nx >> 1][8 * (nx & 1) + 2 * p + 1],
-                                                        bn.h[p], bn.m[p], bn.l[p]);
+                                  if (step + 1 < 2 * NS) {
+                                    const float s0 = src[nx >> 1][8 * (nx & 1) + 2 * p], s1 = src[nx >> 1][8 * (nx & 1) + 2 * p + 1];
+                                    rs_split_pair<PC, true>(PC == 2 ? s0 * bs : s0, PC == 2 ? s1 * bs : s1, bn.h[p], bn.m[p], bn.l[p]);
+                                  }
                                 },
                                 [&](int q) { if (i == 0) ws.piece(q); });
       b = bn;
@@ -422,6 +452,15 @@ __device__ __forceinline__ void rs_load_tile(f32x16& acc, const float* v, int g)
   }
 }
 
+// the same with every value multiplied by sc (f16x2: the residual enters the accumulators in the weight-scaled domain)
+__device__ __forceinline__ void rs_load_tile_scaled(f32x16& acc, const float* v, int g, float sc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(v + 8 * q + 4 * g);
+    acc[4 * q + 0] = t.x * sc; acc[4 * q + 1] = t.y * sc; acc[4 * q + 2] = t.z * sc; acc[4 * q + 3] = t.w * sc;
+  }
+}
+
 // The bin draw of eval.py:225-229 as the epilogue of the logit head's output layer (6 coordinates x 32 bins = the 6 output
 // tiles): tile u holds the logits of coordinate u of this lane's row, registers e <-> bins (e & 3) + 8 (e >> 2) + 4 g, the other
 // 16 bins sit in lane ^ 32.  Same arithmetic as decode_bins_kernel<32> (cppf_core.hip), bit for bit: logits (+ prior), max,
@@ -433,9 +472,13 @@ struct RsDecode {
   int32_t* bins;                // [rows, 6] out
 };
 
-template <int NT>
-__device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDecode& dc, int64_t row, bool in, int g) {
+template <int NT, int PC>
+__device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDecode& dc, int64_t row, bool in, int g, float bs) {
   static_assert(NT == 6, "6 coordinates x 32 bins");
+  if (PC == 2) {                                 // back to the true scale (f16x2: the accumulators carry the weight scale)
+#pragma unroll
+    for (int u = 0; u < 6; ++u) o[u] *= bs;
+  }
   if (dc.prior) {
     const float* pr = dc.prior + row * 192 + 4 * g;
 #pragma unroll
@@ -508,13 +551,21 @@ struct RsGather {               // GATHER launches: see RsX
   int slots, head, fshift;
 };
 
-template <int NT, bool PROJ, bool GATHER, bool DECODE = false>
+// f16x2 (PC == 2, CPPF_MLP_ARITH=split16): every float32 operand as an fp16 pair hi + lo (22-23 significant bits), three
+// products per K step, float32 accumulate.  fp16 has five exponent bits, so the weights are multiplied by a power of two
+// `wscale` before they are split (the host picks it so that the largest weight of the launch sits near 2^13: the lo pieces stay
+// normal) and the biases come pre-multiplied by it: every accumulator then holds wscale x its true value -- the residual stream
+// included, so the skip additions need no rescaling -- and only the B operand of the next product (and the stored outputs) are
+// multiplied by 1 / wscale (exact).  Activations are split unscaled: |x| < 65504 is required, subnormal lo pieces are honoured
+// by the matrix core (absolute resolution 2^-25 for small activations).
+template <int NT, bool PROJ, bool GATHER, bool DECODE = false, int PC = 3>
 __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                               int64_t ldo, int64_t rows,
                                                                               const char* __restrict__ wq,
                                                                               const float* __restrict__ b1,
                                                                               const float* __restrict__ b0, int chain,
-                                                                              RsGather ga, RsDecode dc, RsTap tap) {
+                                                                              RsGather ga, RsDecode dc, RsTap tap, float wscale) {
+  const float bs = (PC == 2) ? 1.0f / wscale : 1.0f;        // B-operand / output factor (a power of two: exact)
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
@@ -526,7 +577,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
 
-  RsStream<NT, T0, WAVES> ws;
+  RsStream<NT, T0, WAVES, PC> ws;
   ws.base = wq;
   ws.ring = s_ring;
   ws.ks1 = ks1;
@@ -593,11 +644,14 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     if (!PROJ && (WAVES == 8 || RS_EARLY_RESIDUAL)) {   // residual of an identity layer: requested before the first product (while
                                                         // the x tiles of the same rows are passing through L2)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
+      for (int u = 0; u < NT; ++u) {
+        if (PC == 2) rs_load_tile_scaled(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g, wscale);
+        else rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
+      }
     }
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
-      rs_product_x<T0, PF>(first, xs, cur, ks1, ws);
+      rs_product_x<T0, PF, PC>(first, xs, cur, ks1, ws);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -605,8 +659,24 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];        // NaN stays NaN like torch.relu
     }
     if (!PROJ && WAVES == 4 && !RS_EARLY_RESIDUAL) {     // (measured alternative: after it; re-reads 1.2 GB per launch from HBM)
+      if (PC == 2) {
+        // scaled on the way in, two tiles at a time: the products are VALU results, which reach the accumulator half of the
+        // register file through v_accvgpr_write -- all eight tiles at once would need 128 transient registers (spills)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
+        for (int u = 0; u < NT; u += 2) {
+          rs_load_tile_scaled(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g, wscale);
+          if (u + 1 < NT) rs_load_tile_scaled(o[u + 1], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * (u + 1), g, wscale);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {         // parked in the accumulator half of the register file right away
+            asm volatile("" : "+a"(o[u][e]));
+            if (u + 1 < NT) asm volatile("" : "+a"(o[u + 1][e]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
+      }
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
     if (more) {
@@ -616,7 +686,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     }
     cur = nxt;
     // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
-    rs_product_h<NT, NT, PF>(o, h, ws);
+    rs_product_h<NT, NT, PF, PC>(o, h, ws, bs);
     if (tap.out && in) {                        // the first layer's output is needed in memory as well (the tuple features)
       float* trow = tap.out + row * tap.ld + 4 * g;
 #pragma unroll
@@ -625,6 +695,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
           v.x = o[u][4 * q + 0]; v.y = o[u][4 * q + 1]; v.z = o[u][4 * q + 2]; v.w = o[u][4 * q + 3];
+          if (PC == 2) v *= bs;
           *reinterpret_cast<f32x4*>(trow + 32 * u + 8 * q) = v;
         }
       }
@@ -636,16 +707,16 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
       const float* bl = s_b1 + 32 * NT * (2 + l);
 #pragma unroll
       for (int u = 0; u < NT; ++u) rs_load_tile(h[u], bl + 32 * u, g);
-      rs_product_h<NT, NT, PF>(h, o, ws);
+      rs_product_h<NT, NT, PF, PC>(h, o, ws, bs);
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) h[u][e] = (h[u][e] < 0.0f) ? 0.0f : h[u][e];
       }
-      rs_product_h<NT, NT, PF>(o, h, ws);
+      rs_product_h<NT, NT, PF, PC>(o, h, ws, bs);
     }
     if (DECODE) {
-      if constexpr (NT == 6) rs_decode_epilogue<NT>(o, dc, in ? row : rows - 1, in, g);
+      if constexpr (NT == 6) rs_decode_epilogue<NT, PC>(o, dc, in ? row : rows - 1, in, g, bs);
     } else if (in && (!(RS_DBG & 32) || o[0][0] == 1.2345e30f)) {
       float* orow = out + row * ldo + 4 * g;
 #pragma unroll
@@ -654,6 +725,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
           v.x = o[u][4 * q + 0]; v.y = o[u][4 * q + 1]; v.z = o[u][4 * q + 2]; v.w = o[u][4 * q + 3];
+          if (PC == 2) v *= bs;                  // back to the true scale (f16x2: the accumulators carry the weight scale)
           *reinterpret_cast<f32x4*>(orow + 32 * u + 8 * q) = v;
         }
       }
@@ -667,10 +739,14 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   RS_WAIT(0, 15);
 }
 
-extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
+static int64_t rs_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain, int pc) {
   if (k_in <= 0 || !(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256) || chain < 0 || chain > 15) return -1;
   const int64_t nt = n_out / 32, ks1 = (k_in + 15) / 16;
-  return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * RS_TILE_BYTES;
+  return (ks1 * (proj ? 2 : 1) + (1 + 2 * (int64_t)chain) * 2 * nt) * nt * rs_tile_bytes(pc);
+}
+
+extern "C" int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
+  return rs_stream_bytes(k_in, n_out, proj, chain, 3);
 }
 
 // test hook (tests/test_mlp_split.py race screen): > 0 forces the number of persistent workgroups of every launch
@@ -680,10 +756,10 @@ extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
   return CPPF_OK;
 }
 
-template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false>
+template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false, int PC = 3>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
-                     RsDecode dc = RsDecode(), RsTap tap = RsTap()) {
+                     RsDecode dc = RsDecode(), RsTap tap = RsTap(), float wscale = 1.0f) {
   constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -698,13 +774,13 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
     CPPF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev & 63]) {
-      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER, DECODE>,
+      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev & 63] = true;
     }
   }
-  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx,
-                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc, tap);
+  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx,
+                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc, tap, wscale);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
@@ -841,4 +917,84 @@ extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k
   dc.bins = bins;
   return rs_launch<6, true, false, true>(x, ldx, k_in, nullptr, 192, rows, static_cast<const char*>(wq), b1, b0, 0,
                                          n_cu > 0 ? n_cu : 256, (hipStream_t)stream, RsGather(), dc);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// f16x2 arithmetic (CPPF_MLP_ARITH=split16): one entry point for every launch form
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain) {
+  return rs_stream_bytes(k_in, n_out, proj, chain, 2);
+}
+
+template <int NT, bool PROJ>
+static int rs16_plain(const CppfReslayerSplit16Args& a, int n_cu, RsTap tap) {
+  return rs_launch<NT, PROJ, false, false, 2>(a.x, a.ldx, a.k_in, a.out, a.ldo, a.rows, static_cast<const char*>(a.wq), a.b1, a.b0,
+                                              a.chain, n_cu, (hipStream_t)a.stream, RsGather(), RsDecode(), tap, a.weight_scale);
+}
+
+// The ResLayer launch of cppf_reslayer_split / _tap / _gather / _decode in f16x2 arithmetic (see the kernel's comment): wq =
+// the fp16 (hi, lo) pairs of weight_scale x the weights in the same fragment order (cppf2_amd.models.pack_split(arith="f16x2");
+// cppf_reslayer_split16_stream_bytes bytes), b1 / b0 = weight_scale x the biases, weight_scale a power of two.  Exactly one of
+// {plain, gather (gidx != NULL; x = heads, k_in = head columns), decode (uniforms != NULL)} ; first_out (tap) only with plain.
+extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
+  CPPF_CHECK_ARG(args != nullptr);
+  const CppfReslayerSplit16Args& a = *args;
+  CPPF_CHECK_ARG(a.x && a.wq && a.b1 && a.rows >= 0 && a.chain >= 0 && a.chain <= 15);
+  {
+    int e = 0;
+    CPPF_CHECK_ARG(a.weight_scale > 0.0f && frexpf(a.weight_scale, &e) == 0.5f);        // a power of two
+  }
+  CPPF_CHECK_ARG((((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.wq | (uintptr_t)a.first_out | (uintptr_t)a.table |
+                   (uintptr_t)a.logit_prior) & 15) == 0);
+  CPPF_CHECK_ARG((a.ldx & 3) == 0 && (a.ldo & 3) == 0 && (a.ld_first & 3) == 0);
+  const bool gather = a.gidx != nullptr, decode = a.uniforms != nullptr, proj = a.b0 != nullptr;
+  CPPF_CHECK_ARG(!(gather && decode) && !((gather || decode) && a.first_out));
+  if (a.rows == 0) return CPPF_OK;
+  int dev = 0, n_cu = 0;
+  CPPF_HIP(hipGetDevice(&dev));
+  CPPF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (n_cu <= 0) n_cu = 256;
+  const char* w = static_cast<const char*>(a.wq);
+  hipStream_t st = (hipStream_t)a.stream;
+  if (gather) {
+    CPPF_CHECK_ARG(a.table && proj && a.out && a.n_out == 128 && a.ldo >= 128);
+    CPPF_CHECK_ARG(a.k_in >= 0 && (a.k_in & 7) == 0 && (a.k_in == 0 || a.ldx >= a.k_in));
+    CPPF_CHECK_ARG(a.slots >= 1 && a.slots <= 8 && a.fdim >= 8 && (a.fdim & (a.fdim - 1)) == 0);
+    const int k_tot = a.k_in + a.slots * a.fdim;
+    CPPF_CHECK_ARG(a.wq_bytes == rs_stream_bytes(k_tot, 128, 1, a.chain, 2));
+    RsGather ga;
+    ga.gidx = a.gidx;
+    ga.table = a.table;
+    ga.slots = a.slots;
+    ga.head = a.k_in;
+    ga.fshift = __builtin_ctz((unsigned)a.fdim);
+    return rs_launch<4, true, true, false, 2>(a.x, a.ldx, k_tot, a.out, a.ldo, a.rows, w, a.b1, a.b0, a.chain, n_cu, st, ga,
+                                              RsDecode(), RsTap(), a.weight_scale);
+  }
+  CPPF_CHECK_ARG(a.k_in > 0 && (a.k_in & 7) == 0 && a.ldx >= a.k_in);
+  if (decode) {
+    CPPF_CHECK_ARG(proj && a.bins && a.chain == 0 && a.wq_bytes == rs_stream_bytes(a.k_in, 192, 1, 0, 2));
+    RsDecode dc;
+    dc.prior = a.logit_prior;
+    dc.uniforms = a.uniforms;
+    dc.bins = a.bins;
+    return rs_launch<6, true, false, true, 2>(a.x, a.ldx, a.k_in, nullptr, 192, a.rows, w, a.b1, a.b0, 0, n_cu, st, RsGather(), dc,
+                                              RsTap(), a.weight_scale);
+  }
+  CPPF_CHECK_ARG(a.out && (a.n_out == 64 || a.n_out == 128 || a.n_out == 192 || a.n_out == 256) && a.ldo >= a.n_out);
+  CPPF_CHECK_ARG(proj || a.k_in == a.n_out);
+  CPPF_CHECK_ARG(a.wq_bytes == rs_stream_bytes(a.k_in, a.n_out, proj, a.chain, 2));
+  RsTap tap;
+  if (a.first_out) {
+    CPPF_CHECK_ARG(a.first_out != a.out && a.first_out != a.x && a.ld_first >= a.n_out);
+    tap.out = a.first_out;
+    tap.ld = a.ld_first;
+  }
+  switch (a.n_out / 32) {
+    case 2: return proj ? rs16_plain<2, true>(a, n_cu, tap) : rs16_plain<2, false>(a, n_cu, tap);
+    case 4: return proj ? rs16_plain<4, true>(a, n_cu, tap) : rs16_plain<4, false>(a, n_cu, tap);
+    case 6: return proj ? rs16_plain<6, true>(a, n_cu, tap) : rs16_plain<6, false>(a, n_cu, tap);
+    default: return proj ? rs16_plain<8, true>(a, n_cu, tap) : rs16_plain<8, false>(a, n_cu, tap);
+  }
 }

@@ -40,7 +40,14 @@ def _stack(dims):
 # Arithmetic of the inference MLPs on the GPU: "split" = every ResLayer as one kernel on the bf16 matrix cores with each
 # float32 operand split exactly into three bf16 values (cppf_reslayer_split: float32-equivalent accuracy, 2-3x the rate of
 # the f32-input matrix instruction); "native" = f32-input matrix cores (library GEMMs + cppf_reslayer128).
+# "split16" = the same kernels in f16x2 arithmetic (fp16 operand pairs, three products: half the matrix-core work, float32-GEMM
+# level error against float64, fp16's operand range; ops.reslayer_split16) -- an option, not the default.
 MLP_ARITH = os.environ.get("CPPF_MLP_ARITH", "split")
+
+
+def _kernel_arith():
+    """True when the ResLayers run as the library's matrix-core kernels (either operand split)."""
+    return MLP_ARITH in ("split", "split16")
 
 
 def split_bf16(w):
@@ -53,7 +60,22 @@ def split_bf16(w):
     return torch.stack([hi, mid, lo])
 
 
-def pack_split(w1, w0, w2, k_in, chain=()):
+def split_f16(w):
+    """float32 tensor -> float16 [2, ...]: hi = RNE(w), lo = RNE(w - hi): w to 22-23 significant bits (f16x2 arithmetic)."""
+    w = w.detach().float()
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo])
+
+
+def f16_scale(*weights):
+    """The power of two the weights of one f16x2 launch are multiplied by: the largest |w| lands in [2^12, 2^13)."""
+    import math
+    m = max(float(w.detach().abs().max()) for w in weights if w is not None)
+    return 2.0 ** (13 - math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 1.0
+
+
+def pack_split(w1, w0, w2, k_in, chain=(), arith="bf16x3", scale=1.0):
     """The weight stream cppf_reslayer_split consumes for one ResLayer (w1 [N, K], w0 [N, K] or None, w2 [N, N] as
     nn.Linear stores them; k_in >= K = the columns of x the kernel reads, the extra ones get zero weights), optionally
     followed by the identity layers `chain` = [(w1_l [N, N], w2_l [N, N]), ...] of the same width.
@@ -64,15 +86,20 @@ def pack_split(w1, w0, w2, k_in, chain=()):
       second product (W2), step (t, s') over the hidden features in the accumulator order of the first product:
         lane half g holds hidden features 32 t + 16 s' + 4 g + (j & 3) + 8 (j >> 2);
       then per chained layer W1_l and W2_l, both in that accumulator feature order (their input is the previous layer's
-      output tiles in registers)."""
+      output tiles in registers).
+    arith="f16x2" (cppf_reslayer_split16): the same order with (hi, lo) fp16 fragments of scale x the weights."""
     n = w1.shape[0]
     nt = n // 32
     ks1 = (k_in + 15) // 16
     dev = w1.device
+    if arith == "f16x2":
+        pc, split = 2, (lambda w: split_f16(w * scale))
+    else:
+        pc, split = 3, split_bf16
 
     def pack_x(w, tiles):
-        s = split_bf16(F.pad(w.detach().float(), (0, ks1 * 16 - w.shape[1])))
-        return s.reshape(3, tiles, 32, ks1, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)      # [s, u, slice, g, i, j]
+        s = split(F.pad(w.detach().float(), (0, ks1 * 16 - w.shape[1])))
+        return s.reshape(pc, tiles, 32, ks1, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)      # [s, u, slice, g, i, j]
 
     def pack_h(w):
         t = torch.arange(nt, device=dev).view(nt, 1, 1, 1)
@@ -80,8 +107,8 @@ def pack_split(w1, w0, w2, k_in, chain=()):
         g = torch.arange(2, device=dev).view(1, 1, 2, 1)
         j = torch.arange(8, device=dev).view(1, 1, 1, 8)
         col = (32 * t + 16 * sp + 4 * g + (j & 3) + 8 * (j >> 2)).reshape(-1)
-        s = split_bf16(w)[:, :, col]
-        return s.reshape(3, nt, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)    # [t, s', u, slice, g, i, j]
+        s = split(w)[:, :, col]
+        return s.reshape(pc, nt, 32, nt, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(-1)    # [t, s', u, slice, g, i, j]
 
     parts = [pack_x(w1, nt) if w0 is None else pack_x(torch.cat([w1, w0]), 2 * nt), pack_h(w2)]
     for w1_l, w2_l in chain:
@@ -122,6 +149,23 @@ def _entry_cache(entry):
     if entry[5] is None:
         entry[5] = {}
     return entry[5]
+
+
+def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0):
+    """(weight stream, first biases of the launch's layers, skip bias, weight scale) of one launch in the current arithmetic,
+    cached per launch shape: bf16 triples (scale 1) or fp16 pairs of scale x the weights with the biases scaled alike."""
+    key = key + (MLP_ARITH,)
+    if key not in cache:
+        chain = [(e[0].t(), e[4].t()) for e in rest]
+        biases = torch.cat([b1] + [e[1] for e in rest])
+        if MLP_ARITH == "split16":
+            sc = f16_scale(w1t, w0t, w2t, *[w for pair in chain for w in pair])
+            wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), k_in, chain=chain, arith="f16x2", scale=sc)
+            cache[key] = (wq, (biases * sc).contiguous(), None if b0 is None else (b0 * sc).contiguous(), sc)
+        else:
+            wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), k_in, chain=chain)
+            cache[key] = (wq, biases.contiguous(), b0, 1.0)
+    return cache[key]
 
 
 def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
@@ -179,7 +223,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         entry = plan[0]
         w1t, b1, w0t, b0, w2t = entry[:5]
         k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
-        assert MLP_ARITH == "split" and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
+        assert _kernel_arith() and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
         cache = _entry_cache(entry)
         chain = cache.get(("gather-chain", k_in, tap_at, cross))
         if chain is None:
@@ -191,11 +235,11 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                 chain = 0                       # (the gathering launch has no second output)
             cache[("gather-chain", k_in, tap_at, cross)] = chain
         key = (k_in, chain, cross if tap_at is not None and chain > tap_at else None)
-        if key not in cache:
-            rest = plan[1:1 + chain]
-            wq = pack_split(w1t.t(), w0t.t(), w2t.t(), k_in, chain=[(e[0].t(), e[4].t()) for e in rest])
-            cache[key] = (wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
-        x = ops.reslayer_split_gather(heads, gidx, table, cache[key][0], cache[key][1], b0, 128, chain=chain)
+        wq, bb1, bb0, sc = _packed(cache, key, w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0)
+        if MLP_ARITH == "split16":
+            x = ops.reslayer_split16(heads, wq, bb1, bb0, 128, sc, chain=chain, gather=(gidx, table))
+        else:
+            x = ops.reslayer_split_gather(heads, gidx, table, wq, bb1, bb0, 128, chain=chain)
         li = 1 + chain
         if tap_at is not None and li - 1 == tap_at:
             tapped = x
@@ -206,12 +250,13 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         if (decode is not None and li == len(plan) - 1):
             assert c is None and decode_supported(seq, x), "fused bin draw: see decode_supported"
             cache = _entry_cache(entry)
-            key = (x.shape[1], "decode")
-            if key not in cache:
-                cache[key] = (pack_split(w1t.t(), w0t.t(), w2t.t(), x.shape[1]), b1)
-            bins = ops.reslayer_split_decode(x, cache[key][0], b1, b0, decode[0], prior=decode[1], bins=decode[2])
+            wq, bb1, bb0, sc = _packed(cache, (x.shape[1], "decode"), w1t, w0t, w2t, x.shape[1], [], b1, b0)
+            if MLP_ARITH == "split16":
+                bins = ops.reslayer_split16(x, wq, bb1, bb0, 192, sc, decode=decode)
+            else:
+                bins = ops.reslayer_split_decode(x, wq, bb1, bb0, decode[0], prior=decode[1], bins=decode[2])
             return bins if tap_at is None else (bins, tapped)
-        if (MLP_ARITH == "split" and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+        if (_kernel_arith() and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.data_ptr() % 16 == 0 and x.shape[1] >= w1t.shape[0]
                 and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
@@ -229,11 +274,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                 cache[ck] = chain
             crossing = tap_at is not None and li <= tap_at < li + chain           # the launch runs from one stack into the other
             key = (x.shape[1], chain, cross if crossing else None)
-            if key not in cache:
-                rest = plan[li + 1:li + 1 + chain]
-                wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), x.shape[1],
-                                chain=[(e[0].t(), e[4].t()) for e in rest])
-                cache[key] = (wq, torch.cat([b1] + [e[1] for e in rest]).contiguous())
+            wq, bb1, bb0, sc = _packed(cache, key, w1t, w0t, w2t, x.shape[1], plan[li + 1:li + 1 + chain], b1, b0)
             out = None
             if w0t is None and li == 0 and keep_input:
                 out = torch.empty_like(x)
@@ -245,12 +286,15 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                 tap_buf = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=x.device)
                 if w0t is None and out is None:
                     out = torch.empty_like(x)
-            x = ops.reslayer_split(x, cache[key][0], cache[key][1], b0, n_out, out=out, chain=chain, tap=tap_buf)
+            if MLP_ARITH == "split16":
+                x = ops.reslayer_split16(x, wq, bb1, bb0, n_out, sc, out=out, chain=chain, tap=tap_buf)
+            else:
+                x = ops.reslayer_split(x, wq, bb1, bb0, n_out, out=out, chain=chain, tap=tap_buf)
             if tap_at is not None and li <= tap_at <= li + chain:
                 tapped = tap_buf if tap_buf is not None else x
             li += 1 + chain
             continue
-        if (MLP_ARITH == "split" and n_out <= 8 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+        if (_kernel_arith() and n_out <= 8 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
                 and x.data_ptr() % 16 == 0 and w1t.shape[0] % 4 == 0 and x.shape[1] >= w1t.shape[0]
                 and (w0t is not None or w1t.shape[0] == n_out) and (tail is not None or c is None or li + 1 < len(plan))):
             # a layer too narrow for a matrix-core tile (the scale head's 64 -> 3): plain float32, one thread per row, in the
@@ -293,7 +337,7 @@ def tail_supported(seq):
     """True when fused_stack(seq, ..., tail=...) can scatter the last layer's rows itself: split arithmetic, inference, a
     projection layer with at most 8 outputs and a multiple of 4 inputs last."""
     last = seq[len(seq) - 1]
-    return (MLP_ARITH == "split" and not torch.is_grad_enabled() and last.fc0 is not None and last.fc1.out_features <= 8
+    return (_kernel_arith() and not torch.is_grad_enabled() and last.fc0 is not None and last.fc1.out_features <= 8
             and last.fc1.in_features % 4 == 0)
 
 
@@ -302,7 +346,7 @@ def decode_supported(seq, x):
     a 192-wide projection layer (6 x 32 bins) last, preceded by a projection or nothing pending (no carried bias offset)."""
     last = seq[len(seq) - 1]
     plan, c = _fused_plan(seq)
-    return (MLP_ARITH == "split" and not torch.is_grad_enabled() and x.is_cuda and last.fc0 is not None
+    return (_kernel_arith() and not torch.is_grad_enabled() and x.is_cuda and last.fc0 is not None
             and last.fc1.out_features == 192 and last.fc1.in_features % 8 == 0 and c is None)
 
 
@@ -367,7 +411,7 @@ class BeyondCPPFShot(nn.Module):
     def gather_supported(self, feat_dim, k):
         """True when heads_from_tuples can feed the tuple encoder without materialising its input rows."""
         first = self.tuple_encoder[0]
-        return (MLP_ARITH == "split" and not torch.is_grad_enabled() and first.fc0 is not None and first.fc1.out_features == 128
+        return (_kernel_arith() and not torch.is_grad_enabled() and first.fc0 is not None and first.fc1.out_features == 128
                 and feat_dim >= 8 and feat_dim & (feat_dim - 1) == 0 and (k * (k - 1) // 2 * 4) % 8 == 0 and k <= 8
                 and first.fc1.in_features == k * (k - 1) // 2 * 4 + k * feat_dim)
 
@@ -405,7 +449,7 @@ class BeyondCPPFShot(nn.Module):
         head's last kernel (padded entries of each group skipped) and `out` is returned -- no index_put, no torch kernel."""
         first = self.scale_encoder[0]
         f = feat.shape[1]
-        if not (MLP_ARITH == "split" and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
+        if not (_kernel_arith() and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
                 and first.fc0 is not None and first.fc1.out_features == 128 and first.fc1.in_features == f
                 and f >= 8 and f & (f - 1) == 0 and feat.shape[0] < 2 ** 31):
             vals = self.scale_head(feat[rows.long()])

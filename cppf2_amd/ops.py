@@ -331,6 +331,58 @@ def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0, tap=None):
     return out
 
 
+def reslayer_split16_supported(k_in, n_out, proj, chain=0):
+    return k_in % 8 == 0 and _L.cppf_reslayer_split16_stream_bytes(int(k_in), int(n_out), int(bool(proj)), int(chain)) > 0
+
+
+def reslayer_split16(x, wq, b1, b0, n_out, scale, out=None, chain=0, tap=None, gather=None, decode=None):
+    """The ResLayer launches of reslayer_split / _gather / _decode in f16x2 arithmetic (cppf_reslayer_split16; not the default):
+    wq = models.pack_split(..., arith="f16x2", scale=scale), b1 / b0 = scale x the biases (scale a power of two).
+    gather = (gidx int32 [rows, k], table float32 [points, F]): x are the head columns; decode = (uniforms, prior | None, bins)."""
+    from ._lib import ReslayerSplit16Args
+    a = ReslayerSplit16Args()
+    b1 = b1.contiguous()
+    b0 = None if b0 is None else b0.contiguous()
+    keep = [b1, b0]
+    if gather is not None:
+        gidx, table = gather
+        rows = gidx.shape[0]
+        heads = x
+        a.x = heads.data_ptr() if heads.shape[1] else table.data_ptr()
+        a.ldx = heads.stride(0) if heads.shape[1] else 0
+        a.k_in = heads.shape[1]
+        a.gidx, a.slots, a.table, a.fdim = gidx.data_ptr(), gidx.shape[1], table.data_ptr(), table.shape[1]
+        out = torch.empty((rows, n_out), dtype=torch.float32, device=table.device)
+    else:
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        rows = x.shape[0]
+        a.x, a.ldx, a.k_in = x.data_ptr(), x.stride(0), x.shape[1]
+    if decode is not None:
+        uniforms, prior, bins = decode
+        uniforms = uniforms.contiguous()
+        prior = None if prior is None else prior.contiguous()
+        if bins is None:
+            bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
+        a.uniforms, a.bins = uniforms.data_ptr(), bins.data_ptr()
+        a.logit_prior = None if prior is None else prior.data_ptr()
+        keep += [uniforms, prior]
+        n_out = 192
+    else:
+        if out is None:
+            out = x if b0 is None else torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+    if tap is not None:
+        a.first_out, a.ld_first = tap.data_ptr(), tap.stride(0)
+    a.n_out, a.rows, a.chain = int(n_out), int(rows), int(chain)
+    a.wq, a.wq_bytes = wq.data_ptr(), wq.numel() * wq.element_size()
+    a.b1 = b1.data_ptr()
+    a.b0 = None if b0 is None else b0.data_ptr()
+    a.weight_scale = float(scale)
+    a.stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_L.cppf_reslayer_split16(C.byref(a)), "cppf_reslayer_split16")
+    return bins if decode is not None else out
+
+
 def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
     """The logit head's output layer (192-wide projection ResLayer) with the bin draw of eval.py:225-229 as its epilogue
     (cppf_reslayer_split_decode): bins int32 [rows, 6] = what decode_bins draws from these logits (+ prior) at `uniforms`

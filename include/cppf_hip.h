@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 6
+#define CPPF_ABI_VERSION 7
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -385,6 +385,29 @@ int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_
 int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
                           const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
                           float* scaled, float* scale, float* tr, float* rot, void* stream);
+
+/* ---- the same ResLayer launches in f16x2 arithmetic (cppf2_amd.models.MLP_ARITH = "split16"; not the default): every
+ * float32 operand as an fp16 pair hi + lo (RNE; 22-23 significant bits), the three products hi hi + hi lo + lo hi on the fp16
+ * matrix cores, float32 accumulate -- half the matrix-core work of the exact bf16-triple form, error against float64 at the
+ * level of a float32 GEMM's accumulation error (tests/test_mlp_split.py, bench.py mlp_error_vs_f64), but NOT exact products, and
+ * fp16's range: activations must stay below 65504 in magnitude (larger ones become Inf -> NaN rows); activations whose lo piece
+ * is subnormal keep an absolute resolution of 2^-25.  wq = fp16 (hi, lo) fragment pairs of weight_scale x the weights in the
+ * fragment order of cppf_reslayer_split (cppf_reslayer_split16_stream_bytes bytes), b1 / b0 = weight_scale x the biases,
+ * weight_scale a power of two chosen so that the largest |weight| x weight_scale is ~2^13.  One struct for all launch forms:
+ * plain (x, out[, first_out = tap]); gather (gidx != NULL: x = heads with k_in head columns, table, slots, fdim; n_out = 128);
+ * decode (uniforms != NULL: n_out = 192, chain = 0, bins out, logit_prior optional).  Unused members must be zero. */
+typedef struct CppfReslayerSplit16Args {
+  const float* x; int64_t ldx; int32_t k_in;
+  float* out; int64_t ldo; int32_t n_out; int64_t rows;
+  const void* wq; int64_t wq_bytes; const float* b1; const float* b0; int32_t chain;
+  float weight_scale;
+  float* first_out; int64_t ld_first;
+  const int32_t* gidx; int32_t slots; const float* table; int32_t fdim;
+  const float* logit_prior; const float* uniforms; int32_t* bins;
+  void* stream;
+} CppfReslayerSplit16Args;
+int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
+int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);
 
 /* Test hook: workgroups > 0 forces the number of persistent workgroups of every later cppf_reslayer_split* launch of this
  * process (the kernels' results do not depend on it; tests/test_mlp_split.py runs the counted-wait protocol at 1, 7 and all
