@@ -325,6 +325,14 @@ def test_counted_wait_protocol_race_screen():
         rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(chain)]
         return models.pack_split(w1, w0, w2, k, chain=rest), mk((1 + chain) * n) * 0.1, (mk(n) * 0.1 if proj else None)
 
+    def layer16(k, n, proj, chain):
+        w1, w2 = mk(n, k) / k ** 0.5, mk(n, n) / n ** 0.5
+        w0 = mk(n, k) / k ** 0.5 if proj else None
+        rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(chain)]
+        sc = models.f16_scale(w1, w0, w2, *[w for p in rest for w in p])
+        return (models.pack_split(w1, w0, w2, k, chain=rest, arith="f16x2", scale=sc), mk((1 + chain) * n) * 0.1 * sc,
+                (mk(n) * 0.1 * sc if proj else None), sc)
+
     cases = []
     for n in (64, 128, 192, 256):
         for proj in (False, True):
@@ -333,6 +341,10 @@ def test_counted_wait_protocol_race_screen():
                 wq, b1, b0 = layer(k, n, proj, chain)
                 cases.append(("n%d proj%d chain%d" % (n, proj, chain),
                               lambda x, wq=wq, b1=b1, b0=b0, n=n, chain=chain: ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=chain), k))
+            chain = 2
+            wq, b1, b0, sc = layer16(k, n, proj, chain)          # the f16x2 instantiations of the same kernels
+            cases.append(("f16x2 n%d proj%d chain%d" % (n, proj, chain),
+                          lambda x, wq=wq, b1=b1, b0=b0, n=n, chain=chain, sc=sc: ops.reslayer_split16(x.clone(), wq, b1, b0, n, sc, chain=chain), k))
     # the gathering first layer (heads 40 + 5 x 64 table columns) with its chain, and the output layer with the bin draw
     wq_g, b1_g, b0_g = layer(360, 128, True, 4)
     table = mk(5000, 64)
@@ -406,3 +418,140 @@ def test_tapped_first_layer_equals_the_separate_launches():
         cls2_want = models.fused_stack(net.logit_encoder, feat_want.clone())
         assert (cls2.reshape(5000, -1) - cls2_want).abs().max().item() < 4e-6 * max(1.0, cls2_want.abs().max().item())
         assert (cls2 - cls).abs().max().item() > 1e-3
+
+
+def test_f16_pairs_carry_22_bits_and_the_host_packing_has_the_documented_layout():
+    """models.split_f16 / pack_split(arith="f16x2"): hi + lo reproduces scale x w to 2^-22 relative (2^-25 absolute where lo is
+    subnormal), both pieces are finite for |scale x w| < 2^14, and the stream has two fragments per tile in the bf16 order."""
+    from cppf2_amd import models
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(256, 256, generator=g) / 16
+    sc = models.f16_scale(w)
+    assert 2 ** 12 <= float((w * sc).abs().max()) <= 2 ** 13 and sc == 2.0 ** round(float(torch.log2(torch.tensor(sc))))
+    pieces = models.split_f16(w * sc)
+    assert pieces.dtype == torch.float16 and torch.isfinite(pieces).all()
+    back = pieces[0].double() + pieces[1].double()
+    err = (back - (w * sc).double()).abs()
+    assert float((err / (w * sc).double().abs().clamp_min(2.0 ** -2)).max()) < 2.0 ** -21.9
+    a3 = models.pack_split(w[:128, :128].contiguous(), None, w[128:, 128:].contiguous(), 128)
+    a2 = models.pack_split(w[:128, :128].contiguous(), None, w[128:, 128:].contiguous(), 128, arith="f16x2", scale=sc)
+    assert a2.dtype == torch.float16 and a3.dtype == torch.bfloat16 and a2.numel() * 3 == a3.numel() * 2
+    # first fragment of the stream = hi pieces of W1 rows 0..31 (lane i) at input features 8 g + j of K step 0
+    frag = a2[:512].reshape(2, 32, 8).float()
+    want = pieces[0][:128, :128][:32, :16].reshape(32, 2, 8).permute(1, 0, 2).float()
+    assert torch.equal(frag, want)
+
+
+@pytest.mark.gpu
+def test_reslayer_split16_matches_float64_like_a_float32_gemm():
+    """The f16x2 kernels (cppf_reslayer_split16) on every supported shape, plain / chained / tapped / gathered / with the bin
+    draw: error against float64 under the same bound as the exact bf16-triple kernels (a few 2^-24 of the output scale, no worse
+    than 3x the library float32 GEMMs'), and in practice below the bf16-triple kernels' own error (fewer accumulator roundings)."""
+    from cppf2_amd import models, ops
+    dev = torch.device("cuda:0")
+    ratio16, ratio3 = [], []
+    for k, n, proj, chain in [(k_, n_, p_, 0) for k_, n_, p_ in SHAPES] + [(360, 128, True, 4), (352, 128, True, 4), (128, 128, False, 3),
+                                                                             (64, 64, False, 1), (128, 64, True, 2), (128, 256, True, 2),
+                                                                             (256, 256, False, 1), (256, 192, True, 1)]:
+        w1, b1, w0, b0, w2 = _layer(k, n, proj, dev, seed=k * 7 + n)
+        rest = [_layer(n, n, False, dev, seed=20 + l) for l in range(chain)]
+        pairs = [(e[0], e[4]) for e in rest]
+        sc = models.f16_scale(w1, w0, w2, *[w for p in pairs for w in p])
+        wq16 = models.pack_split(w1, w0, w2, k, chain=pairs, arith="f16x2", scale=sc)
+        wq3 = models.pack_split(w1, w0, w2, k, chain=pairs)
+        bias = torch.cat([b1] + [e[1] for e in rest])
+        for rows in (1, 257, 3001):
+            x = torch.randn(rows, k, device=dev, generator=torch.Generator(device=dev).manual_seed(rows))
+            want = _ref64(x, w1, b1, w0, b0, w2)
+            nat = torch.addmm(x if w0 is None else torch.addmm(b0, x, w0.t()), torch._addmm_activation(b1, x, w1.t()), w2.t())
+            for e in rest:
+                want = _ref64(want, e[0], e[1], None, None, e[4])
+                nat = torch.addmm(nat, torch._addmm_activation(e[1], nat, e[0].t()), e[4].t())
+            got = ops.reslayer_split16(x.clone(), wq16, bias * sc, None if b0 is None else b0 * sc, n, sc, chain=chain)
+            got3 = ops.reslayer_split(x.clone(), wq3, bias, b0, n, chain=chain)
+            scale = want.abs().max().item()
+            e16 = (got.double() - want.double()).abs().max().item() / scale
+            e3 = (got3.double() - want.double()).abs().max().item() / scale
+            e_nat = (nat.double() - want.double()).abs().max().item() / scale
+            assert e16 < 3e-6 and e16 < 3.0 * e_nat + 2e-7, (k, n, proj, chain, rows, e16, e_nat)
+            if rows == 3001:
+                r16 = ((got.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+                r3 = ((got3.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+                rn = ((nat.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+                ratio16.append(r16 / rn)
+                ratio3.append(r3 / rn)
+            # rows do not depend on the batch they sit in
+            if rows == 257:
+                assert torch.equal(got[:31], ops.reslayer_split16(x[:31].clone(), wq16, bias * sc, None if b0 is None else b0 * sc, n, sc, chain=chain))
+    # rms error relative to the library float32 GEMMs': f16x2 stays within 1.6x on every shape and is on average no worse than
+    # the exact bf16 triples
+    assert max(ratio16) < 1.6 and sum(ratio16) / len(ratio16) <= sum(ratio3) / len(ratio3) + 0.05, (ratio16, ratio3)
+    # tap: first layer's output and the chain's, both equal to the untapped launches of the same arithmetic
+    k, n, chain = 128, 256, 2
+    w1, b1, w0, b0, w2 = _layer(k, n, True, dev, seed=5)
+    rest = [_layer(n, n, False, dev, seed=30 + l) for l in range(chain)]
+    pairs = [(e[0], e[4]) for e in rest]
+    sc = models.f16_scale(w1, w0, w2, *[w for p in pairs for w in p])
+    wq = models.pack_split(w1, w0, w2, k, chain=pairs, arith="f16x2", scale=sc)
+    bias = torch.cat([b1] + [e[1] for e in rest]) * sc
+    x = torch.randn(2000, k, device=dev)
+    tap = torch.empty(2000, n, device=dev)
+    out = ops.reslayer_split16(x, wq, bias, b0 * sc, n, sc, chain=chain, tap=tap)
+    assert torch.equal(out, ops.reslayer_split16(x, wq, bias, b0 * sc, n, sc, chain=chain))
+    first_want = _ref64(x, w1, b1, w0, b0, w2)
+    assert (tap.double() - first_want).abs().max().item() < 2e-6 * first_want.abs().max().item()
+    # NaN stays NaN; an activation beyond fp16's range turns its row non-finite instead of silently wrong
+    xx = torch.randn(64, k, device=dev)
+    xx[3, 5] = float("nan")
+    xx[7, 1] = 1e6
+    got = ops.reslayer_split16(xx, wq, bias, b0 * sc, n, sc, chain=chain)
+    assert torch.isnan(got[3]).all() and not torch.isfinite(got[7]).any() and torch.isfinite(got[[0, 1, 2, 4, 5, 6, 8]]).all()
+    # bad arguments
+    from cppf2_amd import _lib
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split16(x, wq, bias, b0 * sc, n, 3.0, chain=chain)            # scale not a power of two
+    with pytest.raises(_lib.CppfError):
+        ops.reslayer_split16(x, wq[:-8], bias, b0 * sc, n, sc, chain=chain)        # stream size
+
+
+@pytest.mark.gpu
+def test_models_in_f16x2_arithmetic_match_the_modules_and_their_own_unfused_forms():
+    """MLP_ARITH = "split16" through fused_stack: the SHOT model's forward against the plain float32 modules (3e-5), the gathered
+    first layer bit-identical to the materialised rows, the fused bin draw bit-identical to decode_bins on the same arithmetic's
+    logits, and the logits within 2e-5 of the exact bf16-triple arithmetic's."""
+    import os
+    from cppf2_amd import models, ops
+    from cppf2_amd.config import load_config
+    dev = torch.device("cuda:0")
+    cfg = load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config"), "config", ["category=bottle"])
+    torch.manual_seed(4)
+    net = models.BeyondCPPFShot(cfg).to(dev).eval()
+    N, T = 1500, 6000
+    pts = torch.randn(N, 3, device=dev) * 0.05
+    nrm = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    sfeat = torch.rand(N, 352, device=dev)
+    idx = torch.randint(0, N, (T, 5), device=dev, dtype=torch.int32)
+    u = torch.rand(T, 6, device=dev)
+    prev = models.MLP_ARITH
+    try:
+        with torch.no_grad():
+            want_cls, want_scale = net(pts, idx.long(), sfeat, nrm)            # plain modules (library float32)
+            models.MLP_ARITH = "split16"
+            feat = net.encode_points(sfeat)
+            assert (feat - net.shot_encoder(sfeat)).abs().max().item() < 2e-5 * max(1.0, feat.abs().max().item())
+            x = ops.encode_tuples_shot(pts, idx, feat, nrm)
+            cls_m, sc_m = net.heads(x.clone())
+            assert (cls_m - want_cls).abs().max().item() < 3e-5 * max(1.0, want_cls.abs().max().item())
+            assert (sc_m - want_scale).abs().max().item() < 3e-5 * max(1.0, want_scale.abs().max().item())
+            cls_g, sc_g = net.heads_from_tuples(pts, idx, feat, nrm)           # gathered first layer: same arithmetic, same bits
+            assert torch.equal(cls_g, cls_m) and torch.equal(sc_g, sc_m)
+            bins = torch.empty(T, 6, dtype=torch.int32, device=dev)
+            none, _ = net.heads_from_tuples(pts, idx, feat, nrm, decode=(u, None, bins))
+            assert none is None
+            want_bins = ops.decode_bins(cls_m.contiguous(), u, pts, idx, cfg.up, cfg.front, cfg.right)["bins"]
+            assert torch.equal(bins, want_bins)
+            models.MLP_ARITH = "split"
+            cls_3, _ = net.heads(x.clone())
+            assert (cls_3 - cls_m).abs().max().item() < 2e-5 * max(1.0, want_cls.abs().max().item())
+    finally:
+        models.MLP_ARITH = prev
