@@ -90,9 +90,13 @@ def parse():
                          "that survive the back-vote filter, the only rows eval.py:272 ever reads)")
     ap.add_argument("--no-reference-order", action="store_true",
                     help="skip the second timed loop that measures the other scale-head placement (value_reference_order)")
-    ap.add_argument("--mlp-arith", choices=("split", "native"), default=None,
-                    help="arithmetic of the tuple MLP: split = float32 as 3 x bf16 on the bf16 matrix cores (default, "
-                         "cppf_reslayer_split), native = f32-input matrix cores (library GEMMs + cppf_reslayer128)")
+    ap.add_argument("--mlp-arith", choices=("split", "split16", "native"), default=None,
+                    help="arithmetic of the tuple MLP: split = float32 as 3 x bf16 on the bf16 matrix cores (default, exact "
+                         "products, cppf_reslayer_split), split16 = float32 as 2 x fp16 (22-23 bits per operand, half the "
+                         "matrix-core work, cppf_reslayer_split16), native = f32-input matrix cores (library GEMMs + "
+                         "cppf_reslayer128)")
+    ap.add_argument("--no-f16x2", action="store_true",
+                    help="skip the extra timed loop with the MLP in f16x2 arithmetic (value_f16x2_mfma)")
     ap.add_argument("--materialize-tuples", action="store_true",
                     help="write the [T, 360] tuple rows (cppf_encode_tuples_shot) and let the MLP read them back, instead of "
                          "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
@@ -150,7 +154,7 @@ class Step:
     @property
     def gather(self):
         from cppf2_amd import models
-        return (not self.materialize) and models.MLP_ARITH == "split" and self.model.gather_supported(64, 5)
+        return (not self.materialize) and models.MLP_ARITH in ("split", "split16") and self.model.gather_supported(64, 5)
 
     EVENT_SLOTS = 8      # timed steps sampled for the per-stage HIP-event times (events created and first recorded before timing)
 
@@ -366,20 +370,25 @@ def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
     feat = step.model.encode_points(step.shot[:sc * N])
     x = ops.encode_tuples_shot(step.pts[:sc * N], idx, feat, step.normal[:sc * N], pt_off, tup_off)
     out = {}
-    if M.MLP_ARITH == "split":
+    if M.MLP_ARITH in ("split", "split16"):
+        arith0 = M.MLP_ARITH
         xe = x[:rows_err].contiguous()
         m64 = copy.deepcopy(step.model).double()
         want = m64.logit_encoder(m64.tuple_encoder(xe.double()))
         scale = want.abs().max().item()
+        M.MLP_ARITH = "split"
         split = M.fused_stack(step.model.logit_encoder, M.fused_stack(step.model.tuple_encoder, xe.clone()))
+        M.MLP_ARITH = "split16"
+        split16 = M.fused_stack(step.model.logit_encoder, M.fused_stack(step.model.tuple_encoder, xe.clone()))
+        M.MLP_ARITH = arith0
         native = step.model.logit_encoder(step.model.tuple_encoder(xe))              # plain nn.Linear: library f32 GEMMs
 
         def err(t):
             d = t.double() - want
             return {"max": d.abs().max().item() / scale, "rms": d.pow(2).mean().sqrt().item() / scale}
         out["mlp_error_vs_f64"] = {"rows": int(xe.shape[0]), "logit_scale": scale, "split_bf16x3": err(split),
-                                   "library_f32_gemm": err(native),
-                                   "note": "relative to max |logit|; split = the arithmetic the timed step runs"}
+                                   "split_f16x2": err(split16), "library_f32_gemm": err(native),
+                                   "note": "relative to max |logit|; the timed step runs " + ("split_bf16x3" if arith0 == "split" else "split_f16x2")}
     logits = step.model.heads(x, lazy_scale=True)[0].contiguous()                  # [sc*T, 6, 32]
     u = ops.philox_uniform(T, 6, a.seed, 1, ids, dev)
     prior = step.prior[:sc * T]
@@ -533,11 +542,24 @@ def main():
 
     # the same step with the tuple MLP on the f32-input matrix cores (the arithmetic of rounds 1-2), same loop protocol
     dt_native = None
+    headline_arith = _models.MLP_ARITH
     if _models.MLP_ARITH == "split" and not args.no_native_arith:
         _models.MLP_ARITH = "native"
         step.run()
         dt_native, _ = timed_loop(args.steps, sample=False)
         _models.MLP_ARITH = "split"
+
+    # the same step with the MLP in f16x2 arithmetic (fp16 operand pairs, three products per K step: half the matrix-core work;
+    # error against float64 reported under mlp_error_vs_f64.split_f16x2); same loop protocol; not the headline
+    dt_f16 = None
+    if _models.MLP_ARITH == "split" and not args.no_f16x2:
+        _models.MLP_ARITH = "split16"
+        step.run()
+        dt_f16, _ = timed_loop(args.steps, sample=False)
+        rec16 = step.pipe.results.clone()
+        _models.MLP_ARITH = "split"
+        step.run()                  # the records the rest of the report reads are the headline arithmetic's
+        torch.cuda.synchronize()
 
     # Experimental, not the headline: consecutive steps (independent scene batches) alternating between TWO HIP streams, each
     # with its own buffers, so that one step's descriptor / voting kernels run beside the other's matrix-core kernels.  Same loop
@@ -628,7 +650,8 @@ def main():
                         stages_sharing_the_chip_with_torch=sorted(shared),
                         per_kernel=per_kernel,
                         per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
-        if _models.MLP_ARITH == "split":
+        if _models.MLP_ARITH in ("split", "split16"):
+            nprod = 6.0 if _models.MLP_ARITH == "split" else 3.0
             # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 3 launches back to back: the stage
             # time is their sum): matrix-core bound.  `achieved` = the bf16 MFMA work it executes (6 exact-product MFMAs per
             # float32 product, K padded to 16) over the stage's HIP-event time, against the dense bf16 peak; the
@@ -638,7 +661,7 @@ def main():
             layers = [(360, 128, True)] + [(128, 128, False)] * 4 + [(128, 256, True), (256, 256, False), (256, 256, False), (256, 192, True)]
             if args.eager_scale_head:           # the scale head's matrix-core layers run inside this stage too (on every tuple)
                 layers += [(256, 128, True), (128, 64, True)]
-            executed = 6.0 * sum(layer_flops(*l)[0] for l in layers) * B * T
+            executed = nprod * sum(layer_flops(*l)[0] for l in layers) * B * T
             algorithmic = sum(layer_flops(*l)[1] for l in layers) * B * T
             mlp_ms_ = stage_ms["tuple_mlp"]
             hbm = {k_: roofline[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
@@ -646,15 +669,18 @@ def main():
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
-                            launch_ms=mlp_ms_, launches=3, frac_kind="executed_bf16_mfma",
+                            launch_ms=mlp_ms_, launches=3,
+                            frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
                             traffic_covers="the same 3 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             # the same launch time against the other two readings of "algorithmic / peak"
                             frac_algorithmic_of_f32_input_mfma_peak=algorithmic / 1e12 / (mlp_ms_ / 1e3) / F32_MFMA_PEAK_TFLOPS,
                             frac_algorithmic_of_bf16_peak=algorithmic / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS,
-                            algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = 6 bf16 "
-                                              "MFMA products per float32 product (3-way exact operand split)" % (B * T),
+                            algorithmic_model="tuple MLP of train_shot.py:48-73 at %d tuples: 2 M K N per Linear; executed = %d %s "
+                                              "MFMA products per float32 product (%s)"
+                                              % (B * T, int(nprod), "bf16" if nprod == 6.0 else "fp16",
+                                                 "3-way exact operand split" if nprod == 6.0 else "fp16 operand pairs, 22-23 bits"),
                             hbm=hbm)
             roofline.pop("algorithmic_bytes_per_launch", None)
         # sanity of the synthetic workload: pose agreement with ground truth (5 deg / 5 cm on the up axis + centre)
@@ -695,7 +721,10 @@ def main():
                                    % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only",
                                       "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
                                       "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
-                                      if _models.MLP_ARITH == "split" else "f32-input matrix cores",
+                                      if _models.MLP_ARITH == "split" else
+                                      ("float32 operands as fp16 pairs (22-23 significant bits), 3 products on the fp16 matrix "
+                                       "cores, float32 accumulate (error vs float64 at the library float32 GEMMs' level; NOT exact "
+                                       "products)" if _models.MLP_ARITH == "split16" else "f32-input matrix cores"),
                                       ("gathered inside the first ResLayer's kernel (never written)" if GATHERED_TUPLES
                                        else "materialised ([T, 360] float32)")
                                       + ("; bins drawn in the epilogue of the logit head's output layer (logits never written)"
@@ -706,6 +735,9 @@ def main():
                 (total_scenes / dt_other) if dt_other else None,
             # the same run with the MLP on the f32-input matrix instruction (no operand splitting)
             "value_f32_input_mfma": (total_scenes / dt_native) if dt_native else None,
+            # the same run with the MLP in f16x2 arithmetic (operands as fp16 pairs, 22-23 bits; not the headline: products are
+            # not exact there -- its error against float64 is under mlp_error_vs_f64.split_f16x2)
+            "value_f16x2_mfma": (total_scenes / dt_f16) if dt_f16 else None,
             # experimental: the same steps alternating between two HIP streams (not the headline; see the note inside)
             "two_streams": two,
             "records_gathered": int(all_rec.shape[0]),
