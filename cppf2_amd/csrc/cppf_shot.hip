@@ -30,6 +30,10 @@
 #define SH_COPIES 1
 #endif
 #define SH_STRIDE 353
+#ifndef SHOT_DBG
+#define SHOT_DBG 0     // timing probes (scratch/shot_sections.sh): 1 = no sign pass, 2 = no accumulation, 4 = no normalisation, 8 = the compiler's float division, 16 = the general tie pass, 32 = float64 sign pass;
+                       // shot_cov: 64 = no covariance sums, 128 = no reduction, 256 = no neighbour list to the workspace
+#endif
 // Neighbour lists handed from shot_cov to shot_hist through the workspace (entries per query; longer lists are rebuilt)
 #define NBR_CAP 512
 
@@ -460,13 +464,14 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
       if (in) {
         const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
         if (pos < COV_LIST) s_nb[pos] = qv;
-        if (pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
+        if (!(SHOT_DBG & 256) && pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
       }
       m += __popcll(mask);
     }
   }
   __syncthreads();
-  if (m <= COV_LIST) {
+  if (SHOT_DBG & 64) {
+  } else if (m <= COV_LIST) {
     for (int c = lane; c < m; c += 64) cov_accumulate(s_nb[c], px, py, pz, rn2, rs2, rs, a);
   } else {
     // more neighbours than the list holds (a support radius far above the cloud's resolution): the sums straight from the runs
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
     nbr_cnt[qi] = m;
     if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
   }
+  if (SHOT_DBG & 128) { if (lane < NSUM) sums[(int64_t)qi * NSUM + lane] = a[lane % 3]; return; }
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) {
     a[c] += __shfl_xor(a[c], 32);                  // lane l < 32: its own partial + lane l + 32's
@@ -694,6 +700,14 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   }
   __syncthreads();
   const bool listed = (m <= SH_LCAP);
+  // the usual case (m <= 128): each lane keeps its two neighbours' positions and normals in registers for all passes, so the
+  // sign pass, the histogram pass and (shot_accumulate) the normals are one round of gathers instead of three dependent ones
+  const bool small = !COLOR && m <= 128;
+  float4 cp0 = make_float4(px, py, pz, 0.0f), cp1 = cp0, cn0 = cp0, cn1 = cp0;
+  if (small) {
+    if (lane < m) { const int j = s_list[lane]; cp0 = sp[j]; cn0 = sn[j]; }
+    if (lane + 64 < m) { const int j = s_list[lane + 64]; cp1 = sp[j]; cn1 = sn[j]; }
+  }
   // candidates of the later sweeps: the list, or (overflow) every point of the 9 runs again
   double v1[3] = {lp.v1[0], lp.v1[1], lp.v1[2]}, v3[3] = {lp.v3[0], lp.v3[1], lp.v3[2]};
   int plus1 = 0, plus3 = 0, c1 = 0, c3 = 0;
@@ -710,30 +724,81 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   } else {                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 9; ++k)                                            \
       for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {                               \
-        const int j = min(jb + lane, runs.end[k] - 1);                                       \
+        const int j = min(jb + lane, runs.end[k] - 1), base = 0;                             \
         const float4 qv_ = sp[j];                                                            \
+        (void)base;                                                                          \
         const bool act = (jb + lane < runs.end[k]) && (sqdist3(px, py, pz, qv_.x, qv_.y, qv_.z) < r2); \
         __VA_ARGS__                                                                               \
       }                                                                                      \
   }
 
+  // Sign of the projections on v1 / v3 (the reference's float64 dot product): a float32 dot decides it whenever it is further from
+  // zero than 2e-6 (|x| + |y| + |z|) -- eight times the worst float32 error for a unit vector -- and only the lanes it leaves
+  // open evaluate the float64 expression (rare: the wavefront skips that arm otherwise).
+  const float v1f[3] = {(float)v1[0], (float)v1[1], (float)v1[2]}, v3f[3] = {(float)v3[0], (float)v3[1], (float)v3[2]};
+  if (!(SHOT_DBG & 1)) {
   FOR_EACH_NEIGHBOUR({
     bool p1 = false, p3 = false;
     if (act) {
-      const float4 qv = sp[j];
+      const float4 qv = small ? (base == 0 ? cp0 : cp1) : sp[j];
       const float qx = qv.x, qy = qv.y, qz = qv.z;
       if (!(qx == px && qy == py && qz == pz)) {
-        const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-        p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
-        p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
+        const float xf = qx - px, yf = qy - py, zf = qz - pz;
+        const float d1 = fmaf(zf, v1f[2], fmaf(yf, v1f[1], xf * v1f[0]));
+        const float d3 = fmaf(zf, v3f[2], fmaf(yf, v3f[1], xf * v3f[0]));
+        const float bnd = 2e-6f * ((fabsf(xf) + fabsf(yf)) + fabsf(zf));
+        p1 = d1 > 0.0f;
+        p3 = d3 > 0.0f;
+        if ((SHOT_DBG & 32) || !(fabsf(d1) > bnd) || !(fabsf(d3) > bnd)) {
+          const double x = (double)xf, y = (double)yf, z = (double)zf;
+          p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
+          p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
+        }
       }
     }
     plus1 += __popcll(__ballot(p1));
     plus3 += __popcll(__ballot(p3));
   })
+  }
   plus1 = 2 * plus1 - valid;
   plus3 = 2 * plus3 - valid;
-  if (plus1 == 0 || plus3 == 0) {
+  if ((plus1 == 0 || plus3 == 0) && small && !(SHOT_DBG & 16)) {
+    // tie (one query in six: an even count splits evenly about as often as a fair coin does) with the neighbours in registers:
+    // a neighbour's rank in the (distance, original index) order is the number of smaller 64-bit keys (distance bits : index);
+    // the keys go through the unused upper part of the list buffer and every lane scans them for its two neighbours
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_list + 256);
+    auto key_of = [&](const float4 q, bool in) {
+      const bool self = (q.x == px && q.y == py && q.z == pz);
+      return (!in || self) ? ~0ull
+                           : (((unsigned long long)__float_as_uint(sqdist3(px, py, pz, q.x, q.y, q.z)) << 32) |
+                              (unsigned long long)(uint32_t)__float_as_int(q.w));
+    };
+    const unsigned long long k0 = key_of(cp0, lane < m), k1 = key_of(cp1, lane + 64 < m);
+    s_key[lane] = k0;
+    s_key[lane + 64] = k1;
+    __syncthreads();
+    int rk0 = 0, rk1 = 0;
+    for (int c2 = 0; c2 < m; ++c2) {
+      const unsigned long long kk = s_key[c2];
+      rk0 += (kk < k0) ? 1 : 0;
+      rk1 += (kk < k1) ? 1 : 0;
+    }
+    auto decide = [&](const float4 q, unsigned long long key, int rank, bool& h1, bool& h3) {
+      h1 = false; h3 = false;
+      if (key != ~0ull && rank >= med - 2 && rank <= med + 2) {
+        const double x = (double)(q.x - px), y = (double)(q.y - py), z = (double)(q.z - pz);
+        h1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) > 0.0;
+        h3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) > 0.0;
+      }
+    };
+    bool h1a, h3a, h1b, h3b;
+    decide(cp0, k0, rk0, h1a, h3a);
+    decide(cp1, k1, rk1, h1b, h3b);
+    c1 = __popcll(__ballot(h1a)) + __popcll(__ballot(h1b));
+    c3 = __popcll(__ballot(h3a)) + __popcll(__ballot(h3b));
+    if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
+    if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
+  } else if (plus1 == 0 || plus3 == 0) {
     // tie: the 5 neighbours around the median of the (distance, original index)-sorted valid list decide
     FOR_EACH_NEIGHBOUR({
       bool h1 = false, h3 = false;
@@ -810,7 +875,15 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   // usual m < 128) is below the float rounding of the bins it replaces.
   const float fx_scale = (float)(1u << (29 - (32 - __clz(m))));
   __syncthreads();
-  if (listed) {
+  if (SHOT_DBG & 2) {
+  } else if (small) {
+    if (lane < m)
+      shot_accumulate<COLOR>(px, py, pz, cp0.x, cp0.y, cp0.z, sqdist3(px, py, pz, cp0.x, cp0.y, cp0.z), cn0.x, cn0.y, cn0.z, s_rf,
+                             radius, hist, fx_scale);
+    if (m > 64 && lane + 64 < m)
+      shot_accumulate<COLOR>(px, py, pz, cp1.x, cp1.y, cp1.z, sqdist3(px, py, pz, cp1.x, cp1.y, cp1.z), cn1.x, cn1.y, cn1.z, s_rf,
+                             radius, hist, fx_scale);
+  } else if (listed) {
     // the next 64 neighbours' positions and normals are requested before the current 64 are accumulated
     bool act = lane < m;
     float4 qp, qn, ql = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -845,19 +918,30 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   }
 #undef FOR_EACH_NEIGHBOUR
   __syncthreads();
+  if (SHOT_DBG & 4) { for (int c = lane; c < LEN; c += 64) __builtin_nontemporal_store(__uint_as_float(s_hist[c]), &o[c]); return; }
   double acc = 0.0;
+  const float fx_inv = 1.0f / fx_scale;                // a power of two, like fx_scale: the product below is exact
   for (int c = lane; c < LEN; c += 64) {
     uint32_t u = s_hist[c];
 #pragma unroll
     for (int k = 1; k < (COLOR ? 1 : SH_COPIES); ++k) u += s_hist[k * SH_STRIDE + c];
-    const float v = (float)u / fx_scale;               // power-of-two scale: exact
+    const float v = (float)u * fx_inv;
     s_hist[c] = __float_as_uint(v);                    // each bin is folded by the lane that normalises it below
     acc += (double)v * (double)v;
   }
   acc = sqrt(wave_sum(acc));
   const float facc = (float)acc;
+  // v / facc, correctly rounded, as the float division's own expansion computes it (reciprocal refined once, quotient refined
+  // twice with exact remainders) without its range scaling: bins are 0 or >= 2^-29 and facc is their norm, far from the ranges
+  // that need it; 0 / 0 still gives NaN.  The reciprocal is shared by the 352 quotients.
+  const float r0 = __builtin_amdgcn_rcpf(facc);
+  const float r1 = fmaf(fmaf(-facc, r0, 1.0f), r0, r0);
   for (int c = lane; c < LEN; c += 64) {
-    float v = __uint_as_float(s_hist[c]) / facc;
+    const float x = __uint_as_float(s_hist[c]);
+    const float q0 = x * r1;
+    const float q1 = fmaf(fmaf(-facc, q0, x), r1, q0);
+    float v = fmaf(fmaf(-facc, q1, x), r1, q1);
+    if (SHOT_DBG & 8) v = x / facc;
     if (nan_to_zero && !(v == v)) v = 0.0f;            // an all-zero histogram normalises to 0/0
     __builtin_nontemporal_store(v, &o[c]);
   }
