@@ -482,7 +482,7 @@ def main():
     with torch.no_grad():           # the support checks look at the inference mode Step.run() executes in
         GATHERED_TUPLES = step.gather
         if GATHERED_TUPLES:
-            STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_kernel"
+            STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_tile_kernel"
             from cppf2_amd.models import decode_supported
             FUSED_DRAW = decode_supported(step.model.logit_encoder, torch.empty((1, 256), device=dev))
             if FUSED_DRAW:

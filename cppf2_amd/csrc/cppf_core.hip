@@ -420,6 +420,79 @@ __global__ __launch_bounds__(256) void encode_shot_heads_kernel(const float* __r
   }
 }
 
+// The same rows for a compile-time k, moved in whole cache lines: a workgroup takes 256 consecutive tuples, reads their k x 256
+// indices as one contiguous run (and writes the global indices the same way), every thread computes its tuple's 4 C(k,2)
+// features into an LDS tile (rows padded to 4 C(k,2) + 4 words: the 16-byte writes of 16 neighbouring lanes fall into different banks)
+// and the tile leaves as consecutive 16-byte stores -- the thread-per-tuple kernel above issues every store with a row pitch
+// between lanes and every index load with a 4 k-byte pitch.
+struct __attribute__((packed, aligned(4))) Row3 {
+  float x, y, z;
+};
+
+template <int KC>
+__global__ __launch_bounds__(256) void encode_shot_heads_tile_kernel(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                                     const int32_t* __restrict__ idx,
+                                                                     const int32_t* __restrict__ pt_off,
+                                                                     const int32_t* __restrict__ tup_off, ComboTable cb,
+                                                                     float* __restrict__ heads, int ld,
+                                                                     int32_t* __restrict__ gidx) {
+  constexpr int NP = KC * (KC - 1) / 2, NF = 4 * NP, PITCH = NF + 4;
+  __shared__ __attribute__((aligned(16))) float s_out[256 * PITCH];
+  __shared__ int32_t s_idx[256 * KC];
+  const unsigned b = blockIdx.y;
+  const int p0 = pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x * 256; tile < nt; tile += gridDim.x * 256) {
+    const int rows = min(256, nt - tile);
+    const int64_t row0 = (int64_t)t0 + tile;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int e = tid + 256 * i;
+      if (e < rows * KC) {
+        const int g = p0 + idx[row0 * KC + e];
+        s_idx[e] = g;
+        gidx[row0 * KC + e] = g;
+      }
+    }
+    __syncthreads();
+    if (tid < rows) {
+      float p[KC][3], n[KC][3];
+#pragma unroll
+      for (int q = 0; q < KC; ++q) {
+        const int g = s_idx[tid * KC + q];
+        // one 12-byte load each (the rows are 4-byte aligned): a third of the gather instructions, which is what bounds this kernel
+        const Row3 pv = *reinterpret_cast<const Row3*>(pts + 3 * (int64_t)g), nv = *reinterpret_cast<const Row3*>(nrm + 3 * (int64_t)g);
+        p[q][0] = pv.x; p[q][1] = pv.y; p[q][2] = pv.z;
+        n[q][0] = nv.x; n[q][1] = nv.y; n[q][2] = nv.z;
+      }
+      float o[4];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        float v;
+        if (f < 3 * NP) {
+          const int q = f / 3, c = f - 3 * q;
+          v = p[cb.i[q]][c] - p[cb.j[q]][c];
+        } else {
+          const int q = f - 3 * NP;
+          const float* ni = n[cb.i[q]];
+          const float* nj = n[cb.j[q]];
+          const float s_ = (ni[0] * nj[0] + ni[1] * nj[1]) + ni[2] * nj[2];
+          v = fmaxf(s_, -s_);
+        }
+        o[f & 3] = v;
+        if ((f & 3) == 3) *reinterpret_cast<float4*>(&s_out[tid * PITCH + (f - 3)]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < rows * NP; e += 256) {
+      const int r = e / NP, c4 = e - r * NP;
+      *reinterpret_cast<float4*>(heads + (row0 + r) * ld + 4 * c4) = *reinterpret_cast<const float4*>(&s_out[r * PITCH + 4 * c4]);
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int cppf_encode_tuples_shot_heads(int B, const float* pts, const float* normals, const int32_t* idx, int k,
                                              const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples,
                                              float* heads, int32_t ld_heads, int32_t* gidx, void* stream) {
@@ -432,8 +505,8 @@ extern "C" int cppf_encode_tuples_shot_heads(int B, const float* pts, const floa
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
   if (k == 5)
-    hipLaunchKernelGGL(encode_shot_heads_kernel<5>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, idx,
-                       k, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
+    hipLaunchKernelGGL(encode_shot_heads_tile_kernel<5>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals,
+                       idx, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
   else
     hipLaunchKernelGGL(encode_shot_heads_kernel<0>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, idx,
                        k, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);

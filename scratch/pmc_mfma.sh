@@ -2,7 +2,7 @@
 # usage: scratch/pmc_mfma.sh <tag> <script.py> [args]  -> matrix-pipe counters of reslayer_split_kernel launches -> gpurun_out/mfma_<tag>.json
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=$1; shift; cd /tmp
 rm -rf $R/gpurun_out/mf
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $R/gpurun_out/mf -o p -- python3 $R/$@ > $R/gpurun_out/mf.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_${MOPS:-BF16} --output-format csv -d $R/gpurun_out/mf -o p -- python3 $R/$@ > $R/gpurun_out/mf.log 2>&1
 cd $R
 python3 - "$TAG" <<'PY'
 import csv, collections, json, sys, glob
