@@ -28,6 +28,7 @@ power bound; the longest bandwidth-bound kernel under `roofline.hbm`; HIP-event 
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -304,7 +305,20 @@ TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false>#large", "resla
                      "reslayer_split_kernel<6, true, false, true>")
 
 
-def pmc_traffic_mlp():
+def _pmc_names(d, pieces):
+    """Keys of a PMC profile with the kernels' last template argument (operand pieces: 3 = bf16 triples, 2 = fp16 pairs) folded
+    away: {name without it: entry} for the instantiations of `pieces` (profiles older than that argument have none)."""
+    out = {}
+    for k_, v in d.items():
+        m = re.match(r"(reslayer_split_kernel<[^>]*?)(?:, ([23]))?>(#\w+)?$", k_)
+        if m and (m.group(2) is None or int(m.group(2)) == pieces):
+            out[m.group(1) + ">" + (m.group(3) or "")] = v
+        elif not m:
+            out[k_] = v
+    return out
+
+
+def pmc_traffic_mlp(pieces=3):
     """HBM bytes per step of the tuple MLP's three cppf_reslayer_split launches (the gathered 360 -> 128 chain; 128 -> 256 with
     the two 256-wide identity layers behind it; 256 -> 192 + bin draw: the launches `launch_ms` times) from the committed PMC passes; the
     gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under its own
@@ -312,7 +326,7 @@ def pmc_traffic_mlp():
     try:
         cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
         with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
-            d = json.load(f)
+            d = _pmc_names(json.load(f), pieces)
         if TUPLE_MLP_KERNELS[0] not in d:          # a profile written before the split by duration: all launches of a step
             passes = d["vote_worklist_kernel"]["launches"]
             tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
@@ -668,7 +682,7 @@ def main():
                                                "kernel_name", "algorithmic_bytes_per_launch", "algorithmic_model")}
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(),
+                            frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(3 if nprod == 6.0 else 2),
                             launch_ms=mlp_ms_, launches=3,
                             frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
                             traffic_covers="the same 3 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
