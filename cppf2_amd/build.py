@@ -16,9 +16,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
          "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-# per-file additions.  cppf_mlp_split: no SLP vectorisation -- it pairs adjacent float adds / subs into v_pk_add_f32, each of which
-# holds the matrix pipe for 16 cycles when it sits between two MFMAs (scratch/rs/filler_price.hip: 48.8 instead of 32.2 cycles per MFMA)
-FILE_FLAGS = {"cppf_mlp_split.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize (every file): no compiler-generated packed float32 arithmetic.  Two reasons, both measured in round 3:
+# (1) gfx950 erratum (scratch/rs/pk_victim4.hip, profiles/r3_pk_op_sel_erratum.md): v_pk_{mul,add,fma}_f32 whose LOW lane takes the
+#     HIGH half of source 1 (op_sel:[x,1]) occasionally computes that lane with source 1 = 0 while a wavefront of ANOTHER workgroup
+#     issues MFMAs on the same SIMD (1e-8 .. 1e-7 of the evaluations; never alone).  The SLP vectoriser emits exactly those forms
+#     (37 of them in the vote / SHOT / refinement kernels) -- harmless while one stream runs one kernel at a time, wrong votes as
+#     soon as a second stream runs the MLP kernels beside them.  tests/test_abi.py disassembles the built library and fails on any
+#     such instruction.
+# (2) a packed float32 instruction between two MFMAs holds the matrix pipe for 16 cycles (scratch/rs/filler_price.hip: 48.8
+#     instead of 32.2 cycles per MFMA), which is why cppf_mlp_split.hip was built this way first.
+FLAGS.append("-fno-slp-vectorize")
+FILE_FLAGS = {}
 
 
 def _stale(out, deps):

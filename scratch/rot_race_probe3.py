@@ -1,6 +1,8 @@
 """rot_bins beside different hogs / rot_bins variants: which combination changes the counts?"""
 import sys, os, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cppf2_amd import _lib
+if os.environ.get('CPPF_PROBE_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['CPPF_PROBE_LIB'])
 import torch
 import bench
 from cppf2_amd import models, ops
@@ -27,6 +29,7 @@ wqp256, bp1, bp0 = proj(128, 256)
 wqp192, bq1, bq0 = proj(256, 192)
 o256 = torch.empty(800000, 256, device=dev); o192 = torch.empty(400000, 192, device=dev)
 wq192i = layer(192, 192); x192 = torch.randn(400000, 192, device=dev)
+only = os.environ.get("CPPF_PROBE_HOGS")
 hogs = {"none": lambda: None,
         "proj128->256": lambda: ops.reslayer_split(x128, wqp256, bp1, bp0, 256, out=o256),
         "proj256->192": lambda: ops.reslayer_split(x256, wqp192, bq1, bq0, 192, out=o192),
@@ -43,7 +46,7 @@ for vname, vfn in victims.items():
     vfn(); torch.cuda.synchronize()
     ref = pipe.counts.clone()
     for hname, hfn in hogs.items():
-        if hfn is None: continue
+        if hfn is None or (only and hname not in only.split(',')): continue
         bad = 0
         for rep in range(10):
             with torch.cuda.stream(side):

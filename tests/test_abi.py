@@ -82,3 +82,31 @@ def test_percentile_params_match_numpy():
             want = np.percentile(x, ratio * 100)
             got = lo + d * g if g < 0.5 else hi - d * (np.float32(1) - g)
             assert np.float32(got) == np.float32(want), (n, ratio)
+
+
+def test_no_packed_float32_instruction_of_the_erratum_forms_in_the_library(tmp_path):
+    """gfx950 erratum measured in round 3 (scratch/rs/pk_victim4.hip, profiles/r3_pk_op_sel_erratum.md): v_pk_{mul,add,fma}_f32
+    whose low lane takes the HIGH half of source 1 (op_sel:[x,1,...]) occasionally computes that lane with source 1 = 0 while a
+    wavefront of another workgroup issues MFMAs on the same SIMD.  The library is built so that the compiler does not emit them
+    (cppf2_amd/build.py); this disassembles every gfx950 code object in the built .so and fails on any such instruction."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    from cppf2_amd import _lib
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "libcppf_hip.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert len(objs) >= 7, objs                    # one code object per .hip source
+    pat = re.compile(r"v_pk_(mul|add|fma)_f32\b.*\bop_sel:\[[01],1")
+    total = packed = 0
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, stdout=subprocess.PIPE, text=True).stdout
+        for line in dis.splitlines():
+            if "\tv_" in line or "\ts_" in line:
+                total += 1
+            if "v_pk_" in line and "_f32" in line:
+                packed += 1
+                assert not pat.search(line), "packed float32 instruction of an erratum form in %s: %s" % (o, line.strip())
+    assert total > 100000          # the disassembly really covered the kernels
