@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2 --no-two-streams > /dev/null 2>&1
 done
 cd $R
 python3 - <<PY

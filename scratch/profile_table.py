@@ -35,7 +35,7 @@ for r in stats:
     rows.append((key, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, hbm))
 rows.sort(key=lambda x: -x[1] * x[2])
 with open(os.path.join(P, RND + "_summary.md"), "w") as f:
-    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2`, %d passes incl. priming)\n\n" % (RND, steps))
+    f.write("# Round profile summary %s (one MI355X, `python bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2 --no-two-streams`, %d passes incl. priming)\n\n" % (RND, steps))
     f.write("Sources: `%s_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of that command; `%s_pmc_traffic.json` = "
             "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (KB per launch; HBM bytes = "
             "2 x FETCH + WRITE per MI355X_MICROARCH.md's gfx950 note); `%s_bench_n1.json` = the bench line of the same build. "

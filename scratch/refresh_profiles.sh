@@ -2,7 +2,7 @@
 # Round profile refresh on the GPU box: kernel stats of the bench command, PMC traffic passes, bench line.
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; RND=${1:-r3}
 cd /tmp; rm -rf $R/gpurun_out/prof_cur
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cur -o $RND -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2 > $R/gpurun_out/prof_cur.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cur -o $RND -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-scenes 0 --no-reference-order --no-native-arith --no-evidence --no-f16x2 --no-two-streams > $R/gpurun_out/prof_cur.log 2>&1
 cd $R
 bash scratch/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1
 mkdir -p gpurun_out/profiles_new
