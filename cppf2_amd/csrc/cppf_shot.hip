@@ -724,9 +724,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   } else {                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 9; ++k)                                            \
       for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {                               \
-        const int j = min(jb + lane, runs.end[k] - 1), base = 0;                             \
+        const int j = min(jb + lane, runs.end[k] - 1);                                       \
         const float4 qv_ = sp[j];                                                            \
-        (void)base;                                                                          \
         const bool act = (jb + lane < runs.end[k]) && (sqdist3(px, py, pz, qv_.x, qv_.y, qv_.z) < r2); \
         __VA_ARGS__                                                                               \
       }                                                                                      \
@@ -736,26 +735,38 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   // zero than 2e-6 (|x| + |y| + |z|) -- eight times the worst float32 error for a unit vector -- and only the lanes it leaves
   // open evaluate the float64 expression (rare: the wavefront skips that arm otherwise).
   const float v1f[3] = {(float)v1[0], (float)v1[1], (float)v1[2]}, v3f[3] = {(float)v3[0], (float)v3[1], (float)v3[2]};
-  if (!(SHOT_DBG & 1)) {
-  FOR_EACH_NEIGHBOUR({
-    bool p1 = false, p3 = false;
-    if (act) {
-      const float4 qv = small ? (base == 0 ? cp0 : cp1) : sp[j];
-      const float qx = qv.x, qy = qv.y, qz = qv.z;
-      if (!(qx == px && qy == py && qz == pz)) {
-        const float xf = qx - px, yf = qy - py, zf = qz - pz;
-        const float d1 = fmaf(zf, v1f[2], fmaf(yf, v1f[1], xf * v1f[0]));
-        const float d3 = fmaf(zf, v3f[2], fmaf(yf, v3f[1], xf * v3f[0]));
-        const float bnd = 2e-6f * ((fabsf(xf) + fabsf(yf)) + fabsf(zf));
-        p1 = d1 > 0.0f;
-        p3 = d3 > 0.0f;
-        if ((SHOT_DBG & 32) || !(fabsf(d1) > bnd) || !(fabsf(d3) > bnd)) {
-          const double x = (double)xf, y = (double)yf, z = (double)zf;
-          p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
-          p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
-        }
+  auto signs_of = [&](const float4 qv, bool act, bool& p1, bool& p3) {
+    p1 = false; p3 = false;
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
+    if (act && !(qx == px && qy == py && qz == pz)) {
+      const float xf = qx - px, yf = qy - py, zf = qz - pz;
+      const float d1 = fmaf(zf, v1f[2], fmaf(yf, v1f[1], xf * v1f[0]));
+      const float d3 = fmaf(zf, v3f[2], fmaf(yf, v3f[1], xf * v3f[0]));
+      const float bnd = 2e-6f * ((fabsf(xf) + fabsf(yf)) + fabsf(zf));
+      p1 = d1 > 0.0f;
+      p3 = d3 > 0.0f;
+      if ((SHOT_DBG & 32) || !(fabsf(d1) > bnd) || !(fabsf(d3) > bnd)) {
+        const double x = (double)xf, y = (double)yf, z = (double)zf;
+        p1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) >= 0.0;
+        p3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) >= 0.0;
       }
     }
+  };
+  if (SHOT_DBG & 1) {
+  } else if (small) {            // the two register-held neighbours, one after the other (no selection between them inside a loop)
+    bool p1, p3;
+    signs_of(cp0, lane < m, p1, p3);
+    plus1 += __popcll(__ballot(p1));
+    plus3 += __popcll(__ballot(p3));
+    if (m > 64) {
+      signs_of(cp1, lane + 64 < m, p1, p3);
+      plus1 += __popcll(__ballot(p1));
+      plus3 += __popcll(__ballot(p3));
+    }
+  } else {
+  FOR_EACH_NEIGHBOUR({
+    bool p1, p3;
+    signs_of(sp[j], act, p1, p3);
     plus1 += __popcll(__ballot(p1));
     plus3 += __popcll(__ballot(p3));
   })
