@@ -10,6 +10,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
+if os.environ.get("CPPF_LIB"):           # a differently built library (probe builds under scratch/); same ABI version required
+    LIB_PATH = os.path.abspath(os.environ["CPPF_LIB"])
 
 ABI_VERSION = 7
 
