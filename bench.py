@@ -567,14 +567,25 @@ def main():
     # the same step with the MLP in f16x2 arithmetic (fp16 operand pairs, three products per K step: half the matrix-core work;
     # error against float64 reported under mlp_error_vs_f64.split_f16x2); same loop protocol; not the headline
     dt_f16 = None
+    f16_agreement = None
     if _models.MLP_ARITH == "split" and not args.no_f16x2:
         _models.MLP_ARITH = "split16"
         step.run()
         dt_f16, _ = timed_loop(args.steps, sample=False)
         rec16 = step.pipe.results.clone()
+        bins16 = step.pipe.bins.clone()
         _models.MLP_ARITH = "split"
         step.run()                  # the records the rest of the report reads are the headline arithmetic's
         torch.cuda.synchronize()
+        # what the f16x2 step produced against the headline arithmetic's, this run's scenes: bins drawn, records byte for byte
+        r16, r3_ = step.pipe.results_to_numpy(rec16), step.pipe.results_to_numpy()
+        f16_agreement = {"bin_draws": int(bins16.numel()), "bins_differing_from_headline": int((bins16 != step.pipe.bins).sum().item()),
+                         "scenes": int(r3_.shape[0]),
+                         "scenes_with_equal_argmax_rotation_bins_kept_count": int(sum(
+                             all(r16[f][i] == r3_[f][i] for f in ("argmax", "up_idx", "right_idx", "kept"))
+                             for i in range(r3_.shape[0]))),
+                         "max_abs_scale_difference": float(np.nanmax(np.abs(r16["scale"] - r3_["scale"]))),
+                         "max_abs_translation_difference_m": float(np.nanmax(np.abs(r16["t"] - r3_["t"])))}
 
     # Not the headline: consecutive steps (independent scene batches) alternating between TWO HIP streams, each with its own
     # buffers, so that one step's descriptor / voting kernels run beside the other's matrix-core kernels.  Same loop protocol; both
@@ -756,6 +767,7 @@ def main():
             # the same run with the MLP in f16x2 arithmetic (operands as fp16 pairs, 22-23 bits; not the headline: products are
             # not exact there -- its error against float64 is under mlp_error_vs_f64.split_f16x2)
             "value_f16x2_mfma": (total_scenes / dt_f16) if dt_f16 else None,
+            "f16x2_agreement": f16_agreement,
             # experimental: the same steps alternating between two HIP streams (not the headline; see the note inside)
             "two_streams": two,
             "records_gathered": int(all_rec.shape[0]),
