@@ -1308,15 +1308,6 @@ __global__ __launch_bounds__(RB_THREADS) void rot_bins_dense_kernel(
 // largest power of two that keeps rows_per_block x (largest 1 / weight of the block's pairs) below 2^62, i.e. a resolution of
 // ~2^-62 of the largest possible sum -- at least as fine as the float64 rounding of the sums it replaces.
 #define RW_THREADS 256
-#ifndef ROT_LDS_FLOOR
-#define ROT_LDS_FLOOR 0        // probe switch: minimum dynamic LDS request (see rot_bins_impl)
-#endif
-#ifndef ROT_LDS_HEAD
-#define ROT_LDS_HEAD 0         // probe switches (scratch/rot_lds_guard.sh): unused bytes in front of / behind the kernel's LDS data
-#endif
-#ifndef ROT_LDS_TAIL
-#define ROT_LDS_TAIL 0
-#endif
 #define RL_K 8             // table slots per cell (int16 bin ids, -1 = empty)
 struct RwFrame {
   float xx, xy, xz, yx, yy, yz, ux, uy, uz;   // in-plane axes, pair direction
@@ -1325,16 +1316,6 @@ struct RwFrame {
   double inv_wt;                              // 1 / pair weight; phase 1b overwrites it with its fixed-point image (uint64 bits)
 };
 
-#ifdef ROT_TRACE
-// probe builds (scratch/rot_trace.*): every candidate's intermediate values, indexed by (scene, candidate row, axis)
-__device__ float* g_rot_trace = nullptr;
-__device__ long long g_rot_trace_stride = 0;
-extern "C" int cppf_debug_set_rot_trace(float* ptr, long long rows_per_scene) {
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_rot_trace), &ptr, sizeof(ptr)) != hipSuccess) return CPPF_EINVAL;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_rot_trace_stride), &rows_per_scene, sizeof(rows_per_scene)) != hipSuccess) return CPPF_EINVAL;
-  return CPPF_OK;
-}
-#endif
 template <int NAX>
 __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ pt_off, const int32_t* __restrict__ idx, int k,
@@ -1344,8 +1325,7 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
     int max_pairs, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
     const float* __restrict__ sphere, int S, float cos_thr, const int4* __restrict__ lut, int lut_rows, int lut_cols,
     int bmm_size, double* __restrict__ partial /* [B][gridDim.x][NAX][S] */) {
-  extern __shared__ __attribute__((aligned(16))) char smem_[];
-  char* smem = smem_ + ROT_LDS_HEAD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* s_sph = (float4*)smem;                                     // [S] (x, y, z, -)
   unsigned long long* s_acc = (unsigned long long*)(smem + (size_t)S * 16);   // [NAX][S] fixed-point sums
   float2* s_trig = (float2*)(s_acc + (size_t)NAX * S);               // [num_rots] (cos, sin)
@@ -1428,9 +1408,6 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
   const int ncand = npairs * num_rots;
   const int dq = RW_THREADS / num_rots, dr = RW_THREADS - dq * num_rots;
   int pj = (int)threadIdx.x / num_rots, r = (int)threadIdx.x - pj * num_rots;
-#ifdef ROT_TRACE
-  unsigned ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0;
-#endif
   for (int c = threadIdx.x; c < ncand; c += RW_THREADS) {
     const RwFrame fr = s_fr[pj];
     const int row = fr.row0 + r;
@@ -1457,10 +1434,6 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
       cj = min(max(cj, 0), lut_cols - 1);
       const int4 e = lut[ci * lut_cols + cj];
       const int ids[4] = {e.x, e.y, e.z, e.w};
-#ifdef ROT_TRACE
-      int nvote = 0;
-      float dsum = 0.0f;
-#endif
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -1470,43 +1443,13 @@ __global__ __launch_bounds__(RW_THREADS) void rot_bins_lut_kernel(
             const float4 q = s_sph[s];
             const float d = fmaf(z, q.z, fmaf(y, q.y, x * q.x));
             if (d > cos_thr) atomicAdd(&s_acc[a * S + s], (unsigned long long)__double_as_longlong(fr.inv_wt));
-#ifdef ROT_TRACE
-            nvote += (d > cos_thr) ? 1 : 0;
-            dsum += d;
-#endif
           }
         }
       }
-#if defined(ROT_TRACE) && ROT_TRACE == 3
-      if (a == 0) { ck0 += 1u; ck1 += (unsigned)row; ck2 += (unsigned)__float_as_int(fr.tn[0]) + 3u * (unsigned)__float_as_int(fr.xx) + 5u * (unsigned)__float_as_int(fr.ux) + 7u * (unsigned)__float_as_int(fr.yz) + 11u * (unsigned)__float_as_int(fr.tn[1]); }
-      ck3 += (unsigned)__float_as_int(ux) + 3u * (unsigned)__float_as_int(uy) + 7u * (unsigned)__float_as_int(uz);
-#elif defined(ROT_TRACE) && ROT_TRACE == 4
-      ck0 += (unsigned)__float_as_int(x) + 3u * (unsigned)__float_as_int(y) + 7u * (unsigned)__float_as_int(z);
-      ck1 += (unsigned)(row * 131 + a) + 13u * (unsigned)__float_as_int(tn);
-      ck2 += (unsigned)__float_as_int(ux) + 5u * (unsigned)__float_as_int(uy) + 11u * (unsigned)__float_as_int(uz) + 17u * (unsigned)__float_as_int(nn);
-      ck3 += (unsigned)nvote + 1000u * (unsigned)__float_as_int(dsum);
-#elif defined(ROT_TRACE) && ROT_TRACE == 2
-      ck0 += (unsigned)__float_as_int(x) + 3u * (unsigned)__float_as_int(y) + 7u * (unsigned)__float_as_int(z);
-      ck1 += (unsigned)(ci * 131 + cj) + 13u * (unsigned)__float_as_int(phi);
-      ck2 += (unsigned)e.x + 5u * (unsigned)e.y + 11u * (unsigned)e.z + 17u * (unsigned)e.w;
-      ck3 += (unsigned)nvote + 1000u * (unsigned)__float_as_int(dsum);
-#elif defined(ROT_TRACE)
-      if (g_rot_trace && row < g_rot_trace_stride) {
-        float* t = g_rot_trace + (((long long)b * g_rot_trace_stride + row) * NAX + a) * 16;
-        t[0] = x; t[1] = y; t[2] = z; t[3] = phi; t[4] = (float)ci; t[5] = (float)cj; t[6] = __int_as_float(e.x); t[7] = __int_as_float(e.y);
-        t[8] = (float)nvote; t[9] = dsum; t[10] = ux; t[11] = uy; t[12] = uz; t[13] = nn; t[14] = tn; t[15] = (float)fr.inv_wt;
-      }
-#endif
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NAX * S; i += RW_THREADS) out[i] = ldexp((double)s_acc[i], -fx_e);
-#if defined(ROT_TRACE) && ROT_TRACE >= 2
-  if (g_rot_trace) {     // NOTE: thread -> candidate mapping follows the arrival order of the pair list: sums per workgroup only
-    unsigned* t = reinterpret_cast<unsigned*>(g_rot_trace) + ((long long)b * gridDim.x + blockIdx.x) * 4;
-    atomicAdd(&t[0], ck0); atomicAdd(&t[1], ck1); atomicAdd(&t[2], ck2); atomicAdd(&t[3], ck3);
-  }
-#endif
 }
 
 // float32 counts of one (scene, axis): per chunk, the float64 sum of its sub-block partials in sub-block order, one
@@ -1673,7 +1616,7 @@ static int rot_bins_impl(int nax, int B, const float* pts, const int32_t* pt_off
   // one it produced different votes.  The cause was the gfx950 packed-float32 erratum described in cppf2_amd/build.py -- the
   // SLP vectoriser had emitted `v_pk_mul_f32 ... op_sel:[0,1]` in the candidate arithmetic -- and is removed at the source: the
   // library is built without such instructions and tests/test_abi.py checks the disassembly.)
-  const size_t lut_lds = (lut_need + ROT_LDS_HEAD + ROT_LDS_TAIL) < ROT_LDS_FLOOR ? ROT_LDS_FLOOR : (lut_need + ROT_LDS_HEAD + ROT_LDS_TAIL);
+  const size_t lut_lds = lut_need;
   if (bin_lut && lut_need <= 64000 && max_kept > 0) {
     double* partial = (double*)workspace;
     if (nax == 2)

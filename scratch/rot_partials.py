@@ -2,7 +2,7 @@
 import sys, os, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cppf2_amd import _lib
-_lib.LIB_PATH = os.path.abspath(os.environ.get("CPPF_PROBE_LIB", "scratch/rotdbg/lib_none.so"))
+_lib.LIB_PATH = os.path.abspath(os.environ.get("CPPF_PROBE_LIB", "cppf2_amd/libcppf_hip.so"))
 import numpy as np, torch
 import bench
 from cppf2_amd import models, ops
