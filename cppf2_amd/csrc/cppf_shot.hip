@@ -777,6 +777,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     // tie (one query in six: an even count splits evenly about as often as a fair coin does) with the neighbours in registers:
     // a neighbour's rank in the (distance, original index) order is the number of smaller 64-bit keys (distance bits : index);
     // the keys go through the unused upper part of the list buffer and every lane scans them for its two neighbours
+    static_assert(SH_LCAP >= 512, "the tie-break keys live in list entries 256..511");
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_list + 256);
     auto key_of = [&](const float4 q, bool in) {
       const bool self = (q.x == px && q.y == py && q.z == pz);
