@@ -618,6 +618,8 @@ def main():
                        "small kernels of one step run beside the other step's MLP kernels); records compared byte for byte with the "
                        "single-stream ones in this run; not the headline: `value` is the one-stream figure whose kernels rocprof times "
                        "one at a time (DESIGN.md section 11)"}
+        if not same and rank == 0:
+            print("bench.py: WARNING: the two-stream loop's records differ from the single-stream ones (see two_streams in the line)", file=sys.stderr)
         del step_b
 
     if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
