@@ -770,7 +770,7 @@ def main():
             # not exact there -- its error against float64 is under mlp_error_vs_f64.split_f16x2)
             "value_f16x2_mfma": (total_scenes / dt_f16) if dt_f16 else None,
             "f16x2_agreement": f16_agreement,
-            # experimental: the same steps alternating between two HIP streams (not the headline; see the note inside)
+            # the same steps alternating between two HIP streams (not the headline; see the note inside)
             "two_streams": two,
             "records_gathered": int(all_rec.shape[0]),
             # the path's one collective: all_gather of the 160-byte scene records, HIP-event time of the stage
