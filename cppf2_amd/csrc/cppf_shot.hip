@@ -430,11 +430,9 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
   double a[NSUM];
 #pragma unroll
   for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
-  // The 9 runs are walked as ONE flat candidate range (no partly filled wavefront per run), the next 64 candidates are
-  // requested before the current 64 are tested.  Only about a fifth of the candidates lie inside the larger radius: the sweep
-  // just tests them in float32 and compacts the hits (ballot + prefix popcount) into LDS -- and into the workspace for
-  // shot_hist, which needs the same neighbours -- and the float64 covariance sums then run over the dense list (two wavefront
-  // passes for the usual ~90 neighbours instead of seven over the candidates: the kernel is bound by its float64 VALU work).
+  // The candidates of the 9 runs are tested in float32 and the hits (about a fifth of them) compacted (ballot + prefix popcount)
+  // into LDS -- and into the workspace for shot_hist, which needs the same neighbours -- so that the float64 covariance sums run
+  // over a dense list (two wavefront passes for the usual ~90 neighbours instead of seven to nine over the candidates).
   int base[10];
   base[0] = 0;
 #pragma unroll
@@ -448,25 +446,29 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
   };
   int m = 0;
   {
-    int jn = (lane < C) ? cand(lane) : 0;
-    float4 qn = sp[jn];
-    for (int fb = 0; fb < C; fb += 64) {
-      const float4 qv = qn;
-      const int j = jn;
-      const bool valid = fb + lane < C;
-      const int fnext = fb + 64 + lane;
-      if (fb + 64 < C) {
-        jn = (fnext < C) ? cand(fnext) : 0;
-        qn = sp[jn];
+    // run by run (the same scan order as the flat range): the first 64 candidates of every run are requested up front -- nine
+    // independent gathers in flight and no per-lane search for the run a flat index falls into; a run rarely has more than 64
+    float4 q0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int j = runs.beg[k] + lane;
+      q0[k] = sp[j < runs.end[k] ? j : runs.beg[0]];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
+        const int j = jb + lane;
+        const bool valid = j < runs.end[k];
+        const float4 qv = (jb == runs.beg[k]) ? q0[k] : sp[valid ? j : jb];
+        const bool in = valid && sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
+        const unsigned long long mask = __ballot(in);
+        if (in) {
+          const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+          if (pos < COV_LIST) s_nb[pos] = qv;
+          if (!(SHOT_DBG & 256) && pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
+        }
+        m += __popcll(mask);
       }
-      const bool in = valid && sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
-      const unsigned long long mask = __ballot(in);
-      if (in) {
-        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < COV_LIST) s_nb[pos] = qv;
-        if (!(SHOT_DBG & 256) && pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
-      }
-      m += __popcll(mask);
     }
   }
   __syncthreads();
