@@ -48,14 +48,21 @@ def _use_tuned_gemms():
     src = os.path.join(ROOT, "cppf2_amd", "tunableop", "gfx950_bench_shapes.csv")
     if not os.path.exists(src):
         return
+    import atexit
     import shutil
     import tempfile
-    d = tempfile.mkdtemp(prefix="cppf_tunableop_")
+    # one directory per rank process (self_launch strips these variables from its children, so every rank gets here)
+    d = tempfile.mkdtemp(prefix="cppf_tunableop_r%s_" % os.environ.get("RANK", "0"))
+    atexit.register(shutil.rmtree, d, True)
     dev = int(os.environ.get("LOCAL_RANK", "0"))
     shutil.copy(src, os.path.join(d, "gemm%d.csv" % dev))          # PyTorch appends the device ordinal to the name
-    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
-    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
-    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(d, "gemm.csv")
+    for k_, v_ in (("PYTORCH_TUNABLEOP_ENABLED", "1"), ("PYTORCH_TUNABLEOP_TUNING", "0"),
+                   ("PYTORCH_TUNABLEOP_FILENAME", os.path.join(d, "gemm.csv"))):
+        os.environ[k_] = v_
+        _SET_HERE.append(k_)
+
+
+_SET_HERE = []          # environment variables this process set itself (not inherited by the ranks self_launch starts)
 
 
 _use_tuned_gemms()
@@ -147,6 +154,7 @@ class Step:
         self.shot = torch.empty((B * N, 352), dtype=torch.float32, device=dev)
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         self.all_records = None
+        self.records_buf = torch.empty((B * world, 160), dtype=torch.uint8, device=dev)      # the gather's result, allocated once
         self.scales_buf = torch.zeros((B * T, 3), dtype=torch.float32, device=dev)
         self.eager = bool(args.eager_scale_head)
         self.materialize = bool(getattr(args, "materialize_tuples", False))
@@ -246,7 +254,7 @@ class Step:
         pipe.assemble(scales)
         self._mark("assemble_pose")
         # the one collective of the path: 160-byte records of every rank's scenes, global scene order
-        self.all_records = self.dist.gather_results(pipe.results, B * self.world)
+        self.all_records = self.dist.gather_results(pipe.results, B * self.world, out=self.records_buf)
         self._mark("gather")
         return self.ev
 
@@ -447,6 +455,8 @@ def self_launch(args):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        for k_ in _SET_HERE:                     # every rank sets up its own TunableOp table (its own device ordinal and directory)
+            env.pop(k_, None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd()))
     rc = 0
@@ -633,6 +643,7 @@ def main():
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
 
+    failed = False
     if rank == 0:
         B, N, T, R, S = step.B, step.N, step.T, args.rots, step.pipe.S
         res = step.pipe.results_to_numpy()
@@ -782,13 +793,26 @@ def main():
             "pose_5deg5cm_vs_gt": ok / B, "oracle_agreement": agree,
         }
         line.update(evidence)
+        # self-checks of the run: a comparison loop whose records differ from the headline's is a failed run, not a footnote
+        problems = []
+        if two is not None and not two["records_identical_to_single_stream"]:
+            problems.append("two_streams: records differ from the single-stream ones")
+        if f16_agreement is not None and f16_agreement["scenes_with_equal_argmax_rotation_bins_kept_count"] != f16_agreement["scenes"]:
+            problems.append("f16x2_agreement: a scene's arg-max / rotation bins / kept count differs from the headline arithmetic's")
+        line["ok"] = not problems
+        line["problems"] = problems
         if args.breakdown:
             print("%-22s %10s %12s %10s" % ("stage", "ms/launch", "alg MB", "GB/s"), file=sys.stderr)
             for r in rows:
                 print("%-22s %10.3f %12.1f %10.1f" % r, file=sys.stderr)
         print(json.dumps(line))
+        if problems:
+            print("bench.py: FAILED self-checks: " + "; ".join(problems), file=sys.stderr)
+            failed = True
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

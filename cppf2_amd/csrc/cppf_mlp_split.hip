@@ -467,9 +467,9 @@ __device__ __forceinline__ void rs_load_tile_scaled(f32x16& acc, const float* v,
 // softmax_exp, a float32 running sum IN BIN ORDER -- so the running total alternates between the two lanes every four bins --
 // target = uniform * total, bin = #{cdf <= target} capped at 31.  The six coordinates' chains are independent and interleave.
 struct RsDecode {
-  const float* prior;           // [rows, 192] additive logit prior or NULL
-  const float* uniforms;        // [rows, 6]
-  int32_t* bins;                // [rows, 6] out
+  const float* prior = nullptr;     // [rows, 192] additive logit prior or NULL
+  const float* uniforms = nullptr;  // [rows, 6]
+  int32_t* bins = nullptr;          // [rows, 6] out
 };
 
 template <int NT, int PC>
@@ -541,14 +541,14 @@ __device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDeco
 }
 
 struct RsTap {                  // optional second output: the activation after the FIRST layer of a chained launch
-  float* out;                   // [rows, >= n_out] or NULL
-  int64_t ld;
+  float* out = nullptr;         // [rows, >= n_out] or NULL
+  int64_t ld = 0;
 };
 
 struct RsGather {               // GATHER launches: see RsX
-  const int32_t* gidx;          // [rows, slots] global point indices
-  const float* table;           // [points, 1 << fshift]
-  int slots, head, fshift;
+  const int32_t* gidx = nullptr;   // [rows, slots] global point indices
+  const float* table = nullptr;    // [points, 1 << fshift]
+  int slots = 0, head = 0, fshift = 0;
 };
 
 // f16x2 (PC == 2, CPPF_MLP_ARITH=split16): every float32 operand as an fp16 pair hi + lo (22-23 significant bits), three

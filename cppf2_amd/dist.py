@@ -55,12 +55,13 @@ _GATHER_BUFS = {}
 
 
 def _gather_bufs(world, cap, device):
-    """(send [cap, 160], recv [world, cap, 160]) allocated once per (world, cap, device): the step's only collective does
-    not touch the allocator."""
-    key = (world, cap, str(device))
+    """(send [cap, 160], recv [world, cap, 160]) allocated once per (world, cap, device, current stream): the step's only
+    collective does not touch the allocator, and two streams gathering concurrently never share a staging buffer."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (world, cap, str(device), stream)
     b = _GATHER_BUFS.get(key)
     if b is None:
-        if len(_GATHER_BUFS) >= 8:
+        if len(_GATHER_BUFS) >= 16:
             _GATHER_BUFS.clear()
         b = (torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=device),
              torch.empty((world, cap, RECORD_BYTES), dtype=torch.uint8, device=device))
@@ -70,8 +71,9 @@ def _gather_bufs(world, cap, device):
 
 def gather_results(local_records, num_scenes, out=None):
     """local_records: uint8 [n_local, 160] (device or CPU).  Returns uint8 [num_scenes, 160] in global scene order
-    on every rank (`out`, if given, receives it).  Shards are padded to the largest one so the all_gather is a single
-    fixed-size collective; equal shards (the bench's weak scaling) are returned as a view of the receive buffer."""
+    on every rank: `out` if given (a caller that gathers every step passes a buffer it allocated once: no allocator
+    traffic), else a tensor of its own -- never a view of the internal staging buffers, so the results of two gathers do not
+    alias.  Shards are padded to the largest one so the all_gather is a single fixed-size collective."""
     assert local_records.dtype == torch.uint8 and local_records.shape[-1] == RECORD_BYTES
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective()):
         return local_records[:num_scenes]
@@ -92,7 +94,7 @@ def gather_results(local_records, num_scenes, out=None):
         if out is not None:
             out.copy_(res)
             return out
-        return res.to(dev) if stage else res
+        return res.to(dev) if stage else res.clone()
     if out is None:
         out = torch.empty((num_scenes, RECORD_BYTES), dtype=torch.uint8, device=src.device)
     for r in range(world):

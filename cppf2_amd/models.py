@@ -151,21 +151,34 @@ def _entry_cache(entry):
     return entry[5]
 
 
-def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0):
+def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0, stamp=None):
     """(weight stream, first biases of the launch's layers, skip bias, weight scale) of one launch in the current arithmetic,
-    cached per launch shape: bf16 triples (scale 1) or fp16 pairs of scale x the weights with the biases scaled alike."""
+    cached per launch shape: bf16 triples (scale 1) or fp16 pairs of scale x the weights with the biases scaled alike.
+    stamp: weight versions of a SECOND stack the launch runs into (cross-stack launches); it is stored inside the slot and the
+    slot is rebuilt when it changes, so that re-trained weights of the second stack replace their stream instead of adding one."""
     key = key + (MLP_ARITH,)
-    if key not in cache:
+    hit = cache.get(key)
+    if hit is None or hit[0] != stamp:
         chain = [(e[0].t(), e[4].t()) for e in rest]
         biases = torch.cat([b1] + [e[1] for e in rest])
         if MLP_ARITH == "split16":
             sc = f16_scale(w1t, w0t, w2t, *[w for pair in chain for w in pair])
             wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), k_in, chain=chain, arith="f16x2", scale=sc)
-            cache[key] = (wq, (biases * sc).contiguous(), None if b0 is None else (b0 * sc).contiguous(), sc)
+            hit = (stamp, (wq, (biases * sc).contiguous(), None if b0 is None else (b0 * sc).contiguous(), sc))
         else:
             wq = pack_split(w1t.t(), None if w0t is None else w0t.t(), w2t.t(), k_in, chain=chain)
-            cache[key] = (wq, biases.contiguous(), b0, 1.0)
-    return cache[key]
+            hit = (stamp, (wq, biases.contiguous(), b0, 1.0))
+        cache[key] = hit
+    return hit[1]
+
+
+def _chain_len(cache, key, stamp, compute):
+    """Chain length of a launch shape, cached like _packed (one slot per shape, the second stack's stamp inside it)."""
+    hit = cache.get(key)
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, compute())
+        cache[key] = hit
+    return hit[1]
 
 
 def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
@@ -206,7 +219,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         plan_b, c = _fused_plan(seq_b)
         plan = plan_a + plan_b
         tap_at = len(plan_a) - 1
-        cross = seq_b._fused_plan_cache[0]          # weight versions of the second stack: part of every cross-stack cache key
+        cross = seq_b._fused_plan_cache[0]          # weight versions of the second stack: stored inside every cross-stack cache slot
         seq = seq_b
     else:
         plan, c = _fused_plan(seq)
@@ -225,17 +238,16 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
         assert _kernel_arith() and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
         cache = _entry_cache(entry)
-        chain = cache.get(("gather-chain", k_in, tap_at, cross))
-        if chain is None:
-            chain = 0
-            while (1 + chain < len(plan) and plan[1 + chain][2] is None and chain < 15 and plan[1 + chain][0].shape == (128, 128)):
-                chain += 1
-            chain = cut(0, chain)
-            if tap_at == 0:
-                chain = 0                       # (the gathering launch has no second output)
-            cache[("gather-chain", k_in, tap_at, cross)] = chain
-        key = (k_in, chain, cross if tap_at is not None and chain > tap_at else None)
-        wq, bb1, bb0, sc = _packed(cache, key, w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0)
+        def gather_chain():
+            n = 0
+            while (1 + n < len(plan) and plan[1 + n][2] is None and n < 15 and plan[1 + n][0].shape == (128, 128)):
+                n += 1
+            n = cut(0, n)
+            return 0 if tap_at == 0 else n      # (the gathering launch has no second output)
+        chain = _chain_len(cache, ("gather-chain", k_in, tap_at), cross, gather_chain)
+        crossing = tap_at is not None and chain > tap_at
+        wq, bb1, bb0, sc = _packed(cache, (k_in, chain, crossing), w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0,
+                                   stamp=cross if crossing else None)
         if MLP_ARITH == "split16":
             x = ops.reslayer_split16(heads, wq, bb1, bb0, 128, sc, chain=chain, gather=(gidx, table))
         else:
@@ -262,19 +274,19 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
             # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
             cache = _entry_cache(entry)
-            ck = ("chain", x.shape[1], tap_at if tap_at is not None and tap_at >= li else None, cross if tap_at is not None and tap_at >= li else None)
-            chain = cache.get(ck)
-            if chain is None:                             # (one library call per candidate layer: looked up once per shape)
-                chain = 0
-                while (li + 1 + chain < len(plan) and plan[li + 1 + chain][2] is None and chain < 15
-                       and plan[li + 1 + chain][0].shape == (n_out, n_out)
-                       and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, chain + 1)):
-                    chain += 1
-                chain = cut(li, chain)
-                cache[ck] = chain
+            ahead = tap_at is not None and tap_at >= li
+
+            def plain_chain(li=li, n_out=n_out, w0t=w0t):  # (one library call per candidate layer: looked up once per shape)
+                n = 0
+                while (li + 1 + n < len(plan) and plan[li + 1 + n][2] is None and n < 15
+                       and plan[li + 1 + n][0].shape == (n_out, n_out)
+                       and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None, n + 1)):
+                    n += 1
+                return cut(li, n)
+            chain = _chain_len(cache, ("chain", x.shape[1], tap_at if ahead else None), cross if ahead else None, plain_chain)
             crossing = tap_at is not None and li <= tap_at < li + chain           # the launch runs from one stack into the other
-            key = (x.shape[1], chain, cross if crossing else None)
-            wq, bb1, bb0, sc = _packed(cache, key, w1t, w0t, w2t, x.shape[1], plan[li + 1:li + 1 + chain], b1, b0)
+            wq, bb1, bb0, sc = _packed(cache, (x.shape[1], chain, crossing), w1t, w0t, w2t, x.shape[1],
+                                       plan[li + 1:li + 1 + chain], b1, b0, stamp=cross if crossing else None)
             out = None
             if w0t is None and li == 0 and keep_input:
                 out = torch.empty_like(x)

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."; mkdir -p scratch/rotdbg /tmp/isa
 NAME=$1; EDIT=$2
-F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -fPIC -I include -I cppf2_amd/csrc"
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -fPIC -I include -I cppf2_amd/csrc -fno-slp-vectorize"
 LL=/opt/rocm/lib/llvm/bin
 [ -f /tmp/isa/vote_base.s ] || /opt/rocm/bin/hipcc $F --cuda-device-only -S cppf2_amd/csrc/cppf_vote.hip -o /tmp/isa/vote_base.s 2>/dev/null
 python3 - "$NAME" "$EDIT" <<'PY'
