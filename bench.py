@@ -115,6 +115,10 @@ def parse():
                     help="skip the extra loop that times the steps alternating between two HIP streams (two_streams in the line)")
     ap.add_argument("--no-evidence", action="store_true",
                     help="skip the untimed accuracy evidence (mlp_error_vs_f64, bin_flip_rate_vs_expf)")
+    ap.add_argument("--workload", choices=("shot", "ensemble"), default="shot",
+                    help="shot (default, the headline): BASELINE configs[1], the SHOT model; ensemble: BASELINE configs[2], the "
+                         "reference's real per-instance loop (eval.py:219-372) -- the DINO model AND the SHOT model vote every "
+                         "instance, the pose with the smaller alignment loss is kept; value = instances/s")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -257,6 +261,218 @@ class Step:
         self.all_records = self.dist.gather_results(pipe.results, B * self.world, out=self.records_buf)
         self._mark("gather")
         return self.ev
+
+
+class EnsembleStep(Step):
+    """BASELINE configs[2]: one pass of eval.py:207-372 over the batch -- shared tuple table and SHOT descriptors, then the DINO
+    model's pass and the SHOT model's pass (tuple MLP -> bin draw -> centre vote -> back-vote filter -> rotation votes -> scale
+    head on the kept pairs -> pose -> alignment loss each), then the selection; every launch is a kernel of libcppf_hip.so.
+    The DINOv2 descriptors are inputs of the path (seeded unit vectors [N, 1024], resident like the points)."""
+
+    PASS = ["encode", "tuple_mlp", "decode_bins", "vote_frames", "vote_center", "backvote_filter", "rot_bins", "scale_head",
+            "assemble_pose", "alignment_loss"]
+    STAGES = (["sample_tuples", "shot_frames", "shot352", "shot_encoder", "dino_point_transforms"]
+              + ["dino_" + n for n in PASS] + ["shot_" + n for n in PASS] + ["select", "gather"])
+
+    def __init__(self, args, rank, world, dev):
+        super().__init__(args, rank, world, dev)
+        from cppf2_amd.models import BeyondCPPFDino
+        torch.manual_seed(args.seed + 1)
+        self.dino = BeyondCPPFDino(Cfg()).to(dev).eval()
+        g = torch.Generator(device="cpu").manual_seed(args.seed + 17 + rank)
+        self.desc = torch.nn.functional.normalize(torch.randn((self.B * self.N, 1024), generator=g), dim=-1).to(dev)
+        self.scales_buf2 = torch.zeros((self.B * self.T, 3), dtype=torch.float32, device=dev)
+
+    def _vote_pass(self, pre, model, tf, idx, scales_buf):
+        pipe = self.pipe
+        pipe.decode_from_bins(self.pts, idx)
+        self._mark(pre + "decode_bins")
+        pipe.vote_center(self.pts, idx, phase=1)
+        self._mark(pre + "vote_frames")
+        pipe.vote_center(self.pts, idx, phase=2)
+        self._mark(pre + "vote_center")
+        pipe.backvote(self.pts, idx)
+        self._mark(pre + "backvote_filter")
+        pipe.rot_bins(self.pts, idx)
+        self._mark(pre + "rot_bins")
+        scales = model.scale_head_rows(tf, pipe.kept_rows32(), scatter=(pipe.kept_count, pipe.max_kept, scales_buf))
+        self._mark(pre + "scale_head")
+        pipe.assemble(scales)
+        self._mark(pre + "assemble_pose")
+        pipe.alignment_loss(self.pts, idx, True)          # bottle: up-symmetric, y only (eval.py:360-361)
+        self._mark(pre + "alignment_loss")
+
+    @torch.no_grad()
+    def run(self, timed=None):
+        from cppf2_amd import shot as shotmod
+        from cppf2_amd.models import fused_stack
+        ops, pipe, a = self.ops, self.pipe, self.args
+        B, N, T = self.B, self.N, self.T
+        ids = tuple(range(self.scene0, self.scene0 + B))
+        self.ev = [] if timed is not None else None
+        self.ev_slot = timed
+        self._mark("start")
+        idx = ops.sample_tuples(N, T, 5, a.seed, ids, self.dev)                          # eval.py:207: one table for both models
+        self._mark("sample_tuples")
+        shotmod.prepare_device(self.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, self.normal)   # eval.py:210
+        self._mark("shot_frames")
+        shot = shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot, nan_to_zero=True)
+        self._mark("shot352")
+        normal = ops.nan_to_zero_(self.normal)
+        feat = self.model.encode_points(shot)
+        self._mark("shot_encoder")
+        # ---- model 0: DINO (train_dino.py:91-97, 128-133; eval.py:221) -------------------------------------------
+        pipe.use_slot(0)
+        fold = self.dino.first_layer_fold(5)
+        tables = fold.tables(self.dino.transform_points(self.desc))      # desc_transform, then the folded slot products: per POINT
+        self._mark("dino_point_transforms")
+        u = ops.philox_uniform(T, 6, a.seed, 1, ids, self.dev)
+        heads, gidx = ops.encode_tuples_coord_heads(self.pts, idx, pipe.pt_off, pipe.tup_off)
+        self._mark("dino_encode")
+        _, tf = fused_stack((self.dino.tuple_encoder, self.dino.logit_encoder), None, gather=(heads, gidx, tables, fold),
+                            decode=(u, self.prior, pipe.bins))
+        self._mark("dino_tuple_mlp")
+        self._vote_pass("dino_", self.dino, tf, idx, self.scales_buf)
+        # ---- model 1: SHOT (train_shot.py:75-83, 117-122; eval.py:223) -------------------------------------------
+        pipe.use_slot(1)
+        u = ops.philox_uniform(T, 6, a.seed, 2, ids, self.dev)
+        heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+        self._mark("shot_encode")
+        _, tf = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), None, gather=(heads, gidx, feat),
+                            decode=(u, self.prior, pipe.bins))
+        self._mark("shot_tuple_mlp")
+        self._vote_pass("shot_", self.model, tf, idx, self.scales_buf2)
+        pipe.select(True, True)                                                           # eval.py:365-372
+        self._mark("select")
+        self.all_records = self.dist.gather_results(pipe.selected, B * self.world, out=self.records_buf)
+        self._mark("gather")
+        return self.ev
+
+
+def tuple_mlp_flops(model, B, T, N, nprod):
+    """(executed MFMA flops, algorithmic float32 flops) of one pass' tuple MLP launches (the three reslayer_split launches; for
+    the DINO model also the two per-point Linear launches), K padded to 16 in the executed figure."""
+    def layer(k, n, proj):
+        return 2.0 * n * ((k + 15) // 16 * 16) * (2 if proj else 1) + 2.0 * n * n, 2.0 * n * k * (2 if proj else 1) + 2.0 * n * n
+    tail = [(128, 128, False)] * 4 + [(128, 256, True), (256, 256, False), (256, 256, False), (256, 192, True)]
+    if model == "shot":
+        layers = [(360, 128, True)] + tail
+        ex = sum(layer(*l)[0] for l in layers) * B * T
+        al = sum(layer(*l)[1] for l in layers) * B * T
+        return nprod * ex, al
+    # DINO: the first layer's products run over the 30 (32) coordinate columns per tuple; its descriptor columns (and
+    # desc_pair_transform) are the per-point slot tables, desc_transform the per-point Linear in front of them
+    layers = [(30, 128, True)] + tail
+    ex = sum(layer(*l)[0] for l in layers) * B * T + (2.0 * 1024 * 256 + 2.0 * 256 * 1280) * B * N
+    # algorithmic = the reference's network as written: 286-column rows, desc_transform on k gathered descriptors per tuple,
+    # desc_pair_transform over their concatenation (train_dino.py:95-96)
+    al = (sum(layer(*l)[1] for l in [(286, 128, True)] + tail) + 5 * 2.0 * 1024 * 256 + 2.0 * 1280 * 256) * B * T
+    return nprod * ex, al
+
+
+def report_ensemble(args, step, dt, evs, world, backend):
+    """The JSON line of --workload ensemble (rank 0): the contract fields + roofline + cpu_baseline, per model."""
+    from cppf2_amd import models as _models
+    B, N, T, R = step.B, step.N, step.T, args.rots
+    stage_ms = {}
+    for ev in evs:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
+    step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
+    shared = ["sample_tuples", "shot_frames", "shot352"]
+    dino_ms = stage_ms.get("dino_point_transforms", 0.0) + sum(stage_ms.get("dino_" + n, 0.0) for n in EnsembleStep.PASS)
+    shot_ms = stage_ms.get("shot_encoder", 0.0) + sum(stage_ms.get("shot_" + n, 0.0) for n in EnsembleStep.PASS)
+    shared_ms = sum(stage_ms.get(n, 0.0) for n in shared)
+    nprod = 6.0 if _models.MLP_ARITH == "split" else 3.0
+    ex_d, al_d = tuple_mlp_flops("dino", B, T, N, nprod)
+    ex_s, al_s = tuple_mlp_flops("shot", B, T, N, nprod)
+    mlp_ms = stage_ms["dino_point_transforms"] + stage_ms["dino_tuple_mlp"] + stage_ms["shot_tuple_mlp"]
+    rec = step.pipe.results_to_numpy(step.pipe.selected)
+    all_rec = step.pipe.results_to_numpy(step.all_records)
+    assert all_rec.shape[0] == B * world and np.array_equal(all_rec[:B].tobytes(), rec.tobytes())
+    both = [step.pipe.results_to_numpy(step.pipe.result_slots[m]) for m in (0, 1)]
+    ok = 0
+    for b in range(B):
+        sc = step.scenes[b]
+        terr = np.linalg.norm(rec["t"][b] - sc["t"])
+        cosang = abs(float(rec["R"][b][:, 1] @ sc["R"][:, 1]))
+        ok += int(terr < 0.05 and np.degrees(np.arccos(min(cosang, 1.0))) < 5.0)
+    pick = rec["pad_"][:, 0]
+    cpu = None
+    agree = None
+    if args.cpu_scenes > 0 and world == 1:
+        from oracle import pipeline_oracle as PO         # the checker, timed as the CPU baseline (never the product path)
+        from oracle import cppf_oracle as O
+        from oracle import shot_oracle as S
+        from cppf2_amd import synth
+        wd = {k_: v_.detach().cpu().numpy() for k_, v_ in step.dino.state_dict().items()}
+        wsh = {k_: v_.detach().cpu().numpy() for k_, v_ in step.model.state_dict().items()}
+        trig = (step.pipe.cs.cpu().numpy(), step.pipe.sn.cpu().numpy())
+        n_cpu = min(args.cpu_scenes, 2)
+        t0 = time.perf_counter()
+        outs = []
+        for b in range(n_cpu):
+            sc = step.scenes[b]
+            idx = O.sample_tuples(args.seed, step.scene0 + b, T, 5, N).astype(np.int64)
+            shot_feat, normal, _ = S.compute(sc["pc"], Cfg.res * 10, Cfg.res * 10)
+            shot_feat, normal = np.nan_to_num(shot_feat, nan=0.0), np.nan_to_num(normal, nan=0.0)
+            prior = synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6)
+            desc = step.desc[b * N:(b + 1) * N].cpu().numpy()
+            per_model = []
+            for m, (lg, scl) in enumerate((PO.mlp_dino(wd, sc["pc"], desc, idx), PO.mlp_shot(wsh, sc["pc"], idx, shot_feat, normal))):
+                per_model.append(((lg + prior).astype(np.float32), scl, O.philox_uniform(args.seed, step.scene0 + b, 1 + m, T, 6)))
+            outs.append(PO.run_instance_ensemble(sc["pc"], idx, per_model, Cfg.up, Cfg.right, Cfg.front, Cfg.res, num_rots=R,
+                                                 y_only=True, trig=trig))
+        dtc = time.perf_counter() - t0
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            cores = os.cpu_count()
+        cpu = dict(value=n_cpu / dtc, unit="scenes/s", cores=cores, kind="port",
+                   sample="%d instance(s) of the same workload, both models (NumPy oracle: mlp_dino + mlp_shot + run_instance_ensemble; "
+                          "C SHOT oracle), %.1f s" % (n_cpu, dtc),
+                   threads_per_stage={"shot_descriptor": 1, "mlp_matmuls": "BLAS default (all cores)", "votes_and_bins": 1})
+        agree = dict(instances=n_cpu,
+                     pick_equal=int(sum(int(pick[b]) == o["pick"] for b, o in enumerate(outs))),
+                     centre_argmax_equal=[int(sum(int(both[m]["argmax"][b]) == o["models"][m]["argmax"] for b, o in enumerate(outs))) for m in (0, 1)],
+                     up_bin_equal=[int(sum(int(both[m]["up_idx"][b]) == o["models"][m]["up_idx"] for b, o in enumerate(outs))) for m in (0, 1)],
+                     max_abs_loss_difference=float(max(abs(float(step.pipe.losses[m][b]) - o["models"][m]["loss"])
+                                                       for b, o in enumerate(outs) for m in (0, 1))))
+    total = B * world * args.steps
+    line = {
+        "metric": "scenes/sec (1/2/4/8 GPU) at 4096 pts x 20k tuples; 5deg5cm match vs ref",
+        "value": total / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: DINO + SHOT ensemble, every instance voted by BOTH models (eval.py:219-372), %d "
+                               "instances/GPU x %d pts x %d tuples x %d rots, 720 sphere bins, res 2 mm, bottle axes (y-only "
+                               "alignment loss); random-init weights + teacher prior; DINOv2 descriptors = seeded unit vectors "
+                               "[N, 1024] resident in HBM (inputs of the path); MLP arithmetic %s; one scene = one instance "
+                               "through both models" % (B, N, T, R, _models.MLP_ARITH),
+                   "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
+        "step_ms_sampled": {"min": round(step_times[0], 4), "median": round(step_times[len(step_times) // 2], 4),
+                            "max": round(step_times[-1], 4), "n": len(step_times)},
+        "per_model_ms": {"shared (sampler, normals + SHOT352)": round(shared_ms, 4),
+                         "dino (point transforms .. alignment loss)": round(dino_ms, 4),
+                         "shot (point encoder .. alignment loss)": round(shot_ms, 4),
+                         "dino_over_shot": round(dino_ms / shot_ms, 4) if shot_ms > 0 else None},
+        "picked": {"dino": int((pick == 0).sum()), "shot": int((pick == 1).sum()), "none": int((pick < 0).sum())},
+        "roofline": dict(bound="mfma", kernel="tuple_mlp (both models) + the DINO model's per-point Linear launches",
+                         kernel_name="reslayer_split_kernel", achieved=(ex_d + ex_s) / 1e12 / (mlp_ms / 1e3),
+                         peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ex_d + ex_s) / 1e12 / (mlp_ms / 1e3) / BF16_MFMA_PEAK_TFLOPS,
+                         traffic=None, traffic_note="not measured in this run (rocprofv3 --pmc passes: profiles/r4_ensemble_*)",
+                         launch_ms=mlp_ms, launches=8,
+                         frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
+                         executed_flops_per_step={"dino": ex_d, "shot": ex_s},
+                         algorithmic_f32_flops_per_step={"dino (the reference's row form)": al_d, "shot": al_s},
+                         per_stage_ms={s_: round(stage_ms.get(s_, 0.0), 4) for s_ in EnsembleStep.STAGES}),
+        "cpu_baseline": cpu, "oracle_agreement": agree, "pose_5deg5cm_vs_gt": ok / B,
+        "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
+                       "records_gathered": int(all_rec.shape[0]), "bytes_per_rank": int(B * 160),
+                       "gather_us": round(1e3 * stage_ms.get("gather", 0.0), 2)},
+        "ok": True, "problems": [],
+    }
+    print(json.dumps(line))
 
 
 GATHERED_TUPLES = False         # set by main(): the encode stage writes pair features + indices only
@@ -502,6 +718,41 @@ def main():
     from cppf2_amd import models as _models
     if args.mlp_arith:
         _models.MLP_ARITH = args.mlp_arith
+    if args.workload == "ensemble":
+        assert _models.MLP_ARITH in ("split", "split16"), "--workload ensemble runs the library's kernels (split arithmetic)"
+        step = EnsembleStep(args, rank, world, dev)
+        step.prepare_events()
+        step.run()
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step.run()
+        n_s = min(args.steps, Step.EVENT_SLOTS)
+        sampled = {int(round((j + 0.5) * args.steps / n_s - 0.5)): j for j in range(n_s)}
+
+        def sync_():
+            torch.cuda.synchronize()
+            if torch.distributed.is_initialized():
+                torch.distributed.barrier()
+                torch.cuda.synchronize()
+        sync_()
+        t0 = time.perf_counter()
+        evs = []
+        for i_ in range(args.steps):
+            ev_ = step.run(timed=sampled.get(i_))
+            if ev_ is not None:
+                evs.append(ev_)
+        sync_()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if torch.distributed.is_initialized():
+            if torch.distributed.get_backend() == "gloo":
+                tmax = tmax.cpu()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            report_ensemble(args, step, float(tmax.item()), evs, world, backend)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     step = Step(args, rank, world, dev)
     global GATHERED_TUPLES, FUSED_DRAW
     with torch.no_grad():           # the support checks look at the inference mode Step.run() executes in

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 if os.environ.get("CPPF_LIB"):           # a differently built library (probe builds under scratch/); same ABI version required
     LIB_PATH = os.path.abspath(os.environ["CPPF_LIB"])
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CppfError(RuntimeError):
@@ -39,7 +39,7 @@ class ReslayerSplit16Args(C.Structure):
                 ("first_out", C.c_void_p), ("ld_first", C.c_int64),
                 ("gidx", C.c_void_p), ("slots", C.c_int32), ("table", C.c_void_p), ("fdim", C.c_int32),
                 ("logit_prior", C.c_void_p), ("uniforms", C.c_void_p), ("bins", C.c_void_p),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("mode", C.c_int32), ("ld_table", C.c_int64)]
 
 
 assert C.sizeof(SceneGrid) == 32
@@ -107,6 +107,12 @@ SIGNATURES = {
     "cppf_decode_from_bins": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_encode_tuples_shot_heads": (_i, [_i, _p, _p, _p, _i, _p, _p, _i64, _p, _i, _p, _p]),
     "cppf_reslayer_split_gather": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
+    "cppf_linear_split_stream_bytes": (_i64, [_i32, _i32]),
+    "cppf_linear_split": (_i, [_p, _i64, _i32, _p, _i64, _i32, _i64, _p, _i64, _p, _p]),
+    "cppf_encode_tuples_coord_heads": (_i, [_i, _p, _p, _i, _p, _p, _i64, _p, _i32, _p, _p]),
+    "cppf_reslayer_split_sumgather": (_i, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i32, _i64, _p, _i64, _p, _p, _i32, _p]),
+    "cppf_alignment_loss": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "cppf_ensemble_select": (_i, [_i, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "cppf_assemble_pose": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -429,14 +429,16 @@ struct __attribute__((packed, aligned(4))) Row3 {
   float x, y, z;
 };
 
-template <int KC>
+// COORD: the DINO model's head block instead (train_dino.py:92): the 3 C(k,2) coordinate differences only, zero-padded to a
+// multiple of 8 columns (cppf_encode_tuples_coord_heads); nrm is not read.
+template <int KC, bool COORD = false>
 __global__ __launch_bounds__(256) void encode_shot_heads_tile_kernel(const float* __restrict__ pts, const float* __restrict__ nrm,
                                                                      const int32_t* __restrict__ idx,
                                                                      const int32_t* __restrict__ pt_off,
                                                                      const int32_t* __restrict__ tup_off, ComboTable cb,
                                                                      float* __restrict__ heads, int ld,
                                                                      int32_t* __restrict__ gidx) {
-  constexpr int NP = KC * (KC - 1) / 2, NF = 4 * NP, PITCH = NF + 4;
+  constexpr int NP = KC * (KC - 1) / 2, NF = COORD ? (3 * NP + 7) / 8 * 8 : 4 * NP, PITCH = NF + 4;
   __shared__ __attribute__((aligned(16))) float s_out[256 * PITCH];
   __shared__ int32_t s_idx[256 * KC];
   const unsigned b = blockIdx.y;
@@ -462,9 +464,12 @@ __global__ __launch_bounds__(256) void encode_shot_heads_tile_kernel(const float
       for (int q = 0; q < KC; ++q) {
         const int g = s_idx[tid * KC + q];
         // one 12-byte load each (the rows are 4-byte aligned): a third of the gather instructions, which is what bounds this kernel
-        const Row3 pv = *reinterpret_cast<const Row3*>(pts + 3 * (int64_t)g), nv = *reinterpret_cast<const Row3*>(nrm + 3 * (int64_t)g);
+        const Row3 pv = *reinterpret_cast<const Row3*>(pts + 3 * (int64_t)g);
         p[q][0] = pv.x; p[q][1] = pv.y; p[q][2] = pv.z;
-        n[q][0] = nv.x; n[q][1] = nv.y; n[q][2] = nv.z;
+        if (!COORD) {
+          const Row3 nv = *reinterpret_cast<const Row3*>(nrm + 3 * (int64_t)g);
+          n[q][0] = nv.x; n[q][1] = nv.y; n[q][2] = nv.z;
+        }
       }
       float o[4];
 #pragma unroll
@@ -473,6 +478,8 @@ __global__ __launch_bounds__(256) void encode_shot_heads_tile_kernel(const float
         if (f < 3 * NP) {
           const int q = f / 3, c = f - 3 * q;
           v = p[cb.i[q]][c] - p[cb.j[q]][c];
+        } else if (COORD) {
+          v = 0.0f;
         } else {
           const int q = f - 3 * NP;
           const float* ni = n[cb.i[q]];
@@ -485,8 +492,8 @@ __global__ __launch_bounds__(256) void encode_shot_heads_tile_kernel(const float
       }
     }
     __syncthreads();
-    for (int e = tid; e < rows * NP; e += 256) {
-      const int r = e / NP, c4 = e - r * NP;
+    for (int e = tid; e < rows * (NF / 4); e += 256) {
+      const int r = e / (NF / 4), c4 = e - r * (NF / 4);
       *reinterpret_cast<float4*>(heads + (row0 + r) * ld + 4 * c4) = *reinterpret_cast<const float4*>(&s_out[r * PITCH + 4 * c4]);
     }
     __syncthreads();
@@ -510,6 +517,52 @@ extern "C" int cppf_encode_tuples_shot_heads(int B, const float* pts, const floa
   else
     hipLaunchKernelGGL(encode_shot_heads_kernel<0>, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, normals, idx,
                        k, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// The DINO model's head block (coordinate differences, zero-padded to a multiple of 8 columns) + global point indices: the
+// inputs of cppf_reslayer_split_sumgather.  k = 5 runs the tile kernel above; other k a thread-per-tuple kernel.
+__global__ __launch_bounds__(256) void encode_coord_heads_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int k,
+                                                                 const int32_t* __restrict__ pt_off,
+                                                                 const int32_t* __restrict__ tup_off, ComboTable cb,
+                                                                 float* __restrict__ heads, int ld, int32_t* __restrict__ gidx) {
+  const unsigned b = blockIdx.y;
+  const int p0 = pt_off[b];
+  const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
+  const int np = k * (k - 1) / 2, nf = (3 * np + 7) / 8 * 8;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < (unsigned)nt; t += gridDim.x * blockDim.x) {
+    const int64_t row = (int64_t)t0 + t;
+    for (int q = 0; q < k; ++q) gidx[row * k + q] = p0 + idx[row * k + q];
+    float* dst = heads + row * ld;
+    for (int f = 0; f < nf; ++f) {
+      float v = 0.0f;
+      if (f < 3 * np) {
+        const int q = f / 3, c = f - 3 * q;
+        v = pts[3 * (int64_t)(p0 + idx[row * k + cb.i[q]]) + c] - pts[3 * (int64_t)(p0 + idx[row * k + cb.j[q]]) + c];
+      }
+      dst[f] = v;
+    }
+  }
+}
+
+extern "C" int cppf_encode_tuples_coord_heads(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
+                                              const int32_t* tup_off, int64_t total_tuples, float* heads, int32_t ld_heads,
+                                              int32_t* gidx, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && idx && pt_off && tup_off && heads && gidx);
+  CPPF_CHECK_ARG(k >= 2 && k <= 8);
+  const int nf = (3 * (k * (k - 1) / 2) + 7) / 8 * 8;
+  CPPF_CHECK_ARG(ld_heads >= nf && (ld_heads & 3) == 0 && (((uintptr_t)heads) & 15) == 0);
+  if (total_tuples <= 0) return CPPF_OK;
+  int64_t bx = ((total_tuples + B - 1) / B + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  if (k == 5)
+    hipLaunchKernelGGL((encode_shot_heads_tile_kernel<5, true>), dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts,
+                       (const float*)nullptr, idx, pt_off, tup_off, make_combos(k), heads, ld_heads, gidx);
+  else
+    hipLaunchKernelGGL(encode_coord_heads_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, pts, idx, k, pt_off,
+                       tup_off, make_combos(k), heads, ld_heads, gidx);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }

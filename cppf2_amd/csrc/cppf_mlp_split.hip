@@ -47,8 +47,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) for layers up to 128 wide, 4 (one per SIMD, 512 registers:
 // both accumulator sets of a 192- / 256-wide layer at once) above
 __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
+// launch forms of the kernel beyond the ResLayer itself (template argument MODE):
+//   RS_LINEAR     y = x W^T + b, a plain nn.Linear (no ReLU, no second product, no skip) over `groups` column blocks of 32 NT
+//                 outputs each -- the per-point transforms of the DINO model (train_dino.py:86-87) and the per-point slot tables
+//                 below; only the first product of the ResLayer kernel, so 128 accumulator registers: always 8 wavefronts;
+//   RS_SUMGATHER  the ResLayer whose input row is [heads | sum-able per-point parts]: the part of x W1^T (and x W0^T) that
+//                 belongs to the tuple's points has been evaluated once per POINT and slot (a table [points, slots, 2 x 32 NT],
+//                 RS_LINEAR writes it), so the accumulators start from bias + sum_i table[gidx[t, i]][i] and only the head
+//                 columns go through the matrix cores.
+#define RS_RESLAYER 0
+#define RS_LINEAR 1
+#define RS_SUMGATHER 2
+// (RS_SUMGATHER keeps the 8-wavefront workgroup of the other 128-wide launches.  Its table loads -- 160 sixteen-byte loads per lane
+// and row block, 32 distinct rows per wavefront instruction -- occupy the CU's texture-address unit for ~25 us per 256 rows while
+// no wavefront of the CU multiplies: 2.5 ms per launch against 1.85 ms with the loads removed and 2.4 ms with every load an L2 hit,
+// i.e. address processing, not memory latency.  Measured alternatives, none faster: two half-size workgroups per CU with and
+// without a half-block start-up stagger (2.5 ms: the other workgroup's weight stream queues behind the loads), 4 wavefronts of 512
+// registers building the next block's sums in a second accumulator set during the products (2.2 ms without the loads -- one
+// wavefront per SIMD costs 20 % -- and 3.2 ms with them: spills).)
+__host__ __device__ constexpr int rs_waves_mode(int nt, int mode) { return mode == RS_LINEAR ? 8 : rs_waves(nt); }
+__host__ __device__ constexpr int rs_stage_tiles(int mode) { return 16; }     // tile-steps per ring stage
+__host__ __device__ constexpr int rs_wgs_per_cu(int mode) { return 1; }
 #define RS_FRAG_BYTES 1024                      // one operand fragment: 64 lanes x 8 bf16
-#define RS_STAGE_BYTES (16 * 3 * RS_FRAG_BYTES) // one staged chunk: up to 16 tile-steps of three fragments (48 KiB)
+// one staged chunk: up to STG tile-steps of three fragments (16: 48 KiB; 8: 24 KiB)
+__host__ __device__ constexpr int rs_stage_bytes(int stg) { return stg * 3 * RS_FRAG_BYTES; }
 // PC = operand pieces: 3 = bf16 (hi, mid, lo: exact, six products per K step), 2 = fp16 (hi, lo: 22-23 significant bits per
 // operand, three products per K step; see the f16x2 section below)
 __host__ __device__ constexpr int rs_tile_bytes(int pc) { return pc * RS_FRAG_BYTES; }
@@ -87,7 +109,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // K steps per staged chunk (one barrier per chunk): as many as fit a stage
-__host__ __device__ constexpr int rs_spc(int tiles) { return tiles >= 9 ? 1 : tiles >= 5 ? 2 : 4; }
+__host__ __device__ constexpr int rs_spc(int tiles, int stg = 16) { return stg / tiles >= 4 ? 4 : stg / tiles >= 2 ? 2 : 1; }
 
 struct RsFrag {                                  // one operand fragment per slice, as raw dwords (2 bf16 each)
   unsigned h[4], m[4], l[4];
@@ -175,10 +197,11 @@ __host__ __device__ constexpr int rs_waitcnt(int vm, int lgkm) {
 // tiles), then W1, W2 of each chained layer (2 NT steps of NT tiles each).  It moves through a two-stage LDS ring by LDS-DMA in chunks of up to rs_spc(tiles) K steps of one segment: the
 // pieces of chunk c + 1 (1 KiB per wavefront instruction) are issued between the MFMAs of the first K step of chunk c.
 // All memory waits of the kernel's main loops are COUNTED (the vector-memory queue completes in order): see acquire().
-template <int NT, int T0, int WAVES, int PC>
+template <int NT, int T0, int WAVES, int PC, bool LIN = false, int STG = 16>
 struct RsStream {
+  static constexpr int STG_ = STG, SPC0 = rs_spc(T0, STG), SPC1 = rs_spc(NT, STG), STAGE_BYTES = rs_stage_bytes(STG);
   // pieces of a chunk per wavefront, at most (a chunk = rs_spc(tiles) K steps of `tiles` tiles, three fragments each)
-  static constexpr int P0 = (rs_spc(T0) * T0 * PC + WAVES - 1) / WAVES, P1 = (rs_spc(NT) * NT * PC + WAVES - 1) / WAVES;
+  static constexpr int P0 = (SPC0 * T0 * PC + WAVES - 1) / WAVES, P1 = (SPC1 * NT * PC + WAVES - 1) / WAVES;
   static constexpr int PMAX = RS_EXACT_PMAX ? (P0 > P1 ? P0 : P1) : 48 / WAVES;
   int nseg;                    // 2 + 2 per chained identity layer
   int chunks;                  // chunks per row block
@@ -195,20 +218,25 @@ struct RsStream {
   int p_last;
 
   __device__ __forceinline__ void shape(int chain) {
+    if (LIN) {                                   // `chain` column groups, each one first-product segment (ks1 steps of T0 tiles)
+      nseg = chain;
+      chunks = chain * ((ks1 + SPC0 - 1) / SPC0);
+      return;
+    }
     nseg = 2 + 2 * chain;
-    chunks = (ks1 + rs_spc(T0) - 1) / rs_spc(T0) + (1 + 2 * chain) * (2 * NT / rs_spc(NT));
+    chunks = (ks1 + SPC0 - 1) / SPC0 + (1 + 2 * chain) * (2 * NT / SPC1);
   }
   // selects the next chunk of the stream (destination: stage st); its pieces are then issued one by one with piece()
   __device__ __forceinline__ void plan(int st) {
-    p_dst = ring + st * RS_STAGE_BYTES;
+    p_dst = ring + st * STAGE_BYTES;
     if (left <= 0) {                             // past the end: piece() re-reads the stream's first KiB into the idle stage
       p_src = base + lane * 16;
       p_last = 0;
       return;
     }
-    const bool first = seg == 0;
+    const bool first = LIN || seg == 0;
     const int tiles = first ? T0 : NT;
-    const int spc = first ? rs_spc(T0) : rs_spc(NT);
+    const int spc = first ? SPC0 : SPC1;
     const int steps = first ? ks1 : 2 * NT;
     const int ns = steps - pos < spc ? steps - pos : spc;
     const int pieces = ns * tiles * PC;
@@ -253,7 +281,7 @@ struct RsStream {
     const int cur = stage;
     stage ^= 1;
     plan(stage);
-    return reinterpret_cast<const u32x4*>(ring + cur * RS_STAGE_BYTES) + lane;
+    return reinterpret_cast<const u32x4*>(ring + cur * STAGE_BYTES) + lane;
   }
 };
 
@@ -379,7 +407,7 @@ struct RsX {
 // step s's MFMAs.
 template <int NTILES, bool PREFETCH, int PC, class X, class Stream>
 __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, const RsRow rw, int ks1, Stream& ws) {
-  constexpr int SPC = rs_spc(NTILES);
+  constexpr int SPC = rs_spc(NTILES, Stream::STG_);
   float xv[8];
   RS_WAIT(4, 15);                                    // tile 0 has landed (tiles 1, 2 may be in flight)
   __builtin_amdgcn_sched_barrier(0);
@@ -417,7 +445,7 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, 
 // (bs: the factor the source tiles carry and the B operand must not -- 1 for the bf16 triples, 1 / weight scale for the fp16 pairs)
 template <int NS, int NTILES, bool PREFETCH, int PC, class Stream>
 __device__ __forceinline__ void rs_product_h(f32x16 (&dst)[NTILES], const f32x16 (&src)[NS], Stream& ws, float bs) {
-  constexpr int SPC = rs_spc(NTILES);
+  constexpr int SPC = rs_spc(NTILES, Stream::STG_);
   static_assert((2 * NS) % SPC == 0, "whole chunks");
   RsFrag b;
 #pragma unroll
@@ -545,10 +573,11 @@ struct RsTap {                  // optional second output: the activation after 
   int64_t ld = 0;
 };
 
-struct RsGather {               // GATHER launches: see RsX
+struct RsGather {               // GATHER launches: see RsX; RS_SUMGATHER: the per-point slot tables
   const int32_t* gidx = nullptr;   // [rows, slots] global point indices
-  const float* table = nullptr;    // [points, 1 << fshift]
+  const float* table = nullptr;    // GATHER: [points, 1 << fshift]; RS_SUMGATHER: [points, slots, 2 x 32 NT] (row pitch tld floats)
   int slots = 0, head = 0, fshift = 0;
+  int64_t tld = 0;
 };
 
 // f16x2 (PC == 2, CPPF_MLP_ARITH=split16): every float32 operand as an fp16 pair hi + lo (22-23 significant bits), three
@@ -558,16 +587,19 @@ struct RsGather {               // GATHER launches: see RsX
 // included, so the skip additions need no rescaling -- and only the B operand of the next product (and the stored outputs) are
 // multiplied by 1 / wscale (exact).  Activations are split unscaled: |x| < 65504 is required, subnormal lo pieces are honoured
 // by the matrix core (absolute resolution 2^-25 for small activations).
-template <int NT, bool PROJ, bool GATHER, bool DECODE = false, int PC = 3>
-__global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
+template <int NT, bool PROJ, bool GATHER, bool DECODE = false, int PC = 3, int MODE = RS_RESLAYER>
+__global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) void reslayer_split_kernel(const float* x, int64_t ldx, int k_in, float* out,
                                                                               int64_t ldo, int64_t rows,
                                                                               const char* __restrict__ wq,
                                                                               const float* __restrict__ b1,
                                                                               const float* __restrict__ b0, int chain,
                                                                               RsGather ga, RsDecode dc, RsTap tap, float wscale) {
   const float bs = (PC == 2) ? 1.0f / wscale : 1.0f;        // B-operand / output factor (a power of two: exact)
-  constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
+  constexpr int WAVES = rs_waves_mode(NT, MODE), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
+  constexpr bool LIN = MODE == RS_LINEAR;
+  static_assert(!LIN || (!PROJ && !GATHER && !DECODE), "a plain Linear has one product");
+  static_assert(MODE != RS_SUMGATHER || (PROJ && !GATHER), "the table sums stand for columns of a projection layer's input");
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
   const int lane = threadIdx.x & 63;
@@ -577,7 +609,16 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
 
-  RsStream<NT, T0, WAVES, PC> ws;
+  constexpr int STG = rs_stage_tiles(MODE), RING_BYTES = 2 * rs_stage_bytes(STG);
+  RsStream<NT, T0, WAVES, PC, LIN, STG> ws;
+  // RS_LINEAR: `chain` is the number of column groups this workgroup evaluates (blockIdx.y selects which: grids with fewer row
+  // blocks than CUs are spread over the groups as well)
+  const int64_t seg_bytes = (int64_t)ks1 * T0 * rs_tile_bytes(PC);
+  if (LIN) {
+    wq += (int64_t)blockIdx.y * chain * seg_bytes;
+    b1 = b1 ? b1 + (int64_t)blockIdx.y * chain * 32 * NT : b1;
+    out += (int64_t)blockIdx.y * chain * 32 * NT;
+  }
   ws.base = wq;
   ws.ring = s_ring;
   ws.ks1 = ks1;
@@ -591,17 +632,21 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
   ws.lane = lane;
   ws.prime();
   // the biases live in LDS: as kernel-lifetime registers (where the compiler would hoist them) they cost 16 per tile
-  float* s_b1 = reinterpret_cast<float*>(s_ring + 2 * RS_STAGE_BYTES + WAVES * 3 * 2048);
+  float* s_b1 = reinterpret_cast<float*>(s_ring + RING_BYTES + WAVES * 3 * 2048);
   float* s_b0 = s_b1 + 32 * NT;                 // directly behind b1: the first product initialises both in one sweep
-  for (int i = threadIdx.x; i < 32 * NT; i += THREADS) {
-    s_b1[i] = b1[i];
-    if (PROJ) s_b0[i] = b0[i];
+  if (LIN) {
+    for (int i = threadIdx.x; i < 32 * NT * chain; i += THREADS) s_b1[i] = b1 ? b1[i] : 0.0f;      // one bias block per group
+  } else {
+    for (int i = threadIdx.x; i < 32 * NT; i += THREADS) {
+      s_b1[i] = b1[i];
+      if (PROJ) s_b0[i] = b0[i];
+    }
+    for (int i = threadIdx.x; i < 32 * NT * chain; i += THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
   }
-  for (int i = threadIdx.x; i < 32 * NT * chain; i += THREADS) s_b1[2 * 32 * NT + i] = b1[32 * NT + i];   // chained layers
   __syncthreads();
 
   RsX<GATHER> xs;
-  xs.slots = s_ring + 2 * RS_STAGE_BYTES + wave * (3 * 2048);
+  xs.slots = s_ring + RING_BYTES + wave * (3 * 2048);
   xs.k_in = k_in;
   xs.g = g;
   xs.lane = lane;
@@ -614,7 +659,7 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     RsRow rw;
     rw.xrow = x + rc * ldx;
     rw.g0 = rw.g1 = rw.g2 = rw.g3 = rw.g4 = rw.g5 = rw.g6 = rw.g7 = 0;
-    if (GATHER) {
+    if (GATHER || MODE == RS_SUMGATHER) {
       const int32_t* p = ga.gidx + rc * ga.slots;
       rw.g0 = p[0];
       rw.g1 = ga.slots > 1 ? p[1] : 0; rw.g2 = ga.slots > 2 ? p[2] : 0; rw.g3 = ga.slots > 3 ? p[3] : 0;
@@ -629,6 +674,45 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     xs.issue(1, 1, cur);
     xs.issue(2, 2, cur);
   }
+  if constexpr (LIN) {
+    // ---- plain Linear: per row block, one pass over x per column group; the accumulators go straight to memory -----------
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+      const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
+      const bool in = row < rows;
+      const bool more = blk + gridDim.x < nblocks;
+      const RsRow nxt = row_of(more ? blk + gridDim.x : blk);
+#pragma unroll 1
+      for (int grp = 0; grp < chain; ++grp) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) rs_load_tile(acc[u], s_b1 + 32 * (grp * NT + u), g);
+        rs_product_x<NT, false, PC>(acc, xs, cur, ks1, ws);
+        const bool last = grp + 1 == chain;
+        if (!last || more) {                      // the x tiles of the next pass: the same rows again, or the next row block's
+          const RsRow nx = last ? nxt : cur;
+          xs.issue(0, 0, nx);
+          xs.issue(1, 1, nx);
+          xs.issue(2, 2, nx);
+        }
+        if (in) {
+          float* orow = out + row * ldo + (int64_t)grp * 32 * NT + 4 * g;
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+              v.x = acc[u][4 * q + 0]; v.y = acc[u][4 * q + 1]; v.z = acc[u][4 * q + 2]; v.w = acc[u][4 * q + 3];
+              if (PC == 2) v *= bs;
+              *reinterpret_cast<f32x4*>(orow + 32 * u + 8 * q) = v;
+            }
+          }
+        }
+      }
+      cur = nxt;
+    }
+    RS_WAIT(0, 15);
+    return;
+  }
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
@@ -641,6 +725,35 @@ __global__ __launch_bounds__(64 * rs_waves(NT), 1) void reslayer_split_kernel(co
     f32x16 (&o)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
 #pragma unroll
     for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
+    if constexpr (MODE == RS_SUMGATHER) {
+      // + sum_i table[gidx[row, i]][i][:]: the per-point parts of x W1^T (tiles 0 .. NT-1) and x W0^T (tiles NT .. 2 NT-1) of this
+      // lane's row, in slot order (a fixed order: the sums do not depend on the launch geometry).  Lane (r, g) owns features
+      // 32 u + 8 q + 4 g + (0..3) of tile u: one 16-byte load each, 16 of them (4 tiles) requested before the first is added.
+#pragma unroll 1
+      for (int i = 0; i < ((RS_DBG & 64) ? 0 : ga.slots); ++i) {
+        int p = cur.g0;
+        p = i == 1 ? cur.g1 : p; p = i == 2 ? cur.g2 : p; p = i == 3 ? cur.g3 : p; p = i == 4 ? cur.g4 : p;
+        p = i == 5 ? cur.g5 : p; p = i == 6 ? cur.g6 : p; p = i == 7 ? cur.g7 : p;
+        if (RS_DBG & 128) p &= 255;
+        const float* trow = ga.table + ((int64_t)p * ga.tld + (int64_t)i * (32 * T0)) + 4 * g;
+#pragma unroll
+        for (int u0 = 0; u0 < T0; u0 += 4) {
+          f32x4 t[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const f32x4*>(trow + 32 * (u0 + (j >> 2)) + 8 * (j & 3));
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            f32x16& a = acc[u0 + (j >> 2)];
+            const int q = j & 3;
+            if (PC == 2) {                           // (f16x2: the accumulators carry the weight scale)
+              a[4 * q + 0] += t[j].x * wscale; a[4 * q + 1] += t[j].y * wscale; a[4 * q + 2] += t[j].z * wscale; a[4 * q + 3] += t[j].w * wscale;
+            } else {
+              a[4 * q + 0] += t[j].x; a[4 * q + 1] += t[j].y; a[4 * q + 2] += t[j].z; a[4 * q + 3] += t[j].w;
+            }
+          }
+        }
+      }
+    }
     if (!PROJ && (WAVES == 8 || RS_EARLY_RESIDUAL)) {   // residual of an identity layer: requested before the first product (while
                                                         // the x tiles of the same rows are passing through L2)
 #pragma unroll
@@ -756,16 +869,28 @@ extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
   return CPPF_OK;
 }
 
-template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false, int PC = 3>
+template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false, int PC = 3, int MODE = RS_RESLAYER>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
                      RsDecode dc = RsDecode(), RsTap tap = RsTap(), float wscale = 1.0f) {
-  constexpr int WAVES = rs_waves(NT), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
-  const int lds_bytes = 2 * RS_STAGE_BYTES + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4;
+  constexpr int WAVES = rs_waves_mode(NT, MODE), THREADS = 64 * WAVES, BLOCK_ROWS = 32 * WAVES;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int forced = g_rs_debug_cus.load();
   if (forced > 0) cus = forced;
+  cus *= rs_wgs_per_cu(MODE);
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
+  // RS_LINEAR: `chain` = column groups of 32 NT outputs; with fewer row blocks than CUs the groups are spread over blockIdx.y
+  unsigned gy = 1;
+  if (MODE == RS_LINEAR && (int64_t)grid * 2 <= cus) {
+    for (int d = chain; d >= 1; --d)
+      if (chain % d == 0 && (int64_t)grid * d <= cus) { gy = (unsigned)d; break; }
+    chain /= (int)gy;
+  }
+  const int lds_bytes = 2 * rs_stage_bytes(rs_stage_tiles(MODE)) + WAVES * 3 * 2048 + (MODE == RS_LINEAR ? chain : 2 + chain) * 32 * NT * 4;
+  if (lds_bytes > 160 * 1024 / rs_wgs_per_cu(MODE)) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "reslayer_split: %d bytes of LDS for the biases of this launch (too many column groups)", lds_bytes);
+    return CPPF_EINVAL;
+  }
   {
     // more than 64 KiB of dynamic LDS: declared once per kernel and device
     static std::mutex mu;
@@ -774,15 +899,21 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
     CPPF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     if (!done[dev & 63]) {
-      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC>,
+      CPPF_HIP(hipFuncSetAttribute((const void*)reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC, MODE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev & 63] = true;
     }
   }
-  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC>), dim3(grid), dim3(THREADS), lds_bytes, stream, x, ldx,
-                     k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc, tap, wscale);
+  hipLaunchKernelGGL((reslayer_split_kernel<NT, PROJ, GATHER, DECODE, PC, MODE>), dim3(grid, gy), dim3(THREADS), lds_bytes, stream, x,
+                     ldx, k_in, out, ldo, rows, wq, b1, b0, chain, ga, dc, tap, wscale);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
+}
+
+static int rs_cus() {
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+  return n_cu > 0 ? n_cu : 256;
 }
 
 // out[rows, n_out] = L_chain(...L_1(L_0(x))): L_0(x) = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T with skip = x (b0 == NULL;
@@ -920,6 +1051,65 @@ extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k
 }
 
 
+// A plain nn.Linear on the matrix cores in the same split arithmetic: out[rows, n_out] = x[rows, :k_in] W^T + bias (bias may be
+// NULL).  The DINO model's per-point transforms (train_dino.py:86-87: desc_transform over [N, 1024]; desc_pair_transform's
+// slices, folded with the first ResLayer's weights into per-point slot tables, see cppf_reslayer_split_sumgather) run through
+// it, so that no layer of either model is left to a BLAS library.  n_out a multiple of 256 (column groups of 256: one pass over
+// x each), k_in a multiple of 8; x / out as cppf_reslayer_split.  wq = cppf_linear_split_stream_bytes(k_in, n_out) bytes: per
+// column group the first-product segment of pack_split for that group's 256 rows of W (cppf2_amd.models.pack_linear).
+extern "C" int64_t cppf_linear_split_stream_bytes(int32_t k_in, int32_t n_out) {
+  if (k_in <= 0 || n_out <= 0 || (n_out & 255) != 0) return -1;
+  return (int64_t)((k_in + 15) / 16) * (n_out / 32) * rs_tile_bytes(3);
+}
+
+extern "C" int cppf_linear_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
+                                 const void* wq, int64_t wq_bytes, const float* bias, void* stream) {
+  CPPF_CHECK_ARG(x && out && wq && rows >= 0);
+  CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && n_out > 0 && (n_out & 255) == 0 && ldo >= n_out && (ldo & 3) == 0);
+  CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
+  CPPF_CHECK_ARG(wq_bytes == cppf_linear_split_stream_bytes(k_in, n_out));
+  if (rows == 0) return CPPF_OK;
+  return rs_launch<8, false, false, false, 3, RS_LINEAR>(x, ldx, k_in, out, ldo, rows, static_cast<const char*>(wq), bias, nullptr,
+                                                         n_out / 256, rs_cus(), (hipStream_t)stream);
+}
+
+// The first ResLayer of a tuple encoder (a 128-wide projection layer, + `chain` identity layers) whose input row is
+//   [heads[t, 0:head_cols] | s(t)],   s(t) = a sum / concatenation over the tuple's points of per-point vectors
+// (DINO model, train_dino.py:91-97: s = desc_pair_transform(cat_i desc_transform(desc[idx_i])); SHOT model, train_shot.py:75-83:
+// s = cat_i feat[idx_i]) WITHOUT forming the row: x W1^T and x W0^T are linear in s, so their per-point parts are evaluated once
+// per point and slot -- tables[n][i] = [W1_i p_n | W0_i p_n], 128 + 128 floats, written by cppf_linear_split from host-folded
+// weights (cppf2_amd.models) -- and the kernel starts its accumulators from bias + sum_i tables[gidx[t, i]][i] (slot order);
+// only the head columns (pair coordinates: 30 -> 32 columns) go through the matrix cores in the first product.  The tuple rows
+// are never written, and the first product shrinks from 18 (DINO) / 23 (SHOT) K steps to 2 / 3.
+// heads / gidx / out / b1 / b0 / chain as cppf_reslayer_split_gather; tables float32 [points, slots, 256] with point pitch
+// ld_tables floats (>= slots * 256, % 4); wq = cppf_reslayer_split_stream_bytes(head_cols, 128, 1, chain) bytes (the head
+// columns' weights only); b1 / b0 must include the bias terms of the folded transforms.
+extern "C" int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx,
+                                             int32_t slots, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
+                                             int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
+                                             const float* b0, int32_t chain, void* stream) {
+  CPPF_CHECK_ARG(heads && gidx && tables && out && wq && b1 && b0 && rows >= 0);
+  CPPF_CHECK_ARG(head_cols > 0 && (head_cols & 7) == 0 && ld_heads >= head_cols && (ld_heads & 3) == 0);
+  CPPF_CHECK_ARG(slots >= 1 && slots <= 8 && ld_tables >= (int64_t)slots * 256 && (ld_tables & 3) == 0);
+  CPPF_CHECK_ARG((ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
+  CPPF_CHECK_ARG((((uintptr_t)heads | (uintptr_t)tables | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(head_cols, n_out, 1, chain));
+  if (n_out != 128) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_reslayer_split_sumgather: n_out = %d (only the 128-wide projection layer of the "
+             "tuple encoders has this kernel)", n_out);
+    return CPPF_EUNSUPPORTED;
+  }
+  if (rows == 0) return CPPF_OK;
+  RsGather ga;
+  ga.gidx = gidx;
+  ga.table = tables;
+  ga.slots = slots;
+  ga.tld = ld_tables;
+  return rs_launch<4, true, false, false, 3, RS_SUMGATHER>(heads, ld_heads, head_cols, out, ldo, rows, static_cast<const char*>(wq), b1, b0,
+                                                           chain, rs_cus(), (hipStream_t)stream, ga);
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // f16x2 arithmetic (CPPF_MLP_ARITH=split16): one entry point for every launch form
 // ---------------------------------------------------------------------------------------------------------------------
@@ -940,7 +1130,7 @@ static int rs16_plain(const CppfReslayerSplit16Args& a, int n_cu, RsTap tap) {
 extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
   CPPF_CHECK_ARG(args != nullptr);
   const CppfReslayerSplit16Args& a = *args;
-  CPPF_CHECK_ARG(a.x && a.wq && a.b1 && a.rows >= 0 && a.chain >= 0 && a.chain <= 15);
+  CPPF_CHECK_ARG(a.x && a.wq && (a.b1 || a.mode == 1) && a.rows >= 0 && a.chain >= 0 && a.chain <= 15);
   {
     int e = 0;
     CPPF_CHECK_ARG(a.weight_scale > 0.0f && frexpf(a.weight_scale, &e) == 0.5f);        // a power of two
@@ -950,6 +1140,7 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
   CPPF_CHECK_ARG((a.ldx & 3) == 0 && (a.ldo & 3) == 0 && (a.ld_first & 3) == 0);
   const bool gather = a.gidx != nullptr, decode = a.uniforms != nullptr, proj = a.b0 != nullptr;
   CPPF_CHECK_ARG(!(gather && decode) && !((gather || decode) && a.first_out));
+  CPPF_CHECK_ARG(a.mode == 0 || (a.mode == 1 && !gather && !decode && !proj && !a.first_out) || (a.mode == 2 && gather));
   if (a.rows == 0) return CPPF_OK;
   int dev = 0, n_cu = 0;
   CPPF_HIP(hipGetDevice(&dev));
@@ -957,6 +1148,25 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
   if (n_cu <= 0) n_cu = 256;
   const char* w = static_cast<const char*>(a.wq);
   hipStream_t st = (hipStream_t)a.stream;
+  if (a.mode == 1) {                             // plain Linear (cppf_linear_split): b1 = weight_scale x the bias or NULL
+    CPPF_CHECK_ARG(a.out && a.k_in > 0 && (a.k_in & 7) == 0 && a.ldx >= a.k_in && a.n_out > 0 && (a.n_out & 255) == 0 && a.ldo >= a.n_out);
+    CPPF_CHECK_ARG(a.wq_bytes == (int64_t)((a.k_in + 15) / 16) * (a.n_out / 32) * rs_tile_bytes(2));
+    return rs_launch<8, false, false, false, 2, RS_LINEAR>(a.x, a.ldx, a.k_in, a.out, a.ldo, a.rows, w, a.b1, nullptr, a.n_out / 256, n_cu,
+                                                           st, RsGather(), RsDecode(), RsTap(), a.weight_scale);
+  }
+  if (a.mode == 2) {                             // per-point slot tables summed into the accumulators (cppf_reslayer_split_sumgather)
+    CPPF_CHECK_ARG(a.table && proj && a.out && a.n_out == 128 && a.ldo >= 128);
+    CPPF_CHECK_ARG(a.k_in > 0 && (a.k_in & 7) == 0 && a.ldx >= a.k_in);
+    CPPF_CHECK_ARG(a.slots >= 1 && a.slots <= 8 && a.ld_table >= (int64_t)a.slots * 256 && (a.ld_table & 3) == 0);
+    CPPF_CHECK_ARG(a.wq_bytes == rs_stream_bytes(a.k_in, 128, 1, a.chain, 2));
+    RsGather ga;
+    ga.gidx = a.gidx;
+    ga.table = a.table;
+    ga.slots = a.slots;
+    ga.tld = a.ld_table;
+    return rs_launch<4, true, false, false, 2, RS_SUMGATHER>(a.x, a.ldx, a.k_in, a.out, a.ldo, a.rows, w, a.b1, a.b0, a.chain, n_cu, st, ga,
+                                                             RsDecode(), RsTap(), a.weight_scale);
+  }
   if (gather) {
     CPPF_CHECK_ARG(a.table && proj && a.out && a.n_out == 128 && a.ldo >= 128);
     CPPF_CHECK_ARG(a.k_in >= 0 && (a.k_in & 7) == 0 && (a.k_in == 0 || a.ldx >= a.k_in));

@@ -208,3 +208,105 @@ extern "C" int cppf_refine_pose(int B, const float* pts, const int32_t* pt_off, 
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The ensemble score and selection of eval.py:358-372, on the device: both models vote every instance (eval.py:219), each
+// pose is scored by the clipped L1 distance between the kept pairs' points in the object frame and the pair coordinates the
+// model drew, and the smaller score wins (strict '<' against inf, the DINO model first; geo_branch gates model 0 and
+// visual_branch model 1: eval.py:367).  The reference does this in NumPy after six device -> host copies per model; here the
+// two scores and the chosen record never leave the device until the batch's records are read.
+// ---------------------------------------------------------------------------------------------------------------------
+#define AL_THREADS 256
+
+// loss[b] = mean over the kept pairs' 2 end points (x 3 coordinates, or y only) of clip(|canon - pred|, 0, 0.1), float64:
+//   canon = (pc[point] - t) @ R / scale_norm            float32 point - float64 centre -> float64 (eval.py:358)
+//   pred  = bins / (nb - 1) - 0.5                        float32 (eval.py:230; the un-scaled pair the model drew)
+// scale_norm = |scale| of scale_src's record in float32 (np.linalg.norm of the float32 median, eval.py:309-310; the DINO pass'
+// scale also scores the SHOT pass), 1 where it is 0.  Partial sums are added in a fixed order.  NaN when nothing was kept.
+__global__ __launch_bounds__(AL_THREADS) void alignment_loss_kernel(const float* __restrict__ pts, const int32_t* __restrict__ pt_off,
+                                                                    const int32_t* __restrict__ idx, int k,
+                                                                    const int32_t* __restrict__ tup_off,
+                                                                    const int32_t* __restrict__ bins, int nb,
+                                                                    const int32_t* __restrict__ kept_tuple,
+                                                                    const int32_t* __restrict__ kept_count, int y_only,
+                                                                    const CppfSceneResult* __restrict__ results,
+                                                                    const CppfSceneResult* __restrict__ scale_src,
+                                                                    double* __restrict__ loss) {
+  __shared__ double s_part[AL_THREADS];
+  const int b = blockIdx.x;
+  const CppfSceneResult& rec = results[b];
+  const float* sc = scale_src[b].scale;
+  float nrm = __builtin_sqrtf((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]);
+  const double sn = nrm > 0.0f ? (double)nrm : 1.0;
+  const float* p = pts + 3 * (int64_t)pt_off[b];
+  const int t0 = tup_off[b];
+  const int32_t* kept = kept_tuple + t0;
+  const int n = 2 * kept_count[b];
+  const float nbf = (float)(nb - 1);
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < n; e += AL_THREADS) {
+    const int64_t row = (int64_t)t0 + kept[e >> 1];
+    const int pi = idx[row * k + (e & 1)];
+    const double dx = (double)p[3 * pi] - rec.t[0], dy = (double)p[3 * pi + 1] - rec.t[1], dz = (double)p[3 * pi + 2] - rec.t[2];
+    const int32_t* bn = bins + row * 6 + 3 * (e & 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (y_only && c != 1) continue;
+      const double canon = ((dx * rec.R[c] + dy * rec.R[3 + c]) + dz * rec.R[6 + c]) / sn;
+      const float pred = (float)bn[c] / nbf - 0.5f;
+      double d = fabs(canon - (double)pred);
+      d = d < 0.0 ? 0.0 : (d > 0.1 ? 0.1 : d);
+      acc += d;
+    }
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = AL_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) s_part[threadIdx.x] += s_part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[b] = s_part[0] / ((double)n * (y_only ? 1.0 : 3.0));      // 0 / 0 = NaN: nothing kept
+}
+
+extern "C" int cppf_alignment_loss(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k,
+                                   const int32_t* tup_off, const int32_t* bins, int nb, const int32_t* kept_tuple,
+                                   const int32_t* kept_count, int y_only, const CppfSceneResult* results,
+                                   const CppfSceneResult* scale_src, double* loss, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && pt_off && idx && tup_off && bins && kept_tuple && kept_count && results && scale_src && loss);
+  CPPF_CHECK_ARG(k >= 2 && nb >= 2);
+  hipLaunchKernelGGL(alignment_loss_kernel, dim3(B), dim3(AL_THREADS), 0, (hipStream_t)stream, pts, pt_off, idx, k, tup_off, bins,
+                     nb, kept_tuple, kept_count, y_only, results, scale_src, loss);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+// out[b] = the record of the model with the smaller loss (model 0 first, strict '<' against inf; a NaN loss never wins), with
+// the scale of model 0's record (eval.py:308-310, 372) and the pick (0, 1, or -1 when no enabled model has a finite-comparable
+// loss) in pad_[0]; best[b] = the winning loss (inf when none).
+__global__ __launch_bounds__(256) void ensemble_select_kernel(int B, const CppfSceneResult* __restrict__ rec0,
+                                                              const CppfSceneResult* __restrict__ rec1,
+                                                              const double* __restrict__ loss0, const double* __restrict__ loss1,
+                                                              int enable0, int enable1, CppfSceneResult* __restrict__ out,
+                                                              double* __restrict__ best) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double bl = __builtin_inf();
+  int pick = -1;
+  if (enable0 && loss0[b] < bl) { bl = loss0[b]; pick = 0; }
+  if (enable1 && loss1[b] < bl) { bl = loss1[b]; pick = 1; }
+  CppfSceneResult r = pick == 1 ? rec1[b] : rec0[b];
+  r.scale[0] = rec0[b].scale[0]; r.scale[1] = rec0[b].scale[1]; r.scale[2] = rec0[b].scale[2];
+  r.pad_[0] = pick;
+  out[b] = r;
+  best[b] = bl;
+}
+
+extern "C" int cppf_ensemble_select(int B, const CppfSceneResult* rec0, const CppfSceneResult* rec1, const double* loss0,
+                                    const double* loss1, int enable0, int enable1, CppfSceneResult* out, double* best,
+                                    void* stream) {
+  CPPF_CHECK_ARG(B > 0 && rec0 && rec1 && loss0 && loss1 && out && best);
+  hipLaunchKernelGGL(ensemble_select_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, rec0, rec1, loss0, loss1,
+                     enable0, enable1, out, best);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}

@@ -117,6 +117,50 @@ def pack_split(w1, w0, w2, k_in, chain=(), arith="bf16x3", scale=1.0):
     return torch.cat(parts).contiguous()
 
 
+def pack_linear(w, k_in, arith="bf16x3", scale=1.0):
+    """The weight stream cppf_linear_split consumes for out = x W^T (w [n_out, K] as nn.Linear stores it, n_out a multiple of
+    256, k_in >= K the columns of x the kernel reads): per column group of 256 outputs the first-product segment of pack_split
+    (K steps of 8 tiles, operand pieces per tile), the groups one after the other."""
+    n, k = w.shape
+    assert n % 256 == 0 and k_in >= k
+    ks1 = (k_in + 15) // 16
+    pc, split = (2, (lambda t: split_f16(t * scale))) if arith == "f16x2" else (3, split_bf16)
+    s = split(F.pad(w.detach().float(), (0, ks1 * 16 - k)))                         # [pc, n, ks1 * 16]
+    return s.reshape(pc, n // 256, 8, 32, ks1, 2, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(-1).contiguous()   # [grp, s, u, slice, g, i, j]
+
+
+class _FoldedFirstLayer:
+    """A tuple encoder's first ResLayer (a projection layer) on rows [heads | s] with s linear in per-point vectors p of the tuple's
+    points, s = s0 + sum_i E_i p[idx_i]: the per-point parts of x W1^T and x W0^T are moved into per-point slot tables
+        tables[n, i] = [A_i p_n | C_i p_n],   A_i = W1[:, s-columns] E_i,   C_i = W0[:, s-columns] E_i      (128 + 128 floats)
+    (ops.linear_split with `wq_tab`), the constant parts into the biases, and the layer's own products shrink to the head columns
+    (w1_heads / w0_heads).  Algebraically the same layer; the products are folded in float64 and rounded to float32 once."""
+
+    def __init__(self, stamp, a_list, c_list, w1_heads, w0_heads, b1_add=None, b0_add=None):
+        self.stamp = stamp
+        self.slots = len(a_list)
+        self.dp = a_list[0].shape[1]
+        self.tab_w = torch.cat([torch.cat([a, c]) for a, c in zip(a_list, c_list)]).float().contiguous()     # [slots * 256, dp]
+        self.w1_heads, self.w0_heads = w1_heads.float().contiguous(), w0_heads.float().contiguous()       # [128, head columns]
+        self.b1_add, self.b0_add = b1_add, b0_add
+        self._wq = {}
+
+    def table_stream(self):
+        """(packed stream of the table weights, weight scale or None) in the current arithmetic."""
+        if MLP_ARITH not in self._wq:
+            if MLP_ARITH == "split16":
+                sc = f16_scale(self.tab_w)
+                self._wq[MLP_ARITH] = (pack_linear(self.tab_w, self.dp, arith="f16x2", scale=sc), sc)
+            else:
+                self._wq[MLP_ARITH] = (pack_linear(self.tab_w, self.dp), None)
+        return self._wq[MLP_ARITH]
+
+    def tables(self, p):
+        """[points, slots * 256] from the per-point vectors p [points, dp] (float32, device)."""
+        wq, sc = self.table_stream()
+        return ops.linear_split(p, wq, None, self.slots * 256, scale=sc)
+
+
 def _fused_plan(seq):
     """Per-layer (W1^T, b1', W0^T | None, b0', W2^T) with the pending-offset algebra of fused_stack applied once; cached
     on the module and rebuilt when any parameter changed (version counters) or moved."""
@@ -151,7 +195,7 @@ def _entry_cache(entry):
     return entry[5]
 
 
-def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0, stamp=None):
+def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0, stamp=None, add=None):
     """(weight stream, first biases of the launch's layers, skip bias, weight scale) of one launch in the current arithmetic,
     cached per launch shape: bf16 triples (scale 1) or fp16 pairs of scale x the weights with the biases scaled alike.
     stamp: weight versions of a SECOND stack the launch runs into (cross-stack launches); it is stored inside the slot and the
@@ -159,6 +203,9 @@ def _packed(cache, key, w1t, w0t, w2t, k_in, rest, b1, b0, stamp=None):
     key = key + (MLP_ARITH,)
     hit = cache.get(key)
     if hit is None or hit[0] != stamp:
+        if add is not None:                      # constant terms folded into the first layer's biases (_FoldedFirstLayer)
+            b1 = b1 if add[0] is None else b1 + add[0]
+            b0 = b0 if add[1] is None else b0 + add[1]
         chain = [(e[0].t(), e[4].t()) for e in rest]
         biases = torch.cat([b1] + [e[1] for e in rest])
         if MLP_ARITH == "split16":
@@ -232,12 +279,21 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         return chain_
     li = 0
     if gather is not None:
-        heads, gidx, table = gather
+        # gather = (heads, gidx, table): x-tile gather of [heads | table[gidx_0] | ...]; gather = (heads, gidx, tables, fold): the
+        # per-point parts of the first products come from slot tables (fold: _FoldedFirstLayer) and are summed into the accumulators
+        fold = gather[3] if len(gather) > 3 else None
+        heads, gidx, table = gather[:3]
         entry = plan[0]
         w1t, b1, w0t, b0, w2t = entry[:5]
-        k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
-        assert _kernel_arith() and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
+        if fold is not None:
+            k_in = heads.shape[1]
+            assert _kernel_arith() and w0t is not None and w1t.shape[1] == 128 and k_in % 8 == 0, "table-fed first layer: see sum_supported"
+            w1t, w0t = fold.w1_heads.t(), fold.w0_heads.t()
+        else:
+            k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
+            assert _kernel_arith() and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
         cache = _entry_cache(entry)
+
         def gather_chain():
             n = 0
             while (1 + n < len(plan) and plan[1 + n][2] is None and n < 15 and plan[1 + n][0].shape == (128, 128)):
@@ -246,9 +302,13 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
             return 0 if tap_at == 0 else n      # (the gathering launch has no second output)
         chain = _chain_len(cache, ("gather-chain", k_in, tap_at), cross, gather_chain)
         crossing = tap_at is not None and chain > tap_at
-        wq, bb1, bb0, sc = _packed(cache, (k_in, chain, crossing), w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0,
-                                   stamp=cross if crossing else None)
-        if MLP_ARITH == "split16":
+        stamp = (cross if crossing else None, None if fold is None else fold.stamp)
+        wq, bb1, bb0, sc = _packed(cache, (k_in, chain, crossing, fold is not None), w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0,
+                                   stamp=stamp, add=None if fold is None else (fold.b1_add, fold.b0_add))
+        if fold is not None:
+            x = ops.reslayer_split_sumgather(heads, gidx, table, wq, bb1, bb0, 128, chain=chain,
+                                             scale=sc if MLP_ARITH == "split16" else None)
+        elif MLP_ARITH == "split16":
             x = ops.reslayer_split16(heads, wq, bb1, bb0, 128, sc, chain=chain, gather=(gidx, table))
         else:
             x = ops.reslayer_split_gather(heads, gidx, table, wq, bb1, bb0, 128, chain=chain)
@@ -362,6 +422,37 @@ def decode_supported(seq, x):
             and last.fc1.out_features == 192 and last.fc1.in_features % 8 == 0 and c is None)
 
 
+def _scale_head_rows(model, feat, rows, scatter=None):
+    """model.scale_head(feat[rows]) without materialising feat[rows]: the scale head's first layer (a 128-wide projection
+    layer) reads the selected rows of `feat` through the gathering x-tile fetch of cppf_reslayer_split_gather (a table
+    gather with no pair-feature block).  rows: int32 (or int64) [n] tuple rows.
+    scatter = (counts int32 [n / per_group], per_group, out [T, 3]): the result rows are written to out[rows[i]] by the
+    head's last kernel (padded entries of each group skipped) and `out` is returned -- no index_put, no torch kernel."""
+    first = model.scale_encoder[0]
+    f = feat.shape[1]
+    if not (_kernel_arith() and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
+            and first.fc0 is not None and first.fc1.out_features == 128 and first.fc1.in_features == f
+            and f >= 8 and f & (f - 1) == 0 and feat.shape[0] < 2 ** 31):
+        vals = model.scale_head(feat[rows.long()])
+        if scatter is None:
+            return vals
+        counts, per_group, out = scatter
+        keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
+        out[rows.long()[keep]] = vals[keep]
+        return out
+    gidx = (rows if rows.dtype == torch.int32 else rows.to(torch.int32)).reshape(-1, 1)
+    tail = None
+    if scatter is not None and tail_supported(model.scale_encoder):
+        tail = (gidx.reshape(-1), scatter[0], scatter[1], scatter[2])
+    vals = fused_stack(model.scale_encoder, None, gather=(feat[:, :0], gidx, feat), tail=tail)
+    if scatter is not None and tail is None:
+        counts, per_group, out = scatter
+        keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
+        out[rows.long()[keep]] = vals[keep]
+        return out
+    return vals
+
+
 class _EncodeShot(torch.autograd.Function):
     """HIP tuple encode with a backward for the per-point feature table (the only differentiable input:
     points and normals are data).  d feat[n] = sum over (tuple, slot) with idx == n of d out[:, slot block]."""
@@ -427,11 +518,38 @@ class BeyondCPPFShot(nn.Module):
                 and feat_dim >= 8 and feat_dim & (feat_dim - 1) == 0 and (k * (k - 1) // 2 * 4) % 8 == 0 and k <= 8
                 and first.fc1.in_features == k * (k - 1) // 2 * 4 + k * feat_dim)
 
-    def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False, decode=None):
+    def sum_supported(self, feat_dim, k):
+        """True when heads_from_tuples(sum_tables=True) can feed the tuple encoder from per-point slot tables."""
+        first = self.tuple_encoder[0]
+        head = k * (k - 1) // 2 * 4
+        return (_kernel_arith() and not torch.is_grad_enabled() and first.fc0 is not None and first.fc1.out_features == 128
+                and feat_dim % 8 == 0 and head % 8 == 0 and k <= 8 and first.fc1.in_features == head + k * feat_dim)
+
+    def first_layer_fold(self, feat_dim, k):
+        """_FoldedFirstLayer of tuple_encoder[0] for rows [pair features | feat[idx_0] | ... | feat[idx_{k-1}]]
+        (train_shot.py:75-83): slot i's table weights are the columns of fc1 / fc0 that multiply feat[idx_i] (no product to
+        fold: the same multiplications as the row form, summed per slot first)."""
+        first = self.tuple_encoder[0]
+        stamp = tuple((q.data_ptr(), q._version) for q in first.parameters()) + (feat_dim, k)
+        cached = getattr(self, "_fold_cache", None)
+        if cached is None or cached.stamp != stamp:
+            head = k * (k - 1) // 2 * 4
+            w1, w0 = first.fc1.weight.detach(), first.fc0.weight.detach()
+            cached = _FoldedFirstLayer(stamp, [w1[:, head + i * feat_dim: head + (i + 1) * feat_dim] for i in range(k)],
+                                       [w0[:, head + i * feat_dim: head + (i + 1) * feat_dim] for i in range(k)],
+                                       w1[:, :head], w0[:, :head])
+            self._fold_cache = cached
+        return cached
+
+    def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False, decode=None,
+                          sum_tables=False):
         """heads(prepare_tuple_inputs(...)) with the [T, 360] tuple rows never written: the pair features (40 columns) and the
         tuples' global point indices go to the first ResLayer's kernel, which reads the per-point descriptors `feat` itself
         (same values, same arithmetic, bit-identical logits).  Falls back to the materialised rows when the first layer has
         no gathering kernel (other widths, training, native arithmetic).
+        sum_tables=True: the descriptor columns' products with the first layer's weights are evaluated once per point and slot
+        (first_layer_fold) and summed into the kernel's accumulators: the same multiplications in another order (float32-level
+        differences against the row form), 20 of the first product's 23 K steps fewer per tuple.
         decode = (uniforms [T, 6], prior [T, 6, 32] | None, bins int32 [T, 6]): the bins of eval.py:225-229 are drawn by the
         logit head's output layer into `bins` (e.g. VotingPipeline.bins) and None is returned in place of the logits -- only when
         decode_supported(); otherwise the logits are returned as usual and the caller decodes them."""
@@ -440,8 +558,13 @@ class BeyondCPPFShot(nn.Module):
             return self.heads(ops.encode_tuples_shot(points, idx, feat, normal, pt_off, tup_off), lazy_scale=lazy_scale)
         heads, gidx = ops.encode_tuples_shot_heads(points, idx, normal, pt_off, tup_off)
         draw = decode if (decode is not None and decode_supported(self.logit_encoder, feat)) else None
-        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=(heads, gidx, feat.contiguous()),
-                                      decode=draw)
+        if sum_tables and self.sum_supported(feat.shape[1], idx.shape[1]):
+            # the descriptor columns' share of the first products, once per point and slot instead of once per tuple
+            fold = self.first_layer_fold(feat.shape[1], idx.shape[1])
+            src = (heads, gidx, fold.tables(feat.contiguous()), fold)
+        else:
+            src = (heads, gidx, feat.contiguous())
+        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=src, decode=draw)
         second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
         if draw is not None:
             return None, second
@@ -454,34 +577,8 @@ class BeyondCPPFShot(nn.Module):
         return self.scale_encoder(feat_rows)
 
     def scale_head_rows(self, feat, rows, scatter=None):
-        """scale_head(feat[rows]) without materialising feat[rows]: the scale head's first layer (a 128-wide projection
-        layer) reads the selected rows of `feat` through the gathering x-tile fetch of cppf_reslayer_split_gather (a table
-        gather with no pair-feature block).  rows: int32 (or int64) [n] tuple rows.
-        scatter = (counts int32 [n / per_group], per_group, out [T, 3]): the result rows are written to out[rows[i]] by the
-        head's last kernel (padded entries of each group skipped) and `out` is returned -- no index_put, no torch kernel."""
-        first = self.scale_encoder[0]
-        f = feat.shape[1]
-        if not (_kernel_arith() and not torch.is_grad_enabled() and feat.is_cuda and feat.is_contiguous()
-                and first.fc0 is not None and first.fc1.out_features == 128 and first.fc1.in_features == f
-                and f >= 8 and f & (f - 1) == 0 and feat.shape[0] < 2 ** 31):
-            vals = self.scale_head(feat[rows.long()])
-            if scatter is None:
-                return vals
-            counts, per_group, out = scatter
-            keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
-            out[rows.long()[keep]] = vals[keep]
-            return out
-        gidx = (rows if rows.dtype == torch.int32 else rows.to(torch.int32)).reshape(-1, 1)
-        tail = None
-        if scatter is not None and tail_supported(self.scale_encoder):
-            tail = (gidx.reshape(-1), scatter[0], scatter[1], scatter[2])
-        vals = fused_stack(self.scale_encoder, None, gather=(feat[:, :0], gidx, feat), tail=tail)
-        if scatter is not None and tail is None:
-            counts, per_group, out = scatter
-            keep = (torch.arange(rows.numel(), device=rows.device) % per_group) < counts.repeat_interleave(per_group)
-            out[rows.long()[keep]] = vals[keep]
-            return out
-        return vals
+        """scale_head(feat[rows]) on the kept pairs only: see _scale_head_rows."""
+        return _scale_head_rows(self, feat, rows, scatter)
 
     def encode_points(self, shot_feat):
         """shot_encoder over the per-point descriptors (train_shot.py:118)."""
@@ -535,21 +632,109 @@ class BeyondCPPFDino(nn.Module):
         coord = ops.encode_tuples_coord(points, idx)
         return torch.cat([coord, desc_part], -1)
 
-    def heads(self, inputs, decode=None):
+    def heads(self, inputs, decode=None, lazy_scale=False):
         """(preds_cls [T,6,32], preds_scale [T,3]) from the tuple inputs (train_dino.py:130-132); inference on the GPU
         runs the stacks as matrix-core kernels (fused_stack), like the SHOT model.  decode: see
-        BeyondCPPFShot.heads_from_tuples (None is returned in place of the logits when the bins were drawn)."""
+        BeyondCPPFShot.heads_from_tuples (None is returned in place of the logits when the bins were drawn);
+        lazy_scale=True returns the tuple features in place of the scale head's output (see BeyondCPPFShot.heads)."""
         if not torch.is_grad_enabled() and inputs.is_cuda:
             draw = decode if (decode is not None and decode_supported(self.logit_encoder, inputs)) else None
             preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), inputs, decode=draw)
-            preds_scale = fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
+            second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)      # first layer projects: feat is left intact
             if draw is not None:
-                return None, preds_scale
-            return preds_cls.reshape(feat.shape[0], 6, -1), preds_scale
+                return None, second
+            return preds_cls.reshape(feat.shape[0], 6, -1), second
         feat = self.tuple_encoder(inputs)
         preds_scale = self.scale_encoder(feat)
         preds_cls = self.logit_encoder(feat).reshape(feat.shape[0], 6, -1)
         return preds_cls, preds_scale
+
+    def sum_supported(self, k):
+        """True when heads_from_tuples can run: every Linear of prepare_tuple_inputs on the library's matrix-core kernels and the
+        tuple rows never formed (split arithmetic, inference, the reference's layer widths)."""
+        first = self.tuple_encoder[0]
+        d = self.desc_transform.out_features
+        return (_kernel_arith() and not torch.is_grad_enabled() and first.fc0 is not None and first.fc1.out_features == 128
+                and d == 256 and self.desc_transform.in_features % 8 == 0 and k <= 8
+                and self.desc_pair_transform.in_features == k * d and self.desc_pair_transform.out_features == d
+                and first.fc1.in_features == k * (k - 1) // 2 * 3 + d)
+
+    def first_layer_fold(self, k):
+        """_FoldedFirstLayer of tuple_encoder[0] for rows [coords | desc_pair_transform(cat_i q[idx_i])], q = desc_transform(desc)
+        (train_dino.py:91-97): the Linear over the concatenation is a sum of k per-point products W_i q[idx_i] (W = [W_0 | ... ]),
+        and the first ResLayer's fc1 / fc0 are linear too, so slot i's table weights are fc1[:, desc columns] W_i and
+        fc0[:, desc columns] W_i (folded in float64, rounded to float32 once), desc_pair_transform's bias goes through the same
+        columns into the layer's biases, and the layer's own products keep the 30 coordinate columns only."""
+        first = self.tuple_encoder[0]
+        params = list(first.parameters()) + list(self.desc_pair_transform.parameters())
+        stamp = tuple((q.data_ptr(), q._version) for q in params) + (k,)
+        cached = getattr(self, "_fold_cache", None)
+        if cached is None or cached.stamp != stamp:
+            nc, d = self.ncoord, self.desc_transform.out_features
+            w1, w0 = first.fc1.weight.detach().double(), first.fc0.weight.detach().double()
+            wp, bp = self.desc_pair_transform.weight.detach().double(), self.desc_pair_transform.bias.detach().double()
+            cached = _FoldedFirstLayer(stamp, [w1[:, nc:] @ wp[:, i * d:(i + 1) * d] for i in range(k)],
+                                       [w0[:, nc:] @ wp[:, i * d:(i + 1) * d] for i in range(k)], w1[:, :nc], w0[:, :nc],
+                                       b1_add=(w1[:, nc:] @ bp).float(), b0_add=(w0[:, nc:] @ bp).float())
+            self._fold_cache = cached
+        return cached
+
+    def transform_points(self, point_descs):
+        """desc_transform over the per-point descriptors (train_dino.py:95; applied per point, before the gather) on the library's
+        matrix-core Linear kernel: [N, 1024] -> [N, 256]."""
+        lin = self.desc_transform
+        stamp = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version, MLP_ARITH)
+        cached = getattr(self, "_desc_cache", None)
+        if cached is None or cached[0] != stamp:
+            if MLP_ARITH == "split16":
+                sc = f16_scale(lin.weight)
+                cached = (stamp, pack_linear(lin.weight, lin.in_features, arith="f16x2", scale=sc), (lin.bias.detach() * sc).contiguous(), sc)
+            else:
+                cached = (stamp, pack_linear(lin.weight, lin.in_features), lin.bias.detach().contiguous(), None)
+            self._desc_cache = cached
+        return ops.linear_split(point_descs, cached[1], cached[2], lin.out_features, scale=cached[3])
+
+    def point_tables(self, point_descs, k):
+        """Per-point slot tables [N, k * 256] of the folded first layer from the raw descriptors [N, 1024]: two library launches
+        per batch (desc_transform, then the k folded slot products), no BLAS call, no [N, k, 256] stack copy."""
+        return self.first_layer_fold(k).tables(self.transform_points(point_descs.contiguous()))
+
+    def heads_from_tuples(self, points, point_descs, point_idxs_all, pt_off=None, tup_off=None, lazy_scale=False, decode=None,
+                          tables=None):
+        """heads(prepare_tuple_inputs(...)) with the [T, 286] tuple rows never written and every layer a kernel of the library:
+        coordinate columns + global point indices (ops.encode_tuples_coord_heads), per-point slot tables (point_tables; pass
+        `tables` to reuse them), and the first ResLayer summing its tuple's table rows into its accumulators
+        (ops.reslayer_split_sumgather).  point_idxs_all are scene-local with pt_off / tup_off given (batches), global otherwise.
+        lazy_scale / decode as BeyondCPPFShot.heads_from_tuples.  Falls back to heads(prepare_tuple_inputs(...)) when the
+        kernels do not cover the configuration (training, native arithmetic, other widths)."""
+        idx = point_idxs_all.to(torch.int32)
+        k = idx.shape[1]
+        if not (points.is_cuda and self.sum_supported(k)):
+            if pt_off is not None:
+                base = torch.repeat_interleave(pt_off[:-1], (tup_off[1:] - tup_off[:-1]).long()).to(torch.int32)
+                idx = idx + base[:, None]
+            return self.heads(self.prepare_tuple_inputs(points, point_descs, idx), decode=decode, lazy_scale=lazy_scale)
+        fold = self.first_layer_fold(k)
+        if tables is None:
+            tables = fold.tables(self.transform_points(point_descs.contiguous()))
+        heads, gidx = ops.encode_tuples_coord_heads(points, idx, pt_off, tup_off)
+        draw = decode if (decode is not None and decode_supported(self.logit_encoder, heads)) else None
+        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=(heads, gidx, tables, fold), decode=draw)
+        second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
+        if draw is not None:
+            return None, second
+        return preds_cls.reshape(feat.shape[0], 6, -1), second
+
+    def scale_head(self, feat_rows):
+        """scale_encoder on a subset of tuple features (rows of the `feat` heads(lazy_scale=True) returned)."""
+        if not torch.is_grad_enabled() and feat_rows.is_cuda:
+            return fused_stack(self.scale_encoder, feat_rows)
+        return self.scale_encoder(feat_rows)
+
+    def scale_head_rows(self, feat, rows, scatter=None):
+        """scale_head(feat[rows]) on the kept pairs only (eval.py:272 reads nothing else; it is THIS model's scale that the
+        reference keeps, eval.py:308-310): see _scale_head_rows."""
+        return _scale_head_rows(self, feat, rows, scatter)
 
     def forward(self, points, point_descs, point_idxs_all):
         return self.heads(self.prepare_tuple_inputs(points, point_descs, point_idxs_all))

@@ -442,6 +442,89 @@ def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
     return out
 
 
+def linear_split_supported(k_in, n_out):
+    """True when cppf_linear_split evaluates an nn.Linear of these dims (input columns a multiple of 8, outputs of 256)."""
+    return k_in % 8 == 0 and _L.cppf_linear_split_stream_bytes(int(k_in), int(n_out)) > 0
+
+
+def linear_split(x, wq, bias, n_out, out=None, scale=None):
+    """out = x W^T + bias, a plain nn.Linear on the matrix cores in float32-equivalent split arithmetic (cppf_linear_split; the
+    per-point transforms of the DINO model, train_dino.py:86-87).  x float32 [rows, k_in] (device; row stride a multiple of 4),
+    wq = models.pack_linear(W, k_in), bias float32 [n_out] or None, n_out a multiple of 256.
+    scale: f16x2 arithmetic (cppf_reslayer_split16, mode 1) with wq / bias packed at that weight scale."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, k_in = x.shape
+    if out is None:
+        out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape == (rows, n_out) and out.stride(1) == 1
+    bias = None if bias is None else bias.contiguous()
+    if scale is not None:
+        from ._lib import ReslayerSplit16Args
+        a = ReslayerSplit16Args()
+        a.x, a.ldx, a.k_in = x.data_ptr(), x.stride(0), k_in
+        a.out, a.ldo, a.n_out, a.rows = out.data_ptr(), out.stride(0), int(n_out), int(rows)
+        a.wq, a.wq_bytes = wq.data_ptr(), wq.numel() * wq.element_size()
+        a.b1 = None if bias is None else bias.data_ptr()
+        a.weight_scale, a.mode = float(scale), 1
+        a.stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_L.cppf_reslayer_split16(C.byref(a)), "cppf_reslayer_split16(linear)")
+        return out
+    _lib.check(_L.cppf_linear_split(_p(x), x.stride(0), k_in, _p(out), out.stride(0), int(n_out), rows, _p(wq),
+                                    wq.numel() * wq.element_size(), _p(bias), _stream()), "cppf_linear_split")
+    return out
+
+
+def encode_tuples_coord_heads(points, point_idxs_all, pt_off=None, tup_off=None):
+    """The coordinate block of the DINO model's prepare_tuple_inputs (train_dino.py:92: encode_tuples_coord's columns, bit for
+    bit) zero-padded to a multiple of 8 columns, and the tuples' global point indices: (heads float32 [T, round8(3 C(k,2))],
+    gidx int32 [T, k]) -- the inputs of reslayer_split_sumgather."""
+    dev = _dev()
+    pts = _t(points, torch.float32, dev)
+    idx = _t(point_idxs_all, torch.int32, dev)
+    T, k = idx.shape
+    B = 1 if pt_off is None else pt_off.numel() - 1
+    if pt_off is None:
+        pt_off, tup_off = _offsets([pts.shape[0]], dev), _offsets([T], dev)
+    ncol = (k * (k - 1) // 2 * 3 + 7) // 8 * 8
+    heads = torch.empty((T, ncol), dtype=torch.float32, device=dev)
+    gidx = torch.empty((T, k), dtype=torch.int32, device=dev)
+    _lib.check(_L.cppf_encode_tuples_coord_heads(B, _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T, _p(heads), ncol, _p(gidx),
+                                                 _stream()), "cppf_encode_tuples_coord_heads")
+    return heads, gidx
+
+
+def reslayer_split_sumgather(heads, gidx, tables, wq, b1, b0, n_out, chain=0, scale=None):
+    """The first ResLayer of a tuple encoder (+ `chain` identity layers) on rows [heads | s] whose per-point part s enters through
+    per-point slot tables (cppf_reslayer_split_sumgather): tables float32 [points, slots * 256] = [W1_i p | W0_i p] per point and
+    slot, summed into the accumulators in slot order; only the head columns go through the first product.  Returns [T, n_out].
+    scale: f16x2 arithmetic (cppf_reslayer_split16, mode 2)."""
+    assert heads.is_cuda and heads.dtype == torch.float32 and heads.dim() == 2 and heads.stride(1) == 1
+    assert gidx.dtype == torch.int32 and gidx.is_contiguous() and tables.dtype == torch.float32 and tables.stride(1) == 1
+    rows, slots = gidx.shape
+    assert tables.shape[1] == slots * 256
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=heads.device)
+    b1 = b1.contiguous()
+    b0 = b0.contiguous()
+    assert b1.numel() == (1 + chain) * n_out
+    if scale is not None:
+        from ._lib import ReslayerSplit16Args
+        a = ReslayerSplit16Args()
+        a.x, a.ldx, a.k_in = heads.data_ptr(), heads.stride(0), heads.shape[1]
+        a.out, a.ldo, a.n_out, a.rows, a.chain = out.data_ptr(), out.stride(0), int(n_out), int(rows), int(chain)
+        a.wq, a.wq_bytes = wq.data_ptr(), wq.numel() * wq.element_size()
+        a.b1, a.b0 = b1.data_ptr(), b0.data_ptr()
+        a.gidx, a.slots, a.table, a.ld_table = gidx.data_ptr(), int(slots), tables.data_ptr(), tables.stride(0)
+        a.weight_scale, a.mode = float(scale), 2
+        a.stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_L.cppf_reslayer_split16(C.byref(a)), "cppf_reslayer_split16(sumgather)")
+        return out
+    _lib.check(_L.cppf_reslayer_split_sumgather(_p(heads), heads.stride(0), heads.shape[1], _p(gidx), slots, _p(tables),
+                                                tables.stride(0), _p(out), out.stride(0), n_out, rows, _p(wq),
+                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+               "cppf_reslayer_split_sumgather")
+    return out
+
+
 def encode_tuples_coord(points, point_idxs_all, out=None, pt_off=None, tup_off=None):
     """Coordinate part of the DINO model's prepare_tuple_inputs (train_dino.py:92): [T, C(k,2)*3]
     (written into the leading columns of `out` if given)."""

@@ -84,7 +84,14 @@ class VotingPipeline:
         self.counts = e((2, B, self.S), dtype=torch.float32, device=d)
         self.top_idx = e((2, B), dtype=torch.int32, device=d)
         self.top_cnt = e((2, B), dtype=torch.float32, device=d)
-        self.results = e((B, 160), dtype=torch.uint8, device=d)
+        # result records: two slots (one per model of the ensemble, eval.py:219) + the selected ones; `results` is the slot the
+        # stages currently write (slot 0 unless use_slot() says otherwise)
+        self.result_slots = e((2, B, 160), dtype=torch.uint8, device=d)
+        self.results = self.result_slots[0]
+        self._slot = 0
+        self.selected = e((B, 160), dtype=torch.uint8, device=d)
+        self.losses = e((2, B), dtype=torch.float64, device=d)
+        self.best = e((B,), dtype=torch.float64, device=d)
         self.ws_vote_bytes = _L.cppf_vote_center_workspace_bytes(B, self.cells_cap, self.Ttot)
         self.ws_bv_bytes = _L.cppf_backvote_workspace_bytes(self.Ntot, B)
         self.ws_rot_bytes = _L.cppf_rot_bins_workspace_bytes(B, self.S, self.max_kept, self.R, self.bmm)
@@ -192,27 +199,33 @@ class VotingPipeline:
         return (r64[:, 1:4], r64[:, 4:13].reshape(self.B, 3, 3), self.results[:, 104:116].view(torch.float32),
                 self.results[:, 140:144].view(torch.int32).reshape(self.B))
 
-    def alignment_loss(self, pts, idx, scale_norm, y_only):
-        """eval.py:358-363 for every scene, on the device (no host round trip): mean over the kept pairs of the clipped
-        L1 distance between their canonicalised points, (pc - T_est) @ R_est / pred_scale_norm in float64, and the
-        decoded (un-scaled) coordinates bins / 31 - 0.5; the y coordinate only for the up-symmetric categories.
-        scale_norm: float64 [B] (the DINO pass' scale norm, eval.py:308-310).  Returns float64 [B] (NaN if nothing kept)."""
-        B, mk = self.B, self.max_kept
-        t, R, _, _ = self.pose_tensors()
-        rows = self.kept_rows().reshape(B, mk)                                          # global tuple rows, padded
-        valid = torch.arange(mk, device=self.dev)[None, :] < self.kept_count[:, None]
-        base = self.pt_off[:-1].long()
-        pi = idx[rows.reshape(-1)][:, :2].long().reshape(B, mk, 2) + base[:, None, None]
-        p = pts[pi.reshape(-1)].reshape(B, mk, 2, 3).double()
-        canon = torch.einsum("bmpi,bij->bmpj", p - t[:, None, None, :], R) / scale_norm.double()[:, None, None, None]
-        nb = float(self.nb - 1)
-        pred = (self.bins[rows.reshape(-1)].to(torch.float32) / nb - 0.5).reshape(B, mk, 2, 3)   # eval.py:230
-        loss = (canon - pred.double()).abs()
-        if y_only:
-            loss = loss[..., 1]
-        loss = loss.clamp(0.0, 0.1).reshape(B, mk, -1)
-        w = valid[:, :, None].to(torch.float64)
-        return (loss * w).sum((1, 2)) / (w.sum((1, 2)) * loss.shape[2])
+    def use_slot(self, model_idx):
+        """The record slot (0 = DINO pass, 1 = SHOT pass of the ensemble) that assemble() / refine() write from now on."""
+        self._slot = int(model_idx)
+        self.results = self.result_slots[self._slot]
+        return self.results
+
+    def alignment_loss(self, pts, idx, y_only, model_idx=None, scale_slot=0):
+        """eval.py:358-363 for every scene on the device (cppf_alignment_loss): mean over the kept pairs of the clipped L1
+        distance between their canonicalised points, (pc - T_est) @ R_est / pred_scale_norm in float64, and the decoded
+        (un-scaled) coordinates bins / 31 - 0.5; the y coordinate only for the up-symmetric categories.  The scale norm is
+        that of slot `scale_slot`'s records (the DINO pass' for both passes, eval.py:308-310).  Scores the records of the
+        current slot (or slot model_idx) into self.losses[slot]; returns that float64 [B] view (NaN if nothing was kept)."""
+        slot = self._slot if model_idx is None else int(model_idx)
+        _lib.check(_L.cppf_alignment_loss(self.B, ops._p(pts), ops._p(self.pt_off), ops._p(idx), self.k, ops._p(self.tup_off),
+                                          ops._p(self.bins), self.nb, ops._p(self.kept_tuple), ops._p(self.kept_count),
+                                          int(bool(y_only)), ops._p(self.result_slots[slot]), ops._p(self.result_slots[scale_slot]),
+                                          ops._p(self.losses[slot]), ops._stream()), "cppf_alignment_loss")
+        return self.losses[slot]
+
+    def select(self, enable0=True, enable1=True):
+        """eval.py:365-372 on the device (cppf_ensemble_select): self.selected[b] = the record of the model with the smaller
+        alignment loss (strict '<' against inf, the DINO pass first; enable0 = geo_branch, enable1 = visual_branch), carrying
+        the DINO pass' scale and the pick in pad_[0]; self.best = the winning losses."""
+        _lib.check(_L.cppf_ensemble_select(self.B, ops._p(self.result_slots[0]), ops._p(self.result_slots[1]),
+                                           ops._p(self.losses[0]), ops._p(self.losses[1]), int(bool(enable0)), int(bool(enable1)),
+                                           ops._p(self.selected), ops._p(self.best), ops._stream()), "cppf_ensemble_select")
+        return self.selected
 
     def assemble(self, pred_scales=None):
         _lib.check(_L.cppf_assemble_pose(self.B, ops._p(self.sphere), ops._p(self.top_idx[0]), ops._p(self.top_cnt[0]),
@@ -232,7 +245,9 @@ class VotingPipeline:
     def vote(self, pts, idx, logits, uniforms, pred_scales=None, grid=None, grid_off=None):
         """Everything after the MLP: eval.py:225-313.  All arguments are device tensors in the batch layout.
         Returns the device tensor of B result records (uint8 [B,160]); use results_to_numpy() to read them.
-        logits=None: the bins are already in self.bins (drawn by the MLP's output layer, ops.reslayer_split_decode)."""
+        logits=None: the bins are already in self.bins (drawn by the MLP's output layer, ops.reslayer_split_decode).
+        pred_scales: float32 [T, 3], or a callable evaluated after the back-vote filter that returns it -- the scale head is read
+        only for the kept pairs (eval.py:272), so a caller can run it on just those rows (kept_rows32 / kept_count / max_kept)."""
         if logits is None:
             self.decode_from_bins(pts, idx)
         else:
@@ -240,7 +255,7 @@ class VotingPipeline:
         self.vote_center(pts, idx, grid, grid_off)
         self.backvote(pts, idx)
         self.rot_bins(pts, idx)
-        self.assemble(pred_scales)
+        self.assemble(pred_scales() if callable(pred_scales) else pred_scales)
         return self.results
 
     def capture(self, pts, idx, logits, uniforms, pred_scales=None):

@@ -133,53 +133,56 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
         scale_prior = torch.from_numpy(np.asarray(scale_priors, dtype=np.float32)).to(dev).repeat_interleave(num_pairs, 0)
 
     feat_shot = shot_model.encode_points(shot_feat)
-    records, losses, kept = [], [], []
-    scale = scale_norm = None
+    kept = []
+    scales_buf = torch.zeros((pipe.Ttot, 3), dtype=torch.float32, device=dev)
     for model_idx in (0, 1):                                                               # eval.py:219
+        model = (dino_model, shot_model)[model_idx]
+        pipe.use_slot(model_idx)                     # each pass writes its own records; nothing is read back before the end
         u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
         # eval.py:225-229 (the bin draw) runs as the epilogue of the logit head's output layer when the kernels allow it (split
-        # arithmetic, no intermediates requested): the heads then return None in place of the logits
+        # arithmetic, no intermediates requested): the heads then return None in place of the logits.  The scale head is
+        # evaluated after the back-vote filter, on the kept pairs' rows only (eval.py:272 reads nothing else).
         draw = None if keep else (u, None if prior is None else prior.contiguous(), pipe.bins)
         if model_idx == 0:
-            # batched forward: indices are scene-local, tables are concatenated -> add the scene base
-            x = dino_model.prepare_tuple_inputs(pts, desc, idx + base[:, None].to(torch.int32))
-            pred_cls, pred_scales = dino_model.heads(x, decode=draw)
+            # train_dino.py:91-97, 128-133 without its rows: per-point slot tables + coordinate columns, summed by the first
+            # ResLayer's kernel; every layer is a kernel of the library
+            pred_cls, second = dino_model.heads_from_tuples(pts, desc, idx, pipe.pt_off, pipe.tup_off, lazy_scale=not keep, decode=draw)
         else:
             # train_shot.py:75-83 + :100-111; the tuple rows are gathered inside the first ResLayer's kernel
-            pred_cls, pred_scales = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off, decode=draw)
+            pred_cls, second = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off,
+                                                            lazy_scale=not keep, decode=draw)
         raw_cls = pred_cls
         if prior is not None and pred_cls is not None:
             pred_cls = pred_cls + prior
-        if scale_prior is not None:
-            pred_scales = scale_prior + 1e-3 * pred_scales
-        pipe.vote(pts, idx, None if pred_cls is None else pred_cls.contiguous(), u, pred_scales.contiguous())
+
+        def scales(model=model, second=second):
+            s_ = second if keep else model.scale_head_rows(second, pipe.kept_rows32(),
+                                                           scatter=(pipe.kept_count, pipe.max_kept, scales_buf))
+            return (scale_prior + 1e-3 * s_).contiguous() if scale_prior is not None else s_.contiguous()
+        pred_scales = scales() if keep else scales
+        pipe.vote(pts, idx, None if pred_cls is None else pred_cls.contiguous(), u, pred_scales)
         if opt:
             pipe.refine(pts, idx, up_sym)                                                  # eval.py:319-355
-        rec = pipe.results_to_numpy()                                                      # the 160-byte records
-        bad = np.nonzero(rec["flags"] & 6)[0]
-        if bad.size:
-            raise RuntimeError("instances %s were not voted (flags %s: grid above cells_cap / int32)" %
-                               (bad.tolist(), rec["flags"][bad].tolist()))
-        if model_idx == 0:                                                                 # eval.py:308-310
-            scale = rec["scale"].copy()                                                    # float32 [B,3]
-            scale_norm = np.array([np.linalg.norm(s_) for s_ in scale], dtype=np.float32)  # np.linalg.norm per instance
-            sn = torch.from_numpy(np.where(scale_norm > 0, scale_norm, 1).astype(np.float64)).to(dev)
-        losses.append(pipe.alignment_loss(pts, idx, sn, up_sym))                           # eval.py:358-363, on the device
-        records.append(rec)
+        pipe.alignment_loss(pts, idx, up_sym)                  # eval.py:358-363; the DINO pass' scale scores both passes
         if keep:
             kept.append(dict(bins=pipe.bins.cpu().numpy(), mask=pipe.mask.cpu().numpy().astype(bool),
                              pred_cls=pred_cls.cpu().numpy(), raw_cls=raw_cls.cpu().numpy(), pred_scales=pred_scales.cpu().numpy(), u=u.cpu().numpy(),
                              counts=pipe.counts.cpu().numpy()))
-    losses = torch.stack(losses).cpu().numpy()                                             # [2,B] float64
-    # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first ----------------------
-    pick = np.full((B,), -1, dtype=np.int64)
-    best = np.full((B,), np.inf)
-    for model_idx in (0, 1):
-        enabled = (geo_branch and model_idx == 0) or (visual_branch and model_idx == 1)
-        take = (losses[model_idx] < best) & enabled
-        best = np.where(take, losses[model_idx], best)
-        pick = np.where(take, model_idx, pick)
-    out = dict(records=records, losses=losses, pick=pick, best=best, scale=scale.astype(np.float64),
+    # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first -- on the device ---------
+    pipe.select(geo_branch, visual_branch)
+    records = [pipe.results_to_numpy(pipe.result_slots[m]) for m in (0, 1)]                # the 160-byte records: the first read
+    for rec in records:
+        bad = np.nonzero(rec["flags"] & 6)[0]
+        if bad.size:
+            raise RuntimeError("instances %s were not voted (flags %s: grid above cells_cap / int32)" %
+                               (bad.tolist(), rec["flags"][bad].tolist()))
+    chosen = pipe.results_to_numpy(pipe.selected)
+    losses = pipe.losses.cpu().numpy()                                                     # [2,B] float64
+    pick = chosen["pad_"][:, 0].astype(np.int64)
+    best = pipe.best.cpu().numpy()
+    scale = records[0]["scale"].copy()                                                     # eval.py:308-310: float32 [B,3]
+    scale_norm = np.array([np.linalg.norm(s_) for s_ in scale], dtype=np.float32)          # np.linalg.norm per instance
+    out = dict(records=records, selected=chosen, losses=losses, pick=pick, best=best, scale=scale.astype(np.float64),
                scale_norm=scale_norm.astype(np.float64), idx=idx, pipe=pipe, pts=pts)
     if keep:
         out["kept"] = kept

@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 7
+#define CPPF_ABI_VERSION 8
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -288,6 +288,20 @@ int cppf_refine_pose(int B, const float* pts, const int32_t* pt_off, const int32
                      const int32_t* kept_count, int y_only, int steps, float lr, CppfSceneResult* results,
                      void* stream);
 
+/* ---- the ensemble score and selection (eval.py:358-372; BASELINE configs[2]: both models vote every instance).
+ * cppf_alignment_loss: loss[b] (float64) = mean over the kept pairs' end points of clip(|(pc - t) @ R / scale_norm - pred|, 0,
+ *   0.1) (all three coordinates, or y only for the up-symmetric categories, eval.py:360-361), pred = bins / (nb - 1) - 0.5
+ *   (the un-scaled pair the model drew, eval.py:230), scale_norm = float32 norm of scale_src[b].scale (the DINO pass' record for
+ *   both passes, eval.py:308-310; 1 where it is 0); NaN when no pair was kept.  results = the pass' records (t, R).
+ * cppf_ensemble_select: out[b] = the record of the model with the smaller loss -- strict '<' against inf, model 0 (DINO)
+ *   first; enable0 = geo_branch, enable1 = visual_branch (eval.py:367) -- carrying model 0's scale and the pick (-1: none)
+ *   in pad_[0]; best[b] = its loss. */
+int cppf_alignment_loss(int B, const float* pts, const int32_t* pt_off, const int32_t* idx, int k, const int32_t* tup_off,
+                        const int32_t* bins, int nb, const int32_t* kept_tuple, const int32_t* kept_count, int y_only,
+                        const CppfSceneResult* results, const CppfSceneResult* scale_src, double* loss, void* stream);
+int cppf_ensemble_select(int B, const CppfSceneResult* rec0, const CppfSceneResult* rec1, const double* loss0,
+                         const double* loss1, int enable0, int enable1, CppfSceneResult* out, double* best, void* stream);
+
 /* ---- steps in front of the path ---------------------------------------------------------------
  * Back-projection of a masked depth map: replaces backproject() (utils/util.py:2586-2607) + the sign flip and
  * float32 cast at eval.py:185-189.  depth float32[H,W] in metres, mask uint8[H,W]; h_kinv = inverse intrinsics
@@ -373,6 +387,34 @@ int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t hea
                                const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
                                void* stream);
 
+/* ---- the DINO model's tuple encode without its rows, and every Linear of both models on the matrix cores (train_dino.py:86-97,
+ * 128-133; reference call site eval.py:221).
+ * cppf_linear_split: out[rows, n_out] = x[rows, :k_in] W^T + bias (bias may be NULL), a plain nn.Linear in the split arithmetic of
+ *   cppf_reslayer_split; n_out a multiple of 256, k_in a multiple of 8; wq = cppf_linear_split_stream_bytes(k_in, n_out) bytes
+ *   (cppf2_amd.models.pack_linear).  Replaces the library GEMMs of desc_transform (train_dino.py:86, 95) and of the per-slot
+ *   slices of desc_pair_transform (train_dino.py:87, 96).
+ * cppf_encode_tuples_coord_heads: heads float32 [T, ld_heads >= round8(3 C(k,2))] = the coordinate columns of
+ *   cppf_encode_tuples_coord's rows (train_dino.py:92), bit for bit, zero-padded to a multiple of 8 columns; gidx int32 [T, k] =
+ *   scene point base + idx.
+ * cppf_reslayer_split_sumgather: the tuple encoder's first ResLayer (128-wide projection layer, `chain` identity layers behind
+ *   it) on rows [heads | s(t)] where s(t) is linear in per-point vectors of the tuple's points (DINO: desc_pair_transform of the
+ *   concatenated desc_transform outputs, train_dino.py:95-96; SHOT: the concatenated point features, train_shot.py:82): the
+ *   per-point parts of x W1^T and x W0^T come from tables float32 [points, slots, 256] (= [W1_i p | W0_i p] per point p and slot
+ *   i; point pitch ld_tables floats) that cppf_linear_split wrote from host-folded weights, and are summed into the
+ *   accumulators in slot order; only the head columns run through the first product.  wq =
+ *   cppf_reslayer_split_stream_bytes(head_cols, 128, 1, chain) bytes; b1 / b0 include the folded transforms' bias terms.
+ *   Algebraically the reference's network; the [T, 286] / [T, 360] rows are never formed. */
+int64_t cppf_linear_split_stream_bytes(int32_t k_in, int32_t n_out);
+int cppf_linear_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
+                      const void* wq, int64_t wq_bytes, const float* bias, void* stream);
+int cppf_encode_tuples_coord_heads(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
+                                   const int32_t* tup_off, int64_t total_tuples, float* heads, int32_t ld_heads, int32_t* gidx,
+                                   void* stream);
+int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
+                                  const float* tables, int64_t ld_tables, float* out, int64_t ldo, int32_t n_out, int64_t rows,
+                                  const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
+                                  void* stream);
+
 /* ---- the bin draw fused into the MLP's output layer (eval.py:225-229 behind train_shot.py:62-66): the 192-wide projection
  * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]
  * (+ logit_prior[t, c, :])) at uniforms[t, c]  as its epilogue -- cppf_decode_bins' arithmetic bit for bit -- so that the
@@ -405,6 +447,10 @@ typedef struct CppfReslayerSplit16Args {
   const int32_t* gidx; int32_t slots; const float* table; int32_t fdim;
   const float* logit_prior; const float* uniforms; int32_t* bins;
   void* stream;
+  int32_t mode;            /* 0: the forms above; 1: plain Linear (cppf_linear_split: n_out % 256 == 0, b1 = bias or NULL, b0 NULL);
+                              2: gather with per-point slot tables summed into the accumulators (cppf_reslayer_split_sumgather:
+                              table = [points, slots, 256], ld_table its point pitch, fdim unused) */
+  int64_t ld_table;
 } CppfReslayerSplit16Args;
 int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);
