@@ -414,7 +414,7 @@ def report_ensemble(args, step, dt, evs, world, backend):
         for b in range(n_cpu):
             sc = step.scenes[b]
             idx = O.sample_tuples(args.seed, step.scene0 + b, T, 5, N).astype(np.int64)
-            shot_feat, normal, _ = S.compute(sc["pc"], Cfg.res * 10, Cfg.res * 10)
+            shot_feat, normal, _, _ = S.compute_ex(sc["pc"], Cfg.res * 10, Cfg.res * 10, pcl_arithmetic=True)
             shot_feat, normal = np.nan_to_num(shot_feat, nan=0.0), np.nan_to_num(normal, nan=0.0)
             prior = synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6)
             desc = step.desc[b * N:(b + 1) * N].cpu().numpy()

@@ -60,13 +60,13 @@ SIGNATURES = {
     "cppf_sample_tuples": (_i, [_i, _p, _p, _i, _i, _u64, _i32, _i32, _p, _p]),
     "cppf_philox_uniform": (_i, [_i, _p, _i, _i, _u64, _i32, _i32, _i32, _p, _p]),
     "cppf_shot352_workspace_bytes": (_i64, [_i, _i64]),
-    "cppf_shot352": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i64, _p]),
+    "cppf_shot352": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i64, _i, _p]),
     "cppf_shot352_from_normals": (_i, [_i, _p, _p, _i64, _p, _f, _p, _p, _p, _i64, _p]),
     "cppf_shot1344_workspace_bytes": (_i64, [_i, _i64]),
-    "cppf_shot1344": (_i, [_i, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _i64, _p]),
-    "cppf_shot_prepare": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _i64, _p]),
+    "cppf_shot1344": (_i, [_i, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _i64, _i, _p]),
+    "cppf_shot_prepare": (_i, [_i, _p, _p, _i64, _f, _f, _p, _p, _i64, _i, _p]),
     "cppf_shot_describe": (_i, [_i, _p, _p, _i64, _p, _f, _i, _p, _p, _p, _i64, _p]),
-    "cppf_estimate_normals": (_i, [_i, _p, _p, _i64, _f, _p, _p, _i64, _p]),
+    "cppf_estimate_normals": (_i, [_i, _p, _p, _i64, _f, _p, _p, _i64, _i, _p]),
     "cppf_encode_tuples_shot": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
     "cppf_encode_tuples_shot_f16": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _p, _p]),
     "cppf_encode_tuples_coord": (_i, [_i, _p, _p, _i, _p, _p, _i64, _p, _i, _p]),

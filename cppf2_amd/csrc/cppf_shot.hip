@@ -376,12 +376,13 @@ __device__ __forceinline__ void query_runs(const CellHdr& h, const int32_t* __re
 // shot_cov: float64 sums for the normal covariance (radius rn) and the LRF covariance (radius rs)
 // ---------------------------------------------------------------------------------------------
 // One pass over a neighbour (shared by the compacted-list and the direct-scan forms of shot_cov)
+template <bool NORMAL_SUMS = true>
 __device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float py, float pz, float rn2, float rs2,
                                                float rs, double a[NSUM]) {
   const float qx = qv.x, qy = qv.y, qz = qv.z;
   const float d2 = sqdist3(px, py, pz, qx, qy, qz);
   const double x = (double)(qx - px), y = (double)(qy - py), z = (double)(qz - pz);
-  if (d2 < rn2) {
+  if (NORMAL_SUMS && d2 < rn2) {
     a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
     a[6] += x; a[7] += y; a[8] += z; a[9] += 1.0;
   }
@@ -399,7 +400,111 @@ __device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float 
 // The candidates of the 9 runs are first compacted to the ones inside the larger radius (about a third of them), so
 // the float64 sums run over dense wavefronts; the compacted list (positions in the cell-sorted order, scan order) is
 // also left in the workspace for shot_hist, which needs the same neighbours.
-__global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __restrict__ pts,
+// The float32 sums of pcl::NormalEstimation (see shot_cov_kernel<PCL>) over the entries the lanes hold (EMAX per lane; ed >= rn2
+// marks an unused entry) in (distance, index) order: counting sort on 64 distance buckets, exact comparisons inside a bucket,
+// addends written to LDS in rank order (windows of PCL_WIN ranks), nine lanes add one column each sequentially.
+// s_raw: the wavefront's 5016-byte LDS buffer (free on entry; a barrier precedes the call).  Returns the j-th sum in lane j < 9.
+template <int EMAX>
+__device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn2, const float (&ex)[EMAX], const float (&ey)[EMAX],
+                                               const float (&ez)[EMAX], const float (&ed)[EMAX], const int (&ei)[EMAX],
+                                               float& pcl_sum, int& mn) {
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_raw);               // [64] bucket counts
+  uint32_t* s_start = s_hist + 64;                                     // [64] bucket starts
+  uint2* s_key = reinterpret_cast<uint2*>(s_start + 64);               // [<= 64 EMAX] (distance bits, index) by bucket
+  float* s_add = reinterpret_cast<float*>(s_raw);                      // [9][PCL_WIN] addends of a rank window, column-major
+  constexpr int PCL_WIN = 136;                                         // 9 x 136 x 4 = 4896 bytes of the 5016
+  static_assert(512 + 64 * EMAX * 8 <= NSUM * 33 * 8, "keys fit the buffer");
+  s_hist[lane] = 0;
+  __syncthreads();
+  const float bscale = 64.0f / rn2;
+  int eb[EMAX], ep[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    eb[e] = 0; ep[e] = 0;
+    if (ed[e] < rn2) {
+      eb[e] = min(63, (int)(ed[e] * bscale));
+      ep[e] = (int)atomicAdd(&s_hist[eb[e]], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t cnt = s_hist[lane];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    s_start[lane] = incl - cnt;
+    mn = (int)__shfl(incl, 63);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (ed[e] < rn2) s_key[s_start[eb[e]] + ep[e]] = make_uint2(__float_as_uint(ed[e]), (uint32_t)ei[e]);
+  __syncthreads();
+  int er[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    er[e] = -1;
+    if (ed[e] < rn2) {
+      const int s0 = (int)s_start[eb[e]], n_b = (int)s_hist[eb[e]];
+      const uint32_t kd = __float_as_uint(ed[e]), ki = (uint32_t)ei[e];
+      int r = s0;
+      for (int j = 0; j < n_b; ++j) {
+        const uint2 o = s_key[s0 + j];
+        r += (o.x < kd || (o.x == kd && o.y < ki)) ? 1 : 0;
+      }
+      er[e] = r;
+    }
+  }
+  __syncthreads();                               // the keys are dead: the buffer becomes the addend windows
+  for (int w0 = 0; w0 < mn; w0 += PCL_WIN) {
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+      const int r = er[e] - w0;
+      if (er[e] >= 0 && r >= 0 && r < PCL_WIN) {
+        const float x = ex[e], y = ey[e], z = ez[e];
+        s_add[0 * PCL_WIN + r] = x * x; s_add[1 * PCL_WIN + r] = x * y; s_add[2 * PCL_WIN + r] = x * z;
+        s_add[3 * PCL_WIN + r] = y * y; s_add[4 * PCL_WIN + r] = y * z; s_add[5 * PCL_WIN + r] = z * z;
+        s_add[6 * PCL_WIN + r] = x; s_add[7 * PCL_WIN + r] = y; s_add[8 * PCL_WIN + r] = z;
+      }
+    }
+    __syncthreads();
+    if (lane < 9) {
+      const int n_w = min(PCL_WIN, mn - w0);
+      const float* col = s_add + lane * PCL_WIN;
+      int r = 0;
+      for (; r + 8 <= n_w; r += 8) {             // eight addends requested at once, added one after the other
+        const float4 v0 = *reinterpret_cast<const float4*>(col + r), v1 = *reinterpret_cast<const float4*>(col + r + 4);
+        pcl_sum += v0.x; pcl_sum += v0.y; pcl_sum += v0.z; pcl_sum += v0.w;
+        pcl_sum += v1.x; pcl_sum += v1.y; pcl_sum += v1.z; pcl_sum += v1.w;
+      }
+      for (; r + 4 <= n_w; r += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(col + r);
+        pcl_sum += v.x; pcl_sum += v.y; pcl_sum += v.z; pcl_sum += v.w;
+      }
+      for (; r < n_w; ++r) pcl_sum += col[r];
+    }
+    __syncthreads();
+  }
+}
+
+// PCL (template): the normal's sums in pcl::NormalEstimation's arithmetic instead (src_shot/shot.cpp:25-32, 66-72 ->
+// computeMeanAndCovarianceMatrix of PCL 1.9.1): ONE pass of float32 sums of the RAW coordinates and their products over the
+// neighbours in the order a sorted radius search returns them, (distance, index) ascending -- float32 sums of numbers near 0.6 m^2
+// that cancel to a covariance of 1e-4 m^2 depend on that order at the 1e-3 level, so the order is part of the arithmetic
+// (oracle/shot_oracle.c: pcl_normal, mode 1).  The neighbours of the list are ranked by a counting sort on 64 distance buckets
+// (squared distances of surface points are uniform in [0, r^2): ~1.4 per bucket) with exact comparisons inside a bucket, their
+// nine addends are written to LDS in rank order, and nine lanes add one column each, sequentially.  sums[0..8] then hold those
+// float32 sums (as doubles), sums[9] the neighbour count.  This kernel ranks lists of up to 128 neighbours (two entries per lane:
+// its registers keep eight wavefronts per SIMD); a longer list keeps the float64 sums and marks sums[9] with + 0.5 for
+// shot_pcl_long_kernel, which redoes the marked queries from the workspace copy of the list (up to NBR_CAP = 512 neighbours: a
+// 2 mm voxel cloud has at most ~314 inside 2 cm; beyond that the float64 sums stay).
+#define PCL_EMAX_SHORT 2
+#define PCL_EMAX_LONG (NBR_CAP / 64)
+template <bool PCL>
+__global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
@@ -472,7 +577,23 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
     }
   }
   __syncthreads();
+  // PCL: this lane's list entries with d2 < rn2 (coordinates, squared distance, scene-local index), kept in registers
+  float ex[PCL_EMAX_SHORT], ey[PCL_EMAX_SHORT], ez[PCL_EMAX_SHORT], ed[PCL_EMAX_SHORT];
+  int ei[PCL_EMAX_SHORT];
+  const bool pcl_list = PCL && rn > 0.0f && m <= 64 * PCL_EMAX_SHORT;
   if (SHOT_DBG & 64) {
+  } else if (pcl_list) {
+#pragma unroll
+    for (int e = 0; e < PCL_EMAX_SHORT; ++e) {
+      const int c = lane + 64 * e;
+      ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
+      if (c < m) {
+        const float4 qv = s_nb[c];
+        cov_accumulate<false>(qv, px, py, pz, rn2, rs2, rs, a);
+        const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
+        if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
+      }
+    }
   } else if (m <= COV_LIST) {
     for (int c = lane; c < m; c += 64) cov_accumulate(s_nb[c], px, py, pz, rn2, rs2, rs, a);
   } else {
@@ -481,6 +602,9 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
       if (fb + lane < C) cov_accumulate(sp[cand(fb + lane)], px, py, pz, rn2, rs2, rs, a);
   }
   __syncthreads();                                 // the list is dead: its LDS becomes the reduction buffer
+  float pcl_sum = 0.0f;                            // lane j < 9: the j-th float32 sum; mn: neighbours inside rn
+  int mn = 0;
+  if (pcl_list) pcl_float_sums<PCL_EMAX_SHORT>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn);
   if (nbr_cnt && lane == 0) {
     nbr_cnt[qi] = m;
     if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
@@ -505,7 +629,59 @@ __global__ __launch_bounds__(64) void shot_cov_kernel(int B, const float* __rest
 #pragma unroll
     for (int i = 0; i < 11; ++i) t += (lo + i < hi) ? v[i] : 0.0;
     const double t1 = __shfl_down(t, 1), t2 = __shfl_down(t, 2);
-    if (lane < 3 * NSUM && part == 0) sums[(int64_t)qi * NSUM + c] = (t + t1) + t2;
+    // (PCL, list too long for LDS: the float64 sums about the query point stand in, the count is marked with + 0.5)
+    const double mark = (PCL && !pcl_list && rn > 0.0f && c == 9) ? 0.5 : 0.0;
+    if (lane < 3 * NSUM && part == 0 && !(pcl_list && c < 10)) sums[(int64_t)qi * NSUM + c] = ((t + t1) + t2) + mark;
+  }
+  if (pcl_list) {
+    if (lane < 9) sums[(int64_t)qi * NSUM + lane] = (double)pcl_sum;
+    if (lane == 9) sums[(int64_t)qi * NSUM + 9] = (double)mn;
+  }
+}
+
+// The queries shot_cov_kernel<true> marked (more than 128 neighbours): the same float32 sums from the workspace copy of the
+// neighbour list, eight entries per lane.  Every wavefront looks at 64 queries' marks at a time and redoes the marked ones, one
+// after the other (a launch of one workgroup per query cost 60 us just to find that most had nothing to do).
+__global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const float* __restrict__ pts, const int32_t* __restrict__ pt_off,
+                                                           const float4* __restrict__ sorted_pts,
+                                                           const int32_t* __restrict__ scene_of, float rn,
+                                                           const int32_t* __restrict__ nbr_list,
+                                                           const int32_t* __restrict__ nbr_cnt, double* __restrict__ sums) {
+  __shared__ __attribute__((aligned(16))) double s_raw[NSUM * (32 + 1)];
+  const int lane = threadIdx.x;
+  const float rn2 = rn * rn;
+  for (int64_t q0 = (int64_t)blockIdx.x * 64; q0 < total; q0 += (int64_t)gridDim.x * 64) {
+    bool todo = false;
+    if (q0 + lane < total) {
+      const double s9 = sums[(q0 + lane) * NSUM + 9];
+      todo = s9 != floor(s9) && nbr_cnt[q0 + lane] <= NBR_CAP;      // (longer than this kernel's capacity: the float64 sums stay)
+    }
+    unsigned long long mask = __ballot(todo);
+    while (mask) {
+      const int64_t qi = q0 + __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int m = nbr_cnt[qi];
+      const float4* sp = sorted_pts + (int64_t)pt_off[scene_of[qi]];
+      const float px = pts[3 * qi], py = pts[3 * qi + 1], pz = pts[3 * qi + 2];
+      float ex[PCL_EMAX_LONG], ey[PCL_EMAX_LONG], ez[PCL_EMAX_LONG], ed[PCL_EMAX_LONG];
+      int ei[PCL_EMAX_LONG];
+#pragma unroll
+      for (int e = 0; e < PCL_EMAX_LONG; ++e) {
+        const int c = lane + 64 * e;
+        ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
+        if (c < m) {
+          const float4 qv = sp[nbr_list[qi * NBR_CAP + c]];
+          const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
+          if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
+        }
+      }
+      float pcl_sum = 0.0f;
+      int mn = 0;
+      __syncthreads();
+      pcl_float_sums<PCL_EMAX_LONG>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn);
+      if (lane < 9) sums[qi * NSUM + lane] = (double)pcl_sum;
+      if (lane == 9) sums[qi * NSUM + 9] = (double)mn;
+    }
   }
 }
 
@@ -517,9 +693,89 @@ struct LrfPre {
   int32_t valid, nn;
 };
 
+// pcl::computeRoots2 / computeRoots / eigen33 (PCL 1.9.1 common/impl/eigen.hpp, Scalar = float), as oracle/shot_oracle.c restates
+// them: the eigenvector of the smallest eigenvalue of a symmetric float 3x3 in closed form (trigonometric roots of the
+// characteristic polynomial of the matrix scaled by its largest entry; the longest cross product of two rows of M - root I).
+__device__ __forceinline__ void pcl_roots2(float b, float c, float roots[3]) {
+  roots[0] = 0.0f;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) d = 0.0f;
+  const float sd = __builtin_sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+__device__ void pcl_roots(const float m[3][3], float roots[3]) {
+  const float c0 = m[0][0] * m[1][1] * m[2][2] + 2.0f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] -
+                   m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+  const float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] -
+                   m[1][2] * m[1][2];
+  const float c2 = m[0][0] + m[1][1] + m[2][2];
+  if (fabsf(c0) < 1.1920929e-07f) { pcl_roots2(c2, c1, roots); return; }
+  const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = __builtin_sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0f) q = 0.0f;
+  const float rho = __builtin_sqrtf(-a_over_3);
+  const float theta = atan2f(__builtin_sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+  roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  if (roots[0] >= roots[1]) { const float t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  if (roots[1] >= roots[2]) {
+    const float t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+    if (roots[0] >= roots[1]) { const float u = roots[0]; roots[0] = roots[1]; roots[1] = u; }
+  }
+  if (roots[0] <= 0.0f) pcl_roots2(c2, c1, roots);
+}
+
+__device__ void pcl_eigen33(const float cov[3][3], float vec[3]) {
+  float scale = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) scale = fmaxf(scale, fabsf(cov[i][j]));
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float m[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m[i][j] = cov[i][j] / scale;
+  float roots[3];
+  pcl_roots(m, roots);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) m[i][i] -= roots[0];
+  float v[3][3], len[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ra = (k == 2) ? 1 : 0, rb = (k == 0) ? 1 : 2;          // row pairs (0,1), (0,2), (1,2)
+    const float* a = m[ra];
+    const float* b = m[rb];
+    v[k][0] = a[1] * b[2] - a[2] * b[1];
+    v[k][1] = a[2] * b[0] - a[0] * b[2];
+    v[k][2] = a[0] * b[1] - a[1] * b[0];
+    len[k] = v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2];
+  }
+  int best = 2;
+  if (len[0] >= len[1] && len[0] >= len[2]) best = 0;
+  else if (len[1] >= len[0] && len[1] >= len[2]) best = 1;
+  const float bx = best == 0 ? v[0][0] : best == 1 ? v[1][0] : v[2][0];
+  const float by = best == 0 ? v[0][1] : best == 1 ? v[1][1] : v[2][1];
+  const float bz = best == 0 ? v[0][2] : best == 1 ? v[1][2] : v[2][2];
+  const float inv = __builtin_sqrtf(best == 0 ? len[0] : best == 1 ? len[1] : len[2]);
+  vec[0] = bx / inv; vec[1] = by / inv; vec[2] = bz / inv;
+}
+
+// pcl: the sums of a shot_cov_kernel<true> launch -- float32 sums of the raw coordinates in slots 0..8 (count in slot 9; a count
+// with a fractional part marks a query that kept the float64 sums): covariance = E[x x^T] - E[x] E[x]^T in float32, closed-form
+// eigenvector, float32 viewpoint flip (pcl::NormalEstimation + flipNormalTowardsViewpoint, PCL 1.9.1).
 __global__ __launch_bounds__(256) void shot_eig_kernel(int64_t total, const float* __restrict__ pts,
                                                        const double* __restrict__ sums, float* __restrict__ normals,
-                                                       LrfPre* __restrict__ pre) {
+                                                       LrfPre* __restrict__ pre, int pcl) {
   const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= total) return;
   const double* s = sums + qi * NSUM;
@@ -528,6 +784,24 @@ __global__ __launch_bounds__(256) void shot_eig_kernel(int64_t total, const floa
     const int cnt = (int)s[9];
     if (cnt < 3) {
       o[0] = o[1] = o[2] = NAN;
+    } else if (pcl && s[9] == (double)cnt) {
+      float accu[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) accu[c] = (float)s[c] / (float)cnt;
+      float cov[3][3];
+      cov[0][0] = accu[0] - accu[6] * accu[6];
+      cov[0][1] = accu[1] - accu[6] * accu[7];
+      cov[0][2] = accu[2] - accu[6] * accu[8];
+      cov[1][1] = accu[3] - accu[7] * accu[7];
+      cov[1][2] = accu[4] - accu[7] * accu[8];
+      cov[2][2] = accu[5] - accu[8] * accu[8];
+      cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+      float v[3];
+      pcl_eigen33(cov, v);
+      const float vx = 0.0f - pts[3 * qi], vy = 0.0f - pts[3 * qi + 1], vz = 0.0f - pts[3 * qi + 2];
+      const float ct = vx * v[0] + vy * v[1] + vz * v[2];
+      if (ct < 0.0f) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
     } else {
       const double inv = 1.0 / (double)cnt;
       const double mx = s[6] * inv, my = s[7] * inv, mz = s[8] * inv;
@@ -995,9 +1269,19 @@ extern "C" int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points) {
          up256(total_points * (int64_t)NBR_CAP * 4);
 }
 
+// CPPF_SHOT_F64_NORMALS (flags bit 0 of the entry points): the round-1..3 arithmetic for the normals -- float64 covariance about
+// the query point, Jacobi -- instead of pcl::NormalEstimation's (single-pass float32 sums of the raw coordinates in
+// (distance, index) order, closed-form eigen33, float32 viewpoint flip), which is the default since round 4.
+template <class... Args>
+static void launch_cov(bool pcl, dim3 grid, hipStream_t st, Args... args) {
+  if (pcl) hipLaunchKernelGGL(shot_cov_kernel<true>, grid, dim3(64), 0, st, args...);
+  else hipLaunchKernelGGL(shot_cov_kernel<false>, grid, dim3(64), 0, st, args...);
+}
+
 static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, float normal_r, float shot_r,
                     const float* normals_in, float* out_normal, float* out_shot, float* out_rf, void* workspace,
-                    int64_t workspace_bytes, hipStream_t st) {
+                    int64_t workspace_bytes, hipStream_t st, int flags) {
+  const bool pcl = !(flags & CPPF_SHOT_F64_NORMALS);
   CPPF_CHECK_ARG(workspace && workspace_bytes >= cppf_shot352_workspace_bytes(B, n));
   const ShotWs w = carve(workspace, B, n);
   const bool want_n = out_normal != nullptr, want_s = out_shot != nullptr;
@@ -1005,12 +1289,19 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
   hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(rn, rs), w.hdr, w.cell_start,
                      w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, w.scene_of, rn, rs, w.sums, want_s ? w.nbr_list : (int32_t*)nullptr,
-                     want_s ? w.nbr_cnt : (int32_t*)nullptr);
+  launch_cov(pcl, dim3((unsigned)n), st, B, pts, pt_off, (const CellHdr*)w.hdr, (const int32_t*)w.cell_start,
+             (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, rn, rs, w.sums,
+             (want_s || pcl) ? w.nbr_list : (int32_t*)nullptr,      // (PCL normals read long lists back from it)
+             (want_s || pcl) ? w.nbr_cnt : (int32_t*)nullptr);
   CPPF_LAUNCH_CHECK();
+  if (pcl && want_n) {
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+                       (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, rn, (const int32_t*)w.nbr_list,
+                       (const int32_t*)w.nbr_cnt, w.sums);
+    CPPF_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums,
-                     out_normal, want_s ? w.pre : (LrfPre*)nullptr);
+                     out_normal, want_s ? w.pre : (LrfPre*)nullptr, (int)pcl);
   CPPF_LAUNCH_CHECK();
   if (want_s) {
     hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
@@ -1026,22 +1317,22 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
 
 extern "C" int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
                                      float normal_r, float* out_normal, void* workspace, int64_t workspace_bytes,
-                                     void* stream) {
+                                     int flags, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_normal && normal_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
   return shot_run(B, pts, pt_off, total_points, normal_r, 0.0f, nullptr, out_normal, nullptr, nullptr, workspace,
-                  workspace_bytes, (hipStream_t)stream);
+                  workspace_bytes, (hipStream_t)stream, flags);
 }
 
 extern "C" int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                             float shot_r, float* out_shot, float* out_normal, float* out_rf, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
+                            int64_t workspace_bytes, int flags, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_shot && out_normal && normal_r > 0.0f && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
   return shot_run(B, pts, pt_off, total_points, normal_r, shot_r, nullptr, out_normal, out_shot, out_rf, workspace,
-                  workspace_bytes, (hipStream_t)stream);
+                  workspace_bytes, (hipStream_t)stream, flags);
 }
 
 extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
@@ -1051,7 +1342,7 @@ extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t*
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
   return shot_run(B, pts, pt_off, total_points, 0.0f, shot_r, normals, nullptr, out_shot, out_rf, workspace,
-                  workspace_bytes, (hipStream_t)stream);
+                  workspace_bytes, (hipStream_t)stream, 0);
 }
 
 // Two-call form of cppf_shot352 sharing one workspace: prepare = cells + covariances + eigen-solves (normals out,
@@ -1059,7 +1350,7 @@ extern "C" int cppf_shot352_from_normals(int B, const float* pts, const int32_t*
 // the same inputs, same stream, same workspace.
 extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                                  float shot_r, float* out_normal, void* workspace, int64_t workspace_bytes,
-                                 void* stream) {
+                                 int flags, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && pt_off && out_normal && normal_r > 0.0f && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
@@ -1070,11 +1361,18 @@ extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off,
   hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(normal_r, shot_r), w.hdr,
                      w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
+  const bool pcl = !(flags & CPPF_SHOT_F64_NORMALS);
+  launch_cov(pcl, dim3((unsigned)n), st, B, pts, pt_off, (const CellHdr*)w.hdr, (const int32_t*)w.cell_start,
+             (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
   CPPF_LAUNCH_CHECK();
+  if (pcl) {
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+                       (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, (const int32_t*)w.nbr_list,
+                       (const int32_t*)w.nbr_cnt, w.sums);
+    CPPF_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
-                     w.pre);
+                     w.pre, (int)pcl);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }
@@ -1110,7 +1408,7 @@ extern "C" int64_t cppf_shot1344_workspace_bytes(int B, int64_t total_points) {
 
 extern "C" int cppf_shot1344(int B, const float* pts, const float* colors, const int32_t* pt_off, int64_t total_points,
                              float normal_r, float shot_r, float* out_shot, float* out_normal, void* workspace,
-                             int64_t workspace_bytes, void* stream) {
+                             int64_t workspace_bytes, int flags, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && colors && pt_off && out_shot && out_normal && normal_r > 0.0f && shot_r > 0.0f);
   CPPF_CHECK_ARG(total_points >= 0 && total_points <= 0x7fffffffLL);
   if (total_points <= 0) return CPPF_OK;
@@ -1123,11 +1421,18 @@ extern "C" int cppf_shot1344(int B, const float* pts, const float* colors, const
   hipLaunchKernelGGL(shot_cells_kernel, dim3(B), dim3(1024), 0, st, pts, pt_off, fmaxf(normal_r, shot_r), w.hdr,
                      w.cell_start, w.sorted_idx, w.sorted_pts, w.scene_of);
   CPPF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shot_cov_kernel, dim3((unsigned)n), dim3(64), 0, st, B, pts, pt_off, w.hdr, w.cell_start,
-                     w.sorted_pts, w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
+  const bool pcl = !(flags & CPPF_SHOT_F64_NORMALS);
+  launch_cov(pcl, dim3((unsigned)n), st, B, pts, pt_off, (const CellHdr*)w.hdr, (const int32_t*)w.cell_start,
+             (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
   CPPF_LAUNCH_CHECK();
+  if (pcl) {
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+                       (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, (const int32_t*)w.nbr_list,
+                       (const int32_t*)w.nbr_cnt, w.sums);
+    CPPF_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(shot_eig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pts, w.sums, out_normal,
-                     w.pre);
+                     w.pre, (int)pcl);
   CPPF_LAUNCH_CHECK();
   hipLaunchKernelGGL(shot_sort_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, out_normal, pt_off,
                      w.scene_of, w.sorted_idx, w.sorted_nrm);

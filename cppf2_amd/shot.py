@@ -19,6 +19,20 @@ from . import _lib, ops
 
 _L = _lib.load()
 
+# Arithmetic of the normals (include/cppf_hip.h, flags of the SHOT entry points): "pcl" (default) = pcl::NormalEstimation's -- what
+# src_shot/shot.cpp:25-32, 66-72 runs: single-pass float32 sums of the raw coordinates in (distance, index) order, closed-form
+# eigen33, float32 viewpoint flip; "f64" = float64 covariance about the query point + Jacobi (rounds 1-3; more accurate, but not
+# what the reference's checkpoints were trained on).  Every function below takes arithmetic=None = this module default.
+ARITHMETIC = "pcl"
+
+
+def _flags(arithmetic):
+    a = ARITHMETIC if arithmetic is None else arithmetic
+    if a not in ("pcl", "f64"):
+        raise ValueError("arithmetic must be 'pcl' or 'f64', not %r" % (a,))
+    return 1 if a == "f64" else 0          # CPPF_SHOT_F64_NORMALS
+
+
 _WS = {}          # (device, stream) -> scratch buffer
 _PREPARED = {}    # (device, stream) -> (B, n, pts pointer) of the last prepare_device, checked by describe_device
 
@@ -51,7 +65,7 @@ def _workspace(B, n, dev):
     return ws
 
 
-def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
+def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False, arithmetic=None):
     """Batched device API: pts float32 [Ntot,3] (device), pt_off int32 [B+1] (device).
     Returns (shot [Ntot,352], normal [Ntot,3][, rf [Ntot,9]]) device tensors."""
     dev = pts.device
@@ -64,19 +78,20 @@ def compute_device(pts, pt_off, normal_r, shot_r, want_rf=False):
     _PREPARED.pop(_key(dev), None)
     _lib.check(_L.cppf_shot352(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
                                ops._p(out_shot), ops._p(out_normal), ops._p(out_rf), ops._p(ws), ws.numel(),
-                               ops._stream()), "cppf_shot352")
+                               _flags(arithmetic), ops._stream()), "cppf_shot352")
     if want_rf:
         return out_shot, out_normal, out_rf
     return out_shot, out_normal
 
 
-def normals_device(pts, pt_off, normal_r, out=None):
+def normals_device(pts, pt_off, normal_r, out=None, arithmetic=None):
     n = pts.shape[0]
     out = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out is None else out
     ws = _workspace(pt_off.numel() - 1, n, pts.device)
     _PREPARED.pop(_key(pts.device), None)
     _lib.check(_L.cppf_estimate_normals(pt_off.numel() - 1, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r),
-                                        ops._p(out), ops._p(ws), ws.numel(), ops._stream()), "cppf_estimate_normals")
+                                        ops._p(out), ops._p(ws), ws.numel(), _flags(arithmetic), ops._stream()),
+               "cppf_estimate_normals")
     return out
 
 
@@ -91,14 +106,15 @@ def descriptors_device(pts, pt_off, normals, shot_r, out=None):
     return out
 
 
-def prepare_device(pts, pt_off, normal_r, shot_r, out_normal=None):
+def prepare_device(pts, pt_off, normal_r, shot_r, out_normal=None, arithmetic=None):
     """First half of compute_device (cell sort, covariances, eigen-solves): returns the normals."""
     n = pts.shape[0]
     B = pt_off.numel() - 1
     out_normal = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if out_normal is None else out_normal
     ws = _workspace(B, n, pts.device)
     _lib.check(_L.cppf_shot_prepare(B, ops._p(pts), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
-                                    ops._p(out_normal), ops._p(ws), ws.numel(), ops._stream()), "cppf_shot_prepare")
+                                    ops._p(out_normal), ops._p(ws), ws.numel(), _flags(arithmetic), ops._stream()),
+               "cppf_shot_prepare")
     _PREPARED[_key(pts.device)] = (B, n, pts.data_ptr(), float(shot_r), ws.data_ptr())
     return out_normal
 
@@ -120,16 +136,17 @@ def describe_device(pts, pt_off, normals, shot_r, out=None, nan_to_zero=False):
     return out
 
 
-def compute(pc, normal_r=0.1, shot_r=0.17):
-    """shot.compute (src_shot/shot.cpp:45-100): returns [float32[N*352], float32[N*3]]."""
+def compute(pc, normal_r=0.1, shot_r=0.17, arithmetic=None):
+    """shot.compute (src_shot/shot.cpp:45-100): returns [float32[N*352], float32[N*3]].  The normals follow
+    pcl::NormalEstimation's arithmetic (ARITHMETIC = "pcl") unless arithmetic="f64" asks for the float64 ones."""
     dev = ops._dev()
     pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
     pt_off = ops._offsets([pts.shape[0]], dev)
-    s, n = compute_device(pts, pt_off, float(normal_r), float(shot_r))
+    s, n = compute_device(pts, pt_off, float(normal_r), float(shot_r), arithmetic=arithmetic)
     return [s.reshape(-1).cpu().numpy(), n.reshape(-1).cpu().numpy()]
 
 
-def compute_color_device(pts, colors, pt_off, normal_r, shot_r):
+def compute_color_device(pts, colors, pt_off, normal_r, shot_r, arithmetic=None):
     """Batched device API of compute_color: pts / colors float32 [Ntot,3] (device).  Returns (shot1344 [Ntot,1344], normal)."""
     dev = pts.device
     n = pts.shape[0]
@@ -139,24 +156,25 @@ def compute_color_device(pts, colors, pt_off, normal_r, shot_r):
     need = _L.cppf_shot1344_workspace_bytes(B, n)
     ws = torch.empty((max(need, 256),), dtype=torch.uint8, device=dev)
     _lib.check(_L.cppf_shot1344(B, ops._p(pts), ops._p(colors), ops._p(pt_off), n, C.c_float(normal_r), C.c_float(shot_r),
-                                ops._p(out), ops._p(out_normal), ops._p(ws), ws.numel(), ops._stream()), "cppf_shot1344")
+                                ops._p(out), ops._p(out_normal), ops._p(ws), ws.numel(), _flags(arithmetic), ops._stream()),
+               "cppf_shot1344")
     return out, out_normal
 
 
-def compute_color(pc, pc_color, normal_r=0.1, shot_r=0.17):
+def compute_color(pc, pc_color, normal_r=0.1, shot_r=0.17, arithmetic=None):
     """shot.compute_color (src_shot/shot.cpp:102-161): float32[N*1344] (SHOT1344: 352 shape + 992 colour entries)."""
     dev = ops._dev()
     pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
     col = ops._t(np.asarray(pc_color, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
     assert col.shape[0] == pts.shape[0]
     pt_off = ops._offsets([pts.shape[0]], dev)
-    s, _ = compute_color_device(pts, col, pt_off, float(normal_r), float(shot_r))
+    s, _ = compute_color_device(pts, col, pt_off, float(normal_r), float(shot_r), arithmetic=arithmetic)
     return s.reshape(-1).cpu().numpy()
 
 
-def estimate_normal(pc, normal_r):
+def estimate_normal(pc, normal_r, arithmetic=None):
     """shot.estimate_normal (src_shot/shot.cpp:12-42): returns float32[N*3]."""
     dev = ops._dev()
     pts = ops._t(np.asarray(pc, dtype=np.float32).reshape(-1, 3), torch.float32, dev)
     pt_off = ops._offsets([pts.shape[0]], dev)
-    return normals_device(pts, pt_off, float(normal_r)).reshape(-1).cpu().numpy()
+    return normals_device(pts, pt_off, float(normal_r), arithmetic=arithmetic).reshape(-1).cpu().numpy()

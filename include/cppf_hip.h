@@ -85,11 +85,18 @@ int cppf_philox_uniform(int B, const int32_t* tup_off, int max_t, int m, uint64_
 /* ---- a2. SHOT352 + normals: replaces shot.compute(pc, normal_r, shot_r) (src_shot/shot.cpp:45-100,
  * PCL 1.9.1 NormalEstimation + SHOTEstimation).  out_shot: float32[n,352], out_normal: float32[n,3];
  * rows PCL would leave NaN are written as NaN (callers zero them, eval.py:215-216).
- * workspace: cppf_shot352_workspace_bytes(B, total_points) bytes. */
+ * workspace: cppf_shot352_workspace_bytes(B, total_points) bytes.
+ * flags (every entry point that estimates normals): 0 = pcl::NormalEstimation's arithmetic (src_shot/shot.cpp:25-32, 66-72):
+ * single-pass float32 sums of the raw coordinates and their products over the neighbours in (distance, index) order,
+ * covariance = E[x x^T] - E[x] E[x]^T, closed-form pcl::eigen33, float32 flipNormalTowardsViewpoint -- what the reference's
+ * trained checkpoints saw; CPPF_SHOT_F64_NORMALS = float64 covariance about the query point + Jacobi (the more accurate
+ * normals of rounds 1-3: 0.03 deg median / 0.45 deg max away from PCL's arithmetic on the bench clouds).  The local frames and
+ * the descriptor follow PCL's algorithm in both (float64 weighted covariance, SelfAdjointEigenSolver restated as Jacobi). */
+#define CPPF_SHOT_F64_NORMALS 1
 int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points);
 int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r, float shot_r,
                  float* out_shot, float* out_normal, float* out_rf /* optional float32[n,9] local frames */,
-                 void* workspace, int64_t workspace_bytes, void* stream);
+                 void* workspace, int64_t workspace_bytes, int flags, void* stream);
 /* The descriptor half alone, on normals the caller already has (e.g. from cppf_estimate_normals). */
 int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
                               const float* normals, float shot_r, float* out_shot, float* out_rf,
@@ -102,14 +109,14 @@ int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, in
 int64_t cppf_shot1344_workspace_bytes(int B, int64_t total_points);
 int cppf_shot1344(int B, const float* pts, const float* colors, const int32_t* pt_off, int64_t total_points,
                   float normal_r, float shot_r, float* out_shot, float* out_normal,
-                  void* workspace, int64_t workspace_bytes, void* stream);
+                  void* workspace, int64_t workspace_bytes, int flags, void* stream);
 /* Two-call form of cppf_shot352 sharing one workspace: prepare = cell sort + covariances + eigen-solves (normals out,
  * local-frame axes kept in the workspace); describe = the histogram kernel alone.  describe must follow a prepare
  * on the same inputs / stream / workspace.  `normals` are the ones the descriptor reads (eval.py zeroes NaNs only
  * after shot.compute, so pass prepare's output unchanged).  nan_to_zero != 0 makes describe write 0 where shot.compute
  * writes NaN (invalid frames, < 5 neighbours): the np.nan_to_num of eval.py:215 folded into the store. */
 int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
-                      float shot_r, float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);
+                      float shot_r, float* out_normal, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t total_points, const float* normals,
                        float shot_r, int nan_to_zero, float* out_shot, float* out_rf, void* workspace,
                        int64_t workspace_bytes, void* stream);
@@ -117,7 +124,7 @@ int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t t
 int cppf_nan_to_zero(float* x, int64_t n, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
-                          float* out_normal, void* workspace, int64_t workspace_bytes, void* stream);
+                          float* out_normal, void* workspace, int64_t workspace_bytes, int flags, void* stream);
 
 /* ---- a3. tuple encode: replaces BeyondCPPF.prepare_tuple_inputs.
  * SHOT model (train_shot.py:75-83): row = [p_i-p_j for i<j (C(k,2)*3) | max(n_i.n_j, -n_i.n_j) (C(k,2)) |

@@ -38,7 +38,8 @@ def run_scene_full(weights, pc, seed, scene_id, num_tuples, res=2e-3, num_rots=1
     """Sampler -> SHOT -> MLP -> decode -> votes -> pose for one scene; mirrors bench.py's GPU step."""
     n = pc.shape[0]
     idx = O.sample_tuples(seed, scene_id, num_tuples, 5, n).astype(np.int64)
-    shot_feat, normal, _ = S.compute(pc, res * 10, res * 10)                   # eval.py:210
+    # eval.py:210; the normals in pcl::NormalEstimation's arithmetic, like the product's default (cppf2_amd.shot.ARITHMETIC)
+    shot_feat, normal, _, _ = S.compute_ex(pc, res * 10, res * 10, pcl_arithmetic=True)
     shot_feat = np.nan_to_num(shot_feat, nan=0.0)                               # eval.py:215-216
     normal = np.nan_to_num(normal, nan=0.0)
     logits, scales = mlp_shot(weights, pc, idx, shot_feat, normal)

@@ -67,28 +67,50 @@ def test_huge_grid_takes_the_global_atomic_path_and_matches_oracle():
     assert grid.size > 64 * 36864 and np.array_equal(grid, g2) and np.array_equal(cand, c2)
 
 
-def test_shot_large_sparse_cloud_coarsened_cells():
+def _shot_oracle(pc, rn, rs, arithmetic):
+    """(descriptors, normals, diagnostics) of the oracle in the arithmetic the kernel was asked for."""
+    s_, n_, _, d_ = S.compute_ex(pc, rn, rs, pcl_arithmetic=(arithmetic == "pcl"))
+    return s_, n_, d_
+
+
+# normals: float64 Jacobi path to float rounding; PCL arithmetic = identical float32 sums, device atan2f / cosf / sinf inside the roots
+NORMAL_TOL = {"f64": 2e-6, "pcl": 2e-5}
+
+
+def _desc_close(hs, os_, d, arithmetic):
+    """Descriptor rows within 2e-5, except (PCL arithmetic) rows where a neighbour's normal -- equal to 1e-5 only -- sits within that
+    distance of one of PCL's cosine steps (the oracle's own boundary margin)."""
+    err = np.abs(hs - os_).max(1)
+    if arithmetic == "f64":
+        return bool(np.all(err < 2e-5))
+    exempt = (d[:, 5] < 2e-5) | (d[:, 8] < 4e-7)
+    return bool(np.all(err[~exempt] < 5e-5)) and (err >= 5e-5).mean() < 2e-2
+
+
+@pytest.mark.parametrize("arithmetic", ["f64", "pcl"])
+def test_shot_large_sparse_cloud_coarsened_cells(arithmetic):
     # a cloud spanning far more than CELL_CAP cells of edge r: the cell edge is coarsened, results must not change
     rng = np.random.RandomState(0)
     pc = (rng.rand(6000, 3) * np.float32([1.0, 1.5, 1.2])).astype(np.float32)
     pc[:3000] = pc[:3000] * 0.05 + 0.4                     # one dense blob so that descriptors exist
-    hs, hn = shot.compute(pc, 0.02, 0.02)
-    os_, on, _ = S.compute(pc, 0.02, 0.02)
+    hs, hn = shot.compute(pc, 0.02, 0.02, arithmetic=arithmetic)
+    os_, on, d = _shot_oracle(pc, 0.02, 0.02, arithmetic)
     hs, hn = hs.reshape(-1, 352), hn.reshape(-1, 3)
     assert np.array_equal(np.isnan(os_), np.isnan(hs)) and np.array_equal(np.isnan(on), np.isnan(hn))
     ok = ~np.isnan(os_).any(1)
     assert ok.sum() > 1000
-    assert np.abs(hs[ok] - os_[ok]).max() < 2e-5
-    assert np.allclose(hn, on, atol=2e-6, equal_nan=True)
+    assert _desc_close(hs[ok], os_[ok], d[ok], arithmetic)
+    assert np.allclose(hn, on, atol=NORMAL_TOL[arithmetic], equal_nan=True)
 
 
-def test_shot_different_radii():
+@pytest.mark.parametrize("arithmetic", ["f64", "pcl"])
+def test_shot_different_radii(arithmetic):
     sc = synth.make_scene(8, 0, 900)
-    hs, hn = shot.compute(sc["pc"], 0.012, 0.025)
-    os_, on, _ = S.compute(sc["pc"], 0.012, 0.025)
+    hs, hn = shot.compute(sc["pc"], 0.012, 0.025, arithmetic=arithmetic)
+    os_, on, d = _shot_oracle(sc["pc"], 0.012, 0.025, arithmetic)
     ok = ~np.isnan(os_).any(1)
-    assert np.allclose(hn.reshape(-1, 3), on, atol=2e-6, equal_nan=True)
-    assert np.abs(hs.reshape(-1, 352)[ok] - os_[ok]).max() < 2e-5
+    assert np.allclose(hn.reshape(-1, 3), on, atol=NORMAL_TOL[arithmetic], equal_nan=True)
+    assert _desc_close(hs.reshape(-1, 352)[ok], os_[ok], d[ok], arithmetic)
 
 
 def test_vote_center_two_call_form_equals_single_call():
@@ -153,12 +175,23 @@ def test_shot_neighbour_list_paths(n, rn, rs):
     rng = np.random.RandomState(n)
     v = rng.randn(n, 3)
     pc = (v / np.linalg.norm(v, axis=1, keepdims=True) * (rng.rand(n, 1) ** (1 / 3)) * 0.03 + 0.5).astype(np.float32)
-    hs, hn = shot.compute(pc, rn, rs)
+    hs, hn = shot.compute(pc, rn, rs, arithmetic="f64")
     os_, on, _ = S.compute(pc, rn, rs)
     hs, hn = hs.reshape(-1, 352), hn.reshape(-1, 3)
     assert np.array_equal(np.isnan(os_), np.isnan(hs))
     ok = ~np.isnan(os_).any(1)
     assert ok.sum() > n // 2
+    # the normals in PCL's arithmetic on the same clouds: lists up to 313 neighbours are ranked in LDS, up to 512 read back from
+    # the workspace copy, longer ones (the 2600- and 6000-point balls) keep the float64 sums -- documented, and visible here as
+    # agreement with the float64 oracle where the PCL-arithmetic oracle is ~1e-4 away
+    pn = shot.estimate_normal(pc, rn, arithmetic="pcl").reshape(-1, 3)
+    _, on1, _, _ = S.compute_ex(pc, rn, rs, pcl_arithmetic=True)
+    cnt_n = ((pc[:, None, :] - pc[None, :, :]) ** 2).sum(-1) < np.float32(rn) * np.float32(rn)
+    short = cnt_n.sum(1) <= 512
+    if short.any():
+        assert np.allclose(pn[short], on1[short], atol=2e-5, equal_nan=True)
+    if (~short).any():
+        assert np.allclose(pn[~short], on[~short], atol=2e-6, equal_nan=True)
     d2 = ((pc[:, None, :] - pc[None, :200, :]) ** 2).sum(-1)
     cnt = (d2 < rs * rs).sum(0)
     if n == 2600:

@@ -142,7 +142,7 @@ def test_hip_shot_vs_oracle():
     scs = [synth.make_scene(5, s, n) for s, n in enumerate((1200, 777))]
     pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
     pt_off = ops._offsets([1200, 777], pts.device)
-    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True, arithmetic="f64")
     hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
     o = 0
     for sc in scs:
@@ -158,16 +158,21 @@ def test_hip_shot_vs_oracle():
         assert np.abs(hs[o:o + n][ok] - os_[ok]).max() < 2e-5
         o += n
     # two-call form == one-call form (same kernels, same workspace)
-    n2 = shot.prepare_device(pts, pt_off, 0.02, 0.02)
+    n2 = shot.prepare_device(pts, pt_off, 0.02, 0.02, arithmetic="f64")
     s2 = shot.describe_device(pts, pt_off, n2, 0.02)
     assert np.array_equal(n2.cpu().numpy(), hn, equal_nan=True)
     assert np.allclose(s2.cpu().numpy(), hs, atol=1e-6, equal_nan=True)
     # drop-in module call convention (src_shot/shot.cpp:45): list of two flat float32 arrays
-    r = shot.compute(scs[1]["pc"].astype(np.float64), 0.02, 0.02)
+    r = shot.compute(scs[1]["pc"].astype(np.float64), 0.02, 0.02, arithmetic="f64")
     assert isinstance(r, list) and r[0].shape == (777 * 352,) and r[1].shape == (777 * 3,) and r[0].dtype == np.float32
     assert np.allclose(r[0].reshape(-1, 352), hs[1200:], atol=1e-6, equal_nan=True)
-    nn = shot.estimate_normal(scs[1]["pc"], 0.02)
+    nn = shot.estimate_normal(scs[1]["pc"], 0.02, arithmetic="f64")
     assert np.allclose(nn.reshape(-1, 3), hn[1200:], atol=1e-7, equal_nan=True)
+    # the module default is PCL's arithmetic for the normals (next test); the two differ by the float covariance's noise
+    assert shot.ARITHMETIC == "pcl"
+    rp = shot.compute(scs[1]["pc"], 0.02, 0.02)
+    ang = np.degrees(np.arccos(np.clip((rp[1].reshape(-1, 3) * hn[1200:]).sum(1), -1, 1)))
+    assert 0 < np.nanmedian(ang) < 0.1 and np.nanmax(ang) < 1.0
 
 
 @pytest.mark.gpu
@@ -196,7 +201,7 @@ def test_hip_shot_bench_size_vs_oracle():
     scs = [synth.make_scene(0, s, 4096) for s in (0, 1)]
     pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
     pt_off = ops._offsets([4096, 4096], pts.device)
-    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True, arithmetic="f64")
     hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
     for b, sc in enumerate(scs):
         sl = slice(4096 * b, 4096 * (b + 1))
@@ -214,6 +219,50 @@ def test_hip_shot_bench_size_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_hip_shot_pcl_arithmetic_vs_oracle():
+    """The default arithmetic of shot.compute since round 4: pcl::NormalEstimation's (src_shot/shot.cpp:25-32, 66-72 -- single-pass
+    float32 sums of the raw coordinates in (distance, index) order, closed-form eigen33, float32 viewpoint flip) against the
+    oracle's PCL-arithmetic mode (compute_ex(pcl_arithmetic=True)) at bench size, same criteria as the float64 mode: the
+    float32 sums are bit-identical by construction (same addends, same order), what is left in the normals is the
+    device's atan2f / cosf / sinf against glibc's inside the closed-form roots; descriptors within 2e-5 except where the oracle
+    says a neighbour sits on a decision boundary of PCL's interpolation."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from cppf2_amd import ops, shot
+    scs = [synth.make_scene(0, s, 4096) for s in (0, 1)] + [synth.make_scene(3, 0, 900)]
+    sizes = [s["pc"].shape[0] for s in scs]
+    pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
+    pt_off = ops._offsets(sizes, pts.device)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True, arithmetic="pcl")
+    hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
+    o = 0
+    for sc, n in zip(scs, sizes):
+        sl = slice(o, o + n)
+        o += n
+        os_, on, orf, d = S.compute_ex(sc["pc"], 0.02, 0.02, pcl_arithmetic=True)
+        assert np.array_equal(np.isnan(os_), np.isnan(hs[sl])) and np.array_equal(np.isnan(on), np.isnan(hn[sl]))
+        ang = np.degrees(np.arccos(np.clip((hn[sl] * on).sum(1), -1, 1)))
+        assert np.nanmax(np.abs(hn[sl] - on)) < 2e-5, float(np.nanmax(np.abs(hn[sl] - on)))
+        assert np.nanmedian(ang) < 1e-4
+        assert np.allclose(hrf[sl], orf, atol=2e-5, equal_nan=True)
+        ok = ~np.isnan(os_).any(1)
+        err = np.abs(hs[sl][ok] - os_[ok]).max(1)
+        # a neighbour normal that moved by 1e-5 may cross a cosine step the oracle's did not: same exemption, by margin
+        exempt = (d[ok, 5] < 2e-5) | (d[ok, 8] < 4e-7)
+        assert np.all(err[~exempt] < 5e-5), float(err[~exempt].max())
+        assert (err >= 5e-5).mean() < 2e-2
+    # the normals alone through estimate_normal, and a cloud centred at the origin (well-conditioned sums: both arithmetics agree)
+    nn = shot.estimate_normal(scs[2]["pc"], 0.02)
+    assert np.allclose(nn.reshape(-1, 3), hn[o - sizes[2]:o], atol=1e-7, equal_nan=True)
+    pc0 = (scs[2]["pc"] - scs[2]["pc"].mean(0)).astype(np.float32)
+    a = shot.estimate_normal(pc0, 0.02, arithmetic="pcl").reshape(-1, 3)
+    b = shot.estimate_normal(pc0, 0.02, arithmetic="f64").reshape(-1, 3)
+    ang = np.degrees(np.arccos(np.clip(np.abs((a * b).sum(1)), -1, 1)))
+    assert np.nanmedian(ang) < 2e-3 and np.nanpercentile(ang, 99) < 0.05
+
+
+@pytest.mark.gpu
 def test_hip_shot1344_vs_oracle():
     """shot.compute_color on the GPU (cppf_shot1344) against the oracle: rows agree to 2e-5 except where the oracle
     itself has a neighbour within 1e-6 of a decision boundary of PCL's interpolation (shape or colour step)."""
@@ -226,7 +275,7 @@ def test_hip_shot1344_vs_oracle():
         sc = synth.make_scene(6, sid, n)
         col = rng.rand(n, 3).astype(np.float32)
         col[: n // 4] = col[0]                                    # a patch of one colour
-        got = shot.compute_color(sc["pc"], col, 0.02, 0.02)
+        got = shot.compute_color(sc["pc"], col, 0.02, 0.02, arithmetic="f64")       # (the colour oracle runs the float64 normals)
         assert got.shape == (n * 1344,) and got.dtype == np.float32
         got = got.reshape(n, 1344)
         want, _, d = S.compute_color(sc["pc"], col, 0.02, 0.02)
@@ -238,6 +287,6 @@ def test_hip_shot1344_vs_oracle():
         assert (err >= 2e-5).mean() < 1e-2
         assert np.allclose(np.linalg.norm(got[ok], axis=1), 1.0, atol=1e-5)
     # the shape channel is the SHOT352 kernel's
-    s352 = shot.compute(sc["pc"], 0.02, 0.02)[0].reshape(n, 352)
+    s352 = shot.compute(sc["pc"], 0.02, 0.02, arithmetic="f64")[0].reshape(n, 352)
     shape = got[ok, :352]
     assert np.abs(shape / np.linalg.norm(shape, axis=1, keepdims=True) - s352[ok]).max() < 1e-5
