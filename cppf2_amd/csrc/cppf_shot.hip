@@ -504,7 +504,7 @@ __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn
 #define PCL_EMAX_SHORT 2
 #define PCL_EMAX_LONG (NBR_CAP / 64)
 template <bool PCL>
-__global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
+__global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
