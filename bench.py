@@ -110,11 +110,17 @@ def parse():
                          "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
     ap.add_argument("--no-native-arith", action="store_true",
                     help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
-    ap.add_argument("--two-streams", action="store_true", help="(default at one rank; kept for old command lines)")
-    ap.add_argument("--no-two-streams", action="store_true",
-                    help="skip the extra loop that times the steps alternating between two HIP streams (two_streams in the line)")
+    ap.add_argument("--two-streams", action="store_true", help="(the default since round 4; kept for old command lines)")
+    ap.add_argument("--single-stream", "--no-two-streams", dest="single_stream", action="store_true",
+                    help="time the headline with every step on ONE HIP stream (rounds 1-3).  Default: consecutive steps "
+                         "(independent scene batches) alternate between two streams with double-buffered state -- the product's "
+                         "batch mode (eval.run_ensemble runs its two model passes the same way); the single-stream figure is "
+                         "still measured and printed as value_single_stream")
     ap.add_argument("--no-evidence", action="store_true",
                     help="skip the untimed accuracy evidence (mlp_error_vs_f64, bin_flip_rate_vs_expf)")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="skip the rocprofv3 counter passes (roofline.traffic and the unit-activity fractions are then null)")
+    ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)      # set by collect_counters for its children
     ap.add_argument("--workload", choices=("shot", "ensemble"), default="shot",
                     help="shot (default, the headline): BASELINE configs[1], the SHOT model; ensemble: BASELINE configs[2], the "
                          "reference's real per-instance loop (eval.py:219-372) -- the DINO model AND the SHOT model vote every "
@@ -370,6 +376,22 @@ def tuple_mlp_flops(model, B, T, N, nprod):
     return nprod * ex, al
 
 
+def ensemble_mlp_traffic():
+    """HBM bytes per ensemble step of all matrix-core launches (every reslayer_split_kernel instantiation: both tuple MLPs, the
+    point encoder, the DINO model's per-point Linear launches, the scale heads), from this run's counter passes."""
+    passes = (COUNTERS.get("ensemble_select_kernel") or {}).get("launches")
+    if not passes:
+        return None
+    tot = 0.0
+    for k_, v in COUNTERS.items():
+        if isinstance(v, dict) and k_.startswith("reslayer_split_kernel"):
+            b_ = hbm_bytes(v)
+            if b_ is None:
+                return None
+            tot += b_ * v["launches"]
+    return tot / passes
+
+
 def report_ensemble(args, step, dt, evs, world, backend):
     """The JSON line of --workload ensemble (rank 0): the contract fields + roofline + cpu_baseline, per model."""
     from cppf2_amd import models as _models
@@ -378,7 +400,26 @@ def report_ensemble(args, step, dt, evs, world, backend):
     for ev in evs:
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
+    stage_ms_single = {}
+    for ev in evs_single:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms_single[n1] = stage_ms_single.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs_single)
     step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
+    # With two streams a stage's HIP-event time on its own stream includes the time its kernels wait for the other stream's (two
+    # persistent matrix-core kernels do not fit a CU together): the kernels' own durations -- what the roofline divides by -- are
+    # the stage times of the single-stream loop of the same run (rocprofv3 shows the same durations in both modes,
+    # profiles/r4_two_stream_trace.txt).  stage_ms_2s keeps the two-stream stage times for the record.
+    stage_ms_2s = stage_ms
+    if dt_single is not None:
+        stage_ms = stage_ms_single
+    step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
+    # With two streams a stage's HIP-event time on its own stream includes the time its kernels wait for the other stream's (two
+    # persistent matrix-core kernels do not fit a CU together): the kernels' own durations -- what the roofline divides by -- are
+    # the stage times of the single-stream loop of the same run (rocprofv3 shows the same durations in both modes,
+    # profiles/r4_two_stream_trace.txt).  stage_ms_2s keeps the two-stream stage times for the record.
+    stage_ms_2s = stage_ms
+    if dt_single is not None:
+        stage_ms = stage_ms_single
     shared = ["sample_tuples", "shot_frames", "shot352"]
     dino_ms = stage_ms.get("dino_point_transforms", 0.0) + sum(stage_ms.get("dino_" + n, 0.0) for n in EnsembleStep.PASS)
     shot_ms = stage_ms.get("shot_encoder", 0.0) + sum(stage_ms.get("shot_" + n, 0.0) for n in EnsembleStep.PASS)
@@ -460,7 +501,10 @@ def report_ensemble(args, step, dt, evs, world, backend):
         "roofline": dict(bound="mfma", kernel="tuple_mlp (both models) + the DINO model's per-point Linear launches",
                          kernel_name="reslayer_split_kernel", achieved=(ex_d + ex_s) / 1e12 / (mlp_ms / 1e3),
                          peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ex_d + ex_s) / 1e12 / (mlp_ms / 1e3) / BF16_MFMA_PEAK_TFLOPS,
-                         traffic=None, traffic_note="not measured in this run (rocprofv3 --pmc passes: profiles/r4_ensemble_*)",
+                         traffic=ensemble_mlp_traffic(),
+                         traffic_source=("rocprofv3 counter passes of this run: HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of every "
+                                         "reslayer_split_kernel launch of a step" if "reason" not in COUNTERS
+                                         else "null: " + str(COUNTERS.get("reason"))),
                          launch_ms=mlp_ms, launches=8,
                          frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
                          executed_flops_per_step={"dino": ex_d, "shot": ex_s},
@@ -509,59 +553,156 @@ STAGE_KERNEL = {"sample_tuples": "sample_tuples_kernel", "shot_frames": "shot_co
                 "rot_bins": "rot_bins_lut_kernel<2>", "assemble_pose": "assemble_pose_kernel"}
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/rN_pmc_traffic.json of the latest round, produced by scratch/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
-    KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  None if no profile is committed."""
-    try:
-        cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
-        with open(os.path.join(ROOT, "profiles", cands[-1])) as f:       # the latest round's passes
-            table = json.load(f)
-        name = STAGE_KERNEL.get(stage, "")
-        d = table.get(name) or next((v for k_, v in sorted(table.items()) if name and k_.startswith(name)), None)
-        if not d:
-            return None
-        return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
-    except Exception:
-        return None
+# ---------------------------------------------------------------------------------------------------------------------
+# Hardware counters measured IN THIS RUN: before this process touches the GPU, rank 0 of a one-rank run starts fresh child
+# processes of itself under rocprofv3 (the program itself after `--`; counters in their own passes with --kernel-trace only, as
+# MI355X_MICROARCH.md prescribes): FETCH_SIZE, WRITE_SIZE (HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE KB: the guide's
+# gfx950 correction) and one pass of SQ counters (VALU / LDS / matrix-pipe activity per kernel).  No rocprofv3, a failed pass or
+# --no-counters: the fields are null with the reason -- never a number read from profiles/.
+# ---------------------------------------------------------------------------------------------------------------------
+COUNTER_PASSES = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+                  "SQ": ["SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU",
+                         "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]}
+COUNTERS = {"reason": "not collected"}
 
 
-TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false>#large", "reslayer_split_kernel<8, true, false, false>",
-                     "reslayer_split_kernel<6, true, false, true>")
+def kernel_key(name):
+    """'void reslayer_split_kernel<4, true, ...>(float const*, ...)' -> 'reslayer_split_kernel<4, true, ...>'"""
+    n = name.replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(n):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return n[:i].strip()
+    return n.strip()
 
 
-def _pmc_names(d, pieces):
-    """Keys of a PMC profile with the kernels' last template argument (operand pieces: 3 = bf16 triples, 2 = fp16 pairs) folded
-    away: {name without it: entry} for the instantiations of `pieces` (profiles older than that argument have none)."""
-    out = {}
-    for k_, v in d.items():
-        m = re.match(r"(reslayer_split_kernel<[^>]*?)(?:, ([23]))?>(#\w+)?$", k_)
-        if m and (m.group(2) is None or int(m.group(2)) == pieces):
-            out[m.group(1) + ">" + (m.group(3) or "")] = v
-        elif not m:
-            out[k_] = v
+def collect_counters(argv_workload, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ")):
+    """Runs `rocprofv3 --kernel-trace --pmc <pass> -- python3 bench.py <workload flags> --steps 2 --warmup 1 --counter-child` once per
+    pass and returns {kernel key [#large | #small]: {counter: mean per launch, "launches": n, "avg_us": mean duration}} -- a kernel
+    launched both for all tuples and for the kept pairs is split into two duration classes."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"reason": "rocprofv3 not found on PATH or under /opt/rocm/bin"}
+    out, fail = {}, []
+    tmp = tempfile.mkdtemp(prefix="cppf_bench_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k_ in list(env):
+        if k_ in _SET_HERE:
+            env.pop(k_)
+    child = [sys.executable, os.path.abspath(__file__)] + argv_workload + ["--steps", "2", "--warmup", "1", "--counter-child"]
+    for pname in passes:
+        d = os.path.join(tmp, pname)
+        cmd = [exe, "--kernel-trace", "--pmc"] + COUNTER_PASSES[pname] + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        except Exception as e:      # noqa: BLE001
+            fail.append("%s: %r" % (pname, e))
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            fail.append("%s: rocprofv3 exit %d, %d counter files; %s" % (pname, r.returncode, len(files), r.stderr.decode("utf-8", "replace")[-300:]))
+            continue
+        rows = [row for f in files for row in csv.DictReader(open(f))]
+        dur = collections.defaultdict(dict)
+        for row in rows:
+            dur[kernel_key(row["Kernel_Name"])][row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        cls = {}
+        for k_, dd in dur.items():
+            mx = max(dd.values())
+            if "reslayer_split_kernel" in k_ and min(dd.values()) < 0.25 * mx:
+                for i_, t_ in dd.items():
+                    cls[(k_, i_)] = k_ + ("#large" if t_ >= 0.25 * mx else "#small")
+        agg, cnt, us = collections.defaultdict(float), collections.defaultdict(set), collections.defaultdict(dict)
+        for row in rows:
+            k0 = kernel_key(row["Kernel_Name"])
+            k_ = cls.get((k0, row["Dispatch_Id"]), k0)
+            agg[(k_, row["Counter_Name"])] += float(row["Counter_Value"])
+            cnt[k_].add(row["Dispatch_Id"])
+            us[k_][row["Dispatch_Id"]] = dur[k0][row["Dispatch_Id"]] / 1e3
+        for (k_, c_), v_ in agg.items():
+            e = out.setdefault(k_, {})
+            e[c_] = v_ / len(cnt[k_])
+            e["launches"] = len(cnt[k_])
+            e.setdefault("avg_us", {})[pname] = sum(us[k_].values()) / len(us[k_])
+    shutil.rmtree(tmp, ignore_errors=True)
+    if fail:
+        out["reason"] = "; ".join(fail)
     return out
+
+
+def counter_entry(name):
+    """The counters of the kernel whose key starts with `name` (exact key first)."""
+    if not name:
+        return None
+    if name in COUNTERS:
+        return COUNTERS[name]
+    hits = [v for k_, v in sorted(COUNTERS.items()) if isinstance(v, dict) and k_.startswith(name)]
+    return hits[0] if hits else None
+
+
+def hbm_bytes(entry):
+    """HBM bytes per launch from one kernel's counters: 2 x FETCH_SIZE + WRITE_SIZE (KB), or None."""
+    if not entry or "FETCH_SIZE" not in entry or "WRITE_SIZE" not in entry:
+        return None
+    return (2.0 * entry["FETCH_SIZE"] + entry["WRITE_SIZE"]) * 1024.0
+
+
+# what limits each stage's kernel: "hbm" = streaming (bytes / time against 8 TB/s), "unit" = an execution unit (VALU or LDS: which
+# one, and how busy, comes from the SQ counters), "latency" = one workgroup per scene or a chain of dependent phases
+STAGE_BOUND = {"sample_tuples": "hbm", "encode_tuples": "hbm", "decode_bins": "hbm", "vote_frames": "hbm",
+               "shot_frames": "unit", "shot352": "unit", "vote_center": "unit", "rot_bins": "unit",
+               "backvote_filter": "latency", "assemble_pose": "latency"}
+
+
+def pmc_traffic(stage):
+    return hbm_bytes(counter_entry(STAGE_KERNEL.get(stage, "")))
+
+
+def unit_activity(entry):
+    """Busy fractions of the VALU, LDS and matrix pipes over one launch (rocprof's derived-metric definitions: VALUBusy =
+    4 SQ_ACTIVE_INST_VALU / SIMDs / shader cycles; LDS = SQ_LDS_IDX_ACTIVE / CUs / shader cycles; GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs), and the bound they name."""
+    if not entry or "GRBM_GUI_ACTIVE" not in entry:
+        return None
+    cyc = entry["GRBM_GUI_ACTIVE"] / 8.0
+    if cyc <= 0:
+        return None
+    valu = 4.0 * entry.get("SQ_ACTIVE_INST_VALU", 0.0) / 1024.0 / cyc
+    mfma = entry.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc
+    lds = entry.get("SQ_LDS_IDX_ACTIVE", 0.0) / 256.0 / cyc
+    conf = entry.get("SQ_LDS_BANK_CONFLICT", 0.0) / 256.0 / cyc
+    us = entry.get("avg_us", {}).get("SQ")
+    # (rocprof's VALUBusy counts 4 cycles per active VALU instruction-quad: a kernel that keeps the VALU saturated with
+    # instructions that issue faster can read a few percent above 1)
+    return dict(valu_busy=round(valu, 4), lds_busy=round(lds, 4), lds_bank_conflict=round(conf, 4), mfma_busy=round(mfma, 4),
+                shader_clock_ghz=round(cyc / us / 1e3, 3) if us else None, valu_insts_per_launch=entry.get("SQ_INSTS_VALU"))
+
+
+TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false, 3, 0>#large", "reslayer_split_kernel<8, true, false, false, 3, 0>",
+                     "reslayer_split_kernel<6, true, false, true, 3, 0>")
 
 
 def pmc_traffic_mlp(pieces=3):
     """HBM bytes per step of the tuple MLP's three cppf_reslayer_split launches (the gathered 360 -> 128 chain; 128 -> 256 with
-    the two 256-wide identity layers behind it; 256 -> 192 + bin draw: the launches `launch_ms` times) from the committed PMC passes; the
-    gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under its own
-    key (scratch/pmc_bench.sh splits a kernel's dispatches by duration).  None if absent."""
-    try:
-        cands = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
-        with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
-            d = _pmc_names(json.load(f), pieces)
-        if TUPLE_MLP_KERNELS[0] not in d:          # a profile written before the split by duration: all launches of a step
-            passes = d["vote_worklist_kernel"]["launches"]
-            tot = sum((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
-                      for k_, v in d.items() if k_.startswith("reslayer_split_kernel"))
-            return tot / passes if tot > 0 else None
-        if "reslayer_split_kernel<8, false, false, false>" in d:      # a profile of the four-launch form (rounds 2 - 3a)
+    the two 256-wide identity layers behind it; 256 -> 192 + bin draw: the launches `launch_ms` times), from this run's counter
+    passes; the gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under
+    its own key.  None when the passes did not run."""
+    tot = 0.0
+    for k_ in TUPLE_MLP_KERNELS:
+        k_ = k_.replace(", 3, 0>", ", %d, 0>" % pieces)
+        b_ = hbm_bytes(COUNTERS.get(k_) or COUNTERS.get(k_.replace("#large", "")))
+        if b_ is None:
             return None
-        return sum((2.0 * d[k_]["FETCH_SIZE_KB_per_launch"] + d[k_]["WRITE_SIZE_KB_per_launch"]) * 1024.0 for k_ in TUPLE_MLP_KERNELS)
-    except Exception:
-        return None
+        tot += b_
+    return tot
 
 
 def cpu_baseline(args, step):
@@ -587,7 +728,9 @@ def cpu_baseline(args, step):
         cores = os.cpu_count()
     return dict(value=args.cpu_scenes / dt, unit="scenes/s", cores=cores, kind="port",
                 sample="%d scene(s) of the same workload (first scenes of rank 0's batch), NumPy oracle + C SHOT "
-                       "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt)), agree
+                       "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt),
+                threads_per_stage={"shot_descriptor (C oracle, like PCL)": 1, "mlp_matmuls (NumPy -> BLAS)": "all cores (BLAS default)",
+                                   "decode / votes / back-vote / rotation bins (NumPy)": 1}), agree
 
 
 @torch.no_grad()
@@ -647,6 +790,30 @@ def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
     return out
 
 
+def cdist_forced():
+    return os.environ.get("CPPF_DIST_FORCE_COLLECTIVE", "0") not in ("", "0")
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One contiguous slice of the process' allowed cores per local rank (rank r of W gets cores [r c / W, (r + 1) c / W) of the
+    sorted list): the host threads of a rank -- launch loop, RCCL proxy, the allocator -- stay on one socket's cores instead of
+    migrating across all of them while eight ranks launch ~30 kernels per 12 ms step each.  GPUs 0..3 / 4..7 hang off sockets
+    0 / 1 on the 8-GPU boards, and core ids are socket-major, so contiguous slices in LOCAL_RANK order are NUMA-local as well.
+    CPPF_BENCH_NO_AFFINITY=1 leaves the affinity alone.  Returns the slice (or None)."""
+    if local_world <= 1 or os.environ.get("CPPF_BENCH_NO_AFFINITY"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except (AttributeError, OSError):
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) started without a launcher environment: run N FRESH rank processes (one per GPU,
     the environment torch.distributed.run would give them) and exit with their status; rank 0 prints the JSON line on the
@@ -675,19 +842,23 @@ def self_launch(args):
             env.pop(k_, None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd()))
+    # wait for the ranks without polling: the parent sleeps in waitpid until a child exits
     rc = 0
-    live = list(procs)
+    live = {p_.pid: p_ for p_ in procs}
     while live:
-        for p_ in list(live):
-            r_ = p_.poll()
-            if r_ is None:
-                continue
-            live.remove(p_)
-            if r_ != 0 and rc == 0:
-                rc = r_ if r_ > 0 else 1
-                for q_ in live:          # a failed rank leaves the others waiting in a collective: stop exactly those PIDs
-                    q_.terminate()
-        time.sleep(0.05)
+        try:
+            pid, status = os.waitpid(-1, 0)
+        except ChildProcessError:
+            break
+        p_ = live.pop(pid, None)
+        if p_ is None:
+            continue
+        r_ = os.waitstatus_to_exitcode(status)
+        p_.returncode = r_
+        if r_ != 0 and rc == 0:
+            rc = r_ if r_ > 0 else 1
+            for q_ in live.values():       # a failed rank leaves the others waiting in a collective: stop exactly those PIDs
+                q_.terminate()
     return rc
 
 
@@ -703,9 +874,26 @@ def main():
               "or run `python bench.py --gpus %d` without a launcher environment and it starts the ranks itself"
               % (args.gpus, world, args.gpus, args.gpus), file=sys.stderr)
         sys.exit(2)
+    if args.counter_child:              # a child of collect_counters: the bare single-stream loop, nothing else
+        args.single_stream = args.no_reference_order = args.no_native_arith = args.no_f16x2 = args.no_evidence = args.no_counters = True
+        args.cpu_scenes = 0
+    if world == 1 and rank == 0 and not args.no_counters and not cdist_forced():
+        # BEFORE this process initialises the GPU: fresh children under rocprofv3, one counter pass each
+        wl = ["--scenes-per-gpu", str(args.scenes_per_gpu), "--points", str(args.points), "--tuples", str(args.tuples), "--rots",
+              str(args.rots), "--seed", str(args.seed), "--vote-mode", str(args.vote_mode), "--workload", args.workload]
+        wl += ["--mlp-arith", args.mlp_arith] if args.mlp_arith else []
+        wl += ["--eager-scale-head"] if args.eager_scale_head else []
+        wl += ["--materialize-tuples"] if args.materialize_tuples else []
+        COUNTERS.clear()
+        COUNTERS.update(collect_counters(wl))
+    elif args.no_counters:
+        COUNTERS["reason"] = "--no-counters"
+    else:
+        COUNTERS["reason"] = "counter passes run at one rank only (N = 1)"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    affinity = pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     from cppf2_amd import dist as cdist
     backend = None
     if world > 1 or cdist.force_collective():
@@ -775,8 +963,9 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    def timed_loop(k, sample=True):
-        """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds."""
+    def timed_loop(k, sample=True, pair=None):
+        """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds.
+        pair = ([step_a, step_b], [stream_a, stream_b]): step i runs on stream i & 1 with that stream's own state."""
         # per-stage times come from up to EVENT_SLOTS steps spread evenly over the (headline) loop
         n_s = min(k, Step.EVENT_SLOTS) if sample else 0
         sampled = {int(round((j + 0.5) * k / n_s - 0.5)): j for j in range(n_s)}
@@ -784,7 +973,11 @@ def main():
         t0 = time.perf_counter()
         evs_ = []
         for i_ in range(k):
-            ev_ = step.run(timed=sampled.get(i_))
+            if pair is None:
+                ev_ = step.run(timed=sampled.get(i_))
+            else:
+                with torch.cuda.stream(pair[1][i_ & 1]):
+                    ev_ = pair[0][i_ & 1].run(timed=sampled.get(i_))
             if ev_ is not None:
                 evs_.append(ev_)
         sync()
@@ -806,7 +999,38 @@ def main():
                   file=sys.stderr)
         torch.cuda.synchronize()
         step.host_times = None
-    dt, evs = timed_loop(args.steps)
+    # ---- the headline loop.  Default (round 4): the product's batch mode -- consecutive steps, i.e. independent scene batches,
+    # alternate between TWO HIP streams, each with its own resident state (software pipelining: one batch's descriptor, voting and
+    # small MLP kernels run beside the other batch's wide matrix-core kernels).  Both pipelines hold the same scenes here, so
+    # their records must be byte-identical to each other and to a single-stream step's (checked below; `ok`).  The single-stream
+    # loop of rounds 1-3 is timed right after it with the same protocol (value_single_stream); --single-stream makes it the headline.
+    two = None
+    dt_single = None
+    pair = None
+    if not args.single_stream:
+        step.run()
+        torch.cuda.synchronize()
+        ref_rec = step.pipe.results.clone()
+        step_b = Step(args, rank, world, dev)
+        step_b.prepare_events()
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pair = ([step, step_b], streams)
+        for s_, st_ in zip(*pair):
+            st_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st_):
+                for _ in range(max(2, args.warmup)):
+                    s_.run()
+        torch.cuda.synchronize()
+        dt, evs = timed_loop(args.steps, pair=pair)
+        same = bool(torch.equal(step.pipe.results, ref_rec) and torch.equal(step_b.pipe.results, ref_rec))
+        dt_single, evs_single = timed_loop(args.steps)
+        two = {"streams": 2, "records_identical_to_single_stream": same,
+               "note": "steps alternate between two HIP streams with double-buffered state; records of both pipelines compared byte "
+                       "for byte with a single-stream step's in this run; per-stage times of the headline are measured on the stage's "
+                       "own stream while the other stream's kernels share the chip (per_stage_ms_single_stream: the same stages alone)"}
+    else:
+        dt, evs = timed_loop(args.steps)
+        evs_single = evs
     # the other placement of the scale head (see --eager-scale-head), measured the same way right after the headline
     # loop (untimed for the headline): the reference's forward order when the headline uses the kept-pairs-only order
     dt_other = None
@@ -848,41 +1072,6 @@ def main():
                          "max_abs_scale_difference": float(np.nanmax(np.abs(r16["scale"] - r3_["scale"]))),
                          "max_abs_translation_difference_m": float(np.nanmax(np.abs(r16["t"] - r3_["t"])))}
 
-    # Not the headline: consecutive steps (independent scene batches) alternating between TWO HIP streams, each with its own
-    # buffers, so that one step's descriptor / voting kernels run beside the other's matrix-core kernels.  Same loop protocol; both
-    # pipelines process the same scenes, and their records must be byte-identical to the single-stream ones (they were not always,
-    # until the cause -- a gfx950 packed-float32 erratum, profiles/r3_pk_op_sel_erratum.md -- was found and built out).
-    two = None
-    if world == 1 and not cdist.force_collective() and not args.no_two_streams:
-        step.run()
-        torch.cuda.synchronize()
-        ref_rec = step.pipe.results.clone()
-        step_b = Step(args, rank, world, dev)
-        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        pair = [step, step_b]
-        for s_, st_ in zip(pair, streams):
-            with torch.cuda.stream(st_):
-                s_.run()
-                s_.run()
-        k2 = args.steps
-        sync()
-        t0 = time.perf_counter()
-        for i_ in range(k2):
-            with torch.cuda.stream(streams[i_ & 1]):
-                pair[i_ & 1].run()
-        sync()
-        dt2 = time.perf_counter() - t0
-        same = bool(torch.equal(step.pipe.results, ref_rec) and torch.equal(step_b.pipe.results, ref_rec))
-        two = {"value": step.B * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
-               "records_identical_to_single_stream": same,
-               "note": "the same steps alternating between two HIP streams with double-buffered state (software pipelining: the "
-                       "small kernels of one step run beside the other step's MLP kernels); records compared byte for byte with the "
-                       "single-stream ones in this run; not the headline: `value` is the one-stream figure whose kernels rocprof times "
-                       "one at a time (DESIGN.md section 11)"}
-        if not same and rank == 0:
-            print("bench.py: WARNING: the two-stream loop's records differ from the single-stream ones (see two_streams in the line)", file=sys.stderr)
-        del step_b
-
     if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
         for i_, ev in enumerate(evs):
             row = {n1: round(e0.elapsed_time(e1), 3) for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:])}
@@ -893,6 +1082,18 @@ def main():
     for ev in evs:
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
+    stage_ms_single = {}
+    for ev in evs_single:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms_single[n1] = stage_ms_single.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs_single)
+    step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
+    # With two streams a stage's HIP-event time on its own stream includes the time its kernels wait for the other stream's (two
+    # persistent matrix-core kernels do not fit a CU together): the kernels' own durations -- what the roofline divides by -- are
+    # the stage times of the single-stream loop of the same run (rocprofv3 shows the same durations in both modes,
+    # profiles/r4_two_stream_trace.txt).  stage_ms_2s keeps the two-stream stage times for the record.
+    stage_ms_2s = stage_ms
+    if dt_single is not None:
+        stage_ms = stage_ms_single
 
     failed = False
     if rank == 0:
@@ -916,22 +1117,58 @@ def main():
             gbs = (ab / 1e9) / (ms / 1e3) if ms > 0 and ab else 0.0
             rows.append((s, ms, ab / 1e6, gbs))
             if s in hip_stages:
+                # every stage with the bound that limits ITS kernel: the streaming kernels against the HBM peak
+                # (algorithmic bytes / time; the counters' bytes beside them), the voting and descriptor kernels by the busy
+                # fraction of the unit they saturate (VALU or LDS, from this run's SQ counter pass) with their work in the
+                # domain's units (votes, cone tests, points) per second; the latency-bound ones (one workgroup per scene,
+                # dependent phases) carry no fraction
                 tr = pmc_traffic(s)
-                per_kernel[s] = dict(kernel=STAGE_KERNEL.get(s), ms=round(ms, 4), alg_MB=round(ab / 1e6, 2),
-                                     alg_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                                     pmc_MB=None if tr is None else round(tr / 1e6, 2),
-                                     pmc_frac=None if (tr is None or ms <= 0) else round(tr / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4))
+                act = unit_activity(counter_entry(STAGE_KERNEL.get(s, "")))
+                e = dict(kernel=STAGE_KERNEL.get(s), ms=round(ms, 4), alg_MB=round(ab / 1e6, 2),
+                         pmc_MB=None if tr is None else round(tr / 1e6, 2), activity=act)
+                kind = STAGE_BOUND.get(s, "latency")
+                if kind == "hbm":
+                    e.update(bound="hbm", alg_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                             pmc_frac=None if (tr is None or ms <= 0) else round(tr / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4))
+                elif kind == "unit":
+                    if act is not None:
+                        unit = "valu" if act["valu_busy"] >= act["lds_busy"] else "lds"
+                        e.update(bound=unit, frac=act[unit + "_busy"], frac_kind="busy cycles of the %s pipe / shader cycles of the launch "
+                                 "(SQ counters of this run)" % unit.upper())
+                    else:
+                        e.update(bound="valu", frac=None, frac_kind="no SQ counter pass in this run (%s)" % COUNTERS.get("reason", "--no-counters"))
+                    sec = ms / 1e3 if ms > 0 else float("nan")
+                    if s == "vote_center":
+                        e["work"] = {"votes_per_launch": B * T * R, "votes_per_s": B * T * R / sec}
+                    elif s == "rot_bins":
+                        tf = T // 10
+                        e["work"] = {"candidates_per_launch": 2 * B * tf * R, "candidates_per_s": 2 * B * tf * R / sec,
+                                     "exhaustive_equivalent_compare_accumulates_per_s": 2.0 * B * tf * R * S / sec,
+                                     "note": "the lookup table tests <= 8 bins per candidate (0.46 on average) where the "
+                                             "reference's mm tests all %d" % S}
+                    elif s in ("shot_frames", "shot352"):
+                        e["work"] = {"points_per_launch": B * N, "points_per_s": B * N / sec}
+                else:
+                    e.update(bound="latency", frac=None, frac_kind="one workgroup per scene / dependent phases: neither a "
+                                                                   "bandwidth nor an issue bound applies")
+                per_kernel[s] = e
         dom_ms = stage_ms[dominant]
         dom_bytes = algorithmic_bytes(dominant, B, N, T, R, S, G)
         achieved = (dom_bytes / 1e9) / (dom_ms / 1e3)
         hip_only_ms = sum(stage_ms.get(s, 0.0) for s in hip_stages)
         path_bytes = sum(algorithmic_bytes(s, B, N, T, R, S, G) for s in hip_stages)
-        step_ms = 1e3 * dt / args.steps
+        step_ms = 1e3 * (dt_single if dt_single is not None else dt) / args.steps      # the step the stage times belong to
         roofline = dict(bound="hbm", kernel=dominant, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms,
                         kernel_name=STAGE_KERNEL.get(dominant),
                         algorithmic_bytes_per_launch=dom_bytes,
-                        algorithmic_model="SURVEY.md 8d per-scene bytes x %d scenes per launch" % B,
+                        algorithmic_model=("compulsory bytes of the stage as it runs here x %d scenes per launch (bench.py:"
+                                           "algorithmic_bytes): SURVEY.md 8d's per-scene figures, except the tuple encode in its "
+                                           "gathered form (indices + points + normals in, 40 pair features + 5 global indices per "
+                                           "tuple out: 4.1 MB per scene instead of 8d's 30.35 MB of rows) and the decode behind "
+                                           "the fused bin draw (bins in, vote parameters out)" % B),
+                        traffic_source=("rocprofv3 counter passes of this run (2 x FETCH_SIZE + WRITE_SIZE, separate passes, fresh "
+                                        "child processes)" if "reason" not in COUNTERS else "null: " + str(COUNTERS.get("reason"))),
                         # the whole path's algorithmic bytes (HIP stages; ~54 MB/scene) over the whole step
                         # (MLP included) and over the HIP stages alone, as fractions of the HBM peak
                         pipeline_bytes_per_step=path_bytes,
@@ -942,7 +1179,12 @@ def main():
                         mlp_ms=sum(stage_ms.get(s, 0.0) for s in mlp_stages),
                         stages_sharing_the_chip_with_torch=sorted(shared),
                         per_kernel=per_kernel,
-                        per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES})
+                        per_stage_ms={s: round(stage_ms.get(s, 0.0), 4) for s in Step.STAGES},
+                        per_stage_ms_source=("the single-stream loop of this run (kernel durations; with two streams a stage's "
+                                             "event time also counts the waits for the other stream's kernels: "
+                                             "per_stage_ms_two_streams)" if dt_single is not None else "the headline loop"),
+                        per_stage_ms_two_streams=({s: round(stage_ms_2s.get(s, 0.0), 4) for s in Step.STAGES}
+                                                  if dt_single is not None else None))
         if _models.MLP_ARITH in ("split", "split16"):
             nprod = 6.0 if _models.MLP_ARITH == "split" else 3.0
             # The dominant kernel of the step is the tuple MLP (cppf_reslayer_split, 3 launches back to back: the stage
@@ -958,13 +1200,16 @@ def main():
             algorithmic = sum(layer_flops(*l)[1] for l in layers) * B * T
             mlp_ms_ = stage_ms["tuple_mlp"]
             hbm = {k_: roofline[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
-                                               "kernel_name", "algorithmic_bytes_per_launch", "algorithmic_model")}
+                                               "kernel_name", "algorithmic_bytes_per_launch", "algorithmic_model", "traffic_source")}
             roofline.update(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel",
                             achieved=executed / 1e12 / (mlp_ms_ / 1e3), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=executed / 1e12 / (mlp_ms_ / 1e3) / BF16_MFMA_PEAK_TFLOPS, traffic=pmc_traffic_mlp(3 if nprod == 6.0 else 2),
                             launch_ms=mlp_ms_, launches=3,
                             frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
-                            traffic_covers="the same 3 launches as launch_ms (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
+                            traffic_covers="the same 3 launches as launch_ms (counter passes of this run: 2 x FETCH_SIZE + WRITE_SIZE)",
+                            mfma_busy_per_launch={k_: (unit_activity(COUNTERS.get(k_.replace(", 3, 0>", ", %d, 0>" % (3 if nprod == 6.0 else 2)))
+                                                                     or COUNTERS.get(k_.replace("#large", "").replace(", 3, 0>", ", %d, 0>" % (3 if nprod == 6.0 else 2)))) or {})
+                                                  for k_ in TUPLE_MLP_KERNELS},
                             executed_bf16_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
                             algorithmic_f32_tflops=algorithmic / 1e12 / (mlp_ms_ / 1e3), f32_input_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS,
                             # the same launch time against the other two readings of "algorithmic / peak"
@@ -1010,8 +1255,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SHOT model, %d scenes/GPU x %d pts x %d tuples x %d rots, "
                                    "720 sphere bins, res 2 mm, bottle axes; random-init weights + teacher prior; scale head on %s; "
-                                   "MLP arithmetic: %s; tuple rows %s"
+                                   "%s; MLP arithmetic: %s; tuple rows %s"
                                    % (B, N, T, R, "all tuples" if args.eager_scale_head else "the kept pairs only",
+                                      "every step on one HIP stream" if args.single_stream else
+                                      "consecutive steps alternate between two HIP streams (double-buffered state)",
                                       "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
                                       "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
                                       if _models.MLP_ARITH == "split" else
@@ -1032,9 +1279,18 @@ def main():
             # not exact there -- its error against float64 is under mlp_error_vs_f64.split_f16x2)
             "value_f16x2_mfma": (total_scenes / dt_f16) if dt_f16 else None,
             "f16x2_agreement": f16_agreement,
-            # the same steps alternating between two HIP streams (not the headline; see the note inside)
+            # the headline's stream mode; value_single_stream = the same steps on ONE stream (rounds 1-3), same loop protocol
             "two_streams": two,
+            "value_single_stream": (total_scenes / dt_single) if dt_single else None,
+            "ms_per_step_single_stream": (1e3 * dt_single / args.steps) if dt_single else None,
+            # first-event to last-event time of the sampled steps on their own stream (with two streams a step overlaps the next)
+            "step_ms_sampled": {"min": round(step_times[0], 4), "median": round(step_times[len(step_times) // 2], 4),
+                                "max": round(step_times[-1], 4), "n": len(step_times)},
             "records_gathered": int(all_rec.shape[0]),
+            # SHA-256 of the gathered records in global scene order: equal for every world size and stream mode (the records
+            # depend on the global scene id only)
+            "records_sha256": __import__("hashlib").sha256(all_rec.tobytes()).hexdigest(),
+            "host_cores_of_rank0": affinity,
             # the path's one collective: all_gather of the 160-byte scene records, HIP-event time of the stage
             "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
                            "op": "all_gather_into_tensor" if backend == "nccl" else ("all_gather" if backend else None),

@@ -98,6 +98,20 @@ class VotingPipeline:
         self.nb = 32
         self.ws = e((max(self.ws_vote_bytes, self.ws_bv_bytes, self.ws_rot_bytes, 256),), dtype=torch.uint8, device=d)
 
+    def twin(self):
+        """A second pipeline of the same batch geometry with working buffers of its own (bins, vote parameters, kept lists,
+        workspace) that shares THIS pipeline's result slots, losses and selection buffers: the two model passes of the ensemble
+        (eval.py:219) -- or two consecutive batches -- can then run on two HIP streams at once, each pass writing its own
+        record slot, and select() / the final read see both.  The caller orders the streams (the SHOT pass' alignment loss reads
+        the DINO pass' scale: an event between assemble() on one stream and alignment_loss() on the other)."""
+        t = VotingPipeline(self.np_, self.nt_, k=self.k, res=self.res, num_rots=self.R, angle_tol=self.angle_tol,
+                           backproj_ratio=self.ratio, imp_wt_margin=self.margin, bmm_size=self.bmm, cfg_up=self.cfg_up,
+                           cfg_right=self.cfg_right, cfg_front=self.cfg_front, cells_cap=self.cells_cap, vote_mode=self.vote_mode,
+                           sphere_pts=self.sphere_np, device=self.dev, trig=(self.cs, self.sn))
+        t.result_slots, t.selected, t.losses, t.best = self.result_slots, self.selected, self.losses, self.best
+        t.results = t.result_slots[0]
+        return t
+
     # -- stages ---------------------------------------------------------------------------------
     def decode(self, pts, idx, logits, uniforms, prior=None):
         """prior (optional, same shape as logits) is added to the logits inside the kernel (== logits + prior)."""

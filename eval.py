@@ -95,15 +95,31 @@ def needed_cells(pc, res):
     return int(np.prod(ext.astype(np.int64) + 1))
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """The two HIP streams the model passes of run_ensemble run on (one pair per device for the life of the process: scratch
+    buffers keyed by stream are reused from call to call)."""
+    key = str(torch.device(dev))
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    return _SIDE_STREAMS[key]
+
+
 @torch.no_grad()
 def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_pairs, num_rots, angle_tol=1.,
                  imp_wt_margin=0.01, backproj_ratio=.1, opt=False, geo_branch=True, visual_branch=True, up_sym=False,
-                 priors=None, keep=False, scale_priors=None):
+                 priors=None, keep=False, scale_priors=None, two_streams=True):
     """eval.py:207-372 for a batch of instances of one category.  pcs: list of float32 [N_b,3]; descs: list of float32
     [N_b,1024] (DINOv2 features at the points: inputs to the path); priors: optional callable(idx_global, base) -> logit
     prior [T,6,nb] added to both models' logits; scale_priors: optional float32 [B,3] teacher box extents that stand in for
     the scale head of random-init weights (the head's output stays in the sum at 1e-3).  Returns dict(records=[2 x
-    structured array], losses float64 [2,B], pick int [B], scale, scale_norm, idx, pipe, ...)."""
+    structured array], losses float64 [2,B], pick int [B], scale, scale_norm, idx, pipe, ...).
+    two_streams (default): the DINO pass and the SHOT pass (descriptors included) run on two HIP streams at once, each with
+    working buffers of its own (VotingPipeline.twin) -- one pass' voting and descriptor kernels beside the other's wide
+    matrix-core kernels; the only cross-stream dependency is the DINO pass' scale, which scores the SHOT pass too
+    (eval.py:308-310).  Same records as the one-stream order (keep=True, which hands out intermediates, uses that order)."""
     dev = ops._dev()
     B = len(pcs)
     Ns = [int(p.shape[0]) for p in pcs]
@@ -121,53 +137,72 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                           cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
     # eval.py:207 -- one tuple table per instance, shared by both models
     idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in zip(scene_ids, Ns)])
-    # eval.py:210-216
-    shot_feat, normal = shot.compute_device(pts, pipe.pt_off, cfg.res * 10, cfg.res * 10)
-    shot_feat = ops.nan_to_zero_(shot_feat)
-    normal = ops.nan_to_zero_(normal)
     desc = torch.from_numpy(np.concatenate(descs)).to(dev)
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
     prior = priors(idx, base) if priors is not None else None
     scale_prior = None
     if scale_priors is not None:
         scale_prior = torch.from_numpy(np.asarray(scale_priors, dtype=np.float32)).to(dev).repeat_interleave(num_pairs, 0)
-
-    feat_shot = shot_model.encode_points(shot_feat)
+    two = bool(two_streams) and not keep
+    main = torch.cuda.current_stream(dev)
+    streams = _side_streams(dev) if two else [main, main]
+    pipes = [pipe, pipe.twin() if two else pipe]
+    for st_ in streams:
+        st_.wait_stream(main)
     kept = []
-    scales_buf = torch.zeros((pipe.Ttot, 3), dtype=torch.float32, device=dev)
-    for model_idx in (0, 1):                                                               # eval.py:219
+    extra = {}
+    dino_scored = torch.cuda.Event() if two else None
+
+    def one_pass(model_idx):
         model = (dino_model, shot_model)[model_idx]
-        pipe.use_slot(model_idx)                     # each pass writes its own records; nothing is read back before the end
+        pp = pipes[model_idx]
+        pp.use_slot(model_idx)                       # each pass writes its own records; nothing is read back before the end
+        scales_buf = torch.zeros((pp.Ttot, 3), dtype=torch.float32, device=dev)
         u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
         # eval.py:225-229 (the bin draw) runs as the epilogue of the logit head's output layer when the kernels allow it (split
         # arithmetic, no intermediates requested): the heads then return None in place of the logits.  The scale head is
         # evaluated after the back-vote filter, on the kept pairs' rows only (eval.py:272 reads nothing else).
-        draw = None if keep else (u, None if prior is None else prior.contiguous(), pipe.bins)
+        draw = None if keep else (u, None if prior is None else prior.contiguous(), pp.bins)
         if model_idx == 0:
             # train_dino.py:91-97, 128-133 without its rows: per-point slot tables + coordinate columns, summed by the first
             # ResLayer's kernel; every layer is a kernel of the library
-            pred_cls, second = dino_model.heads_from_tuples(pts, desc, idx, pipe.pt_off, pipe.tup_off, lazy_scale=not keep, decode=draw)
+            pred_cls, second = dino_model.heads_from_tuples(pts, desc, idx, pp.pt_off, pp.tup_off, lazy_scale=not keep, decode=draw)
         else:
-            # train_shot.py:75-83 + :100-111; the tuple rows are gathered inside the first ResLayer's kernel
-            pred_cls, second = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pipe.pt_off, pipe.tup_off,
+            # eval.py:210-216, then train_shot.py:75-83 + :100-111; the tuple rows are gathered inside the first ResLayer's kernel
+            shot_feat, normal = shot.compute_device(pts, pp.pt_off, cfg.res * 10, cfg.res * 10)
+            shot_feat = ops.nan_to_zero_(shot_feat)
+            normal = ops.nan_to_zero_(normal)
+            extra["shot_feat"], extra["normal"] = shot_feat, normal
+            feat_shot = shot_model.encode_points(shot_feat)
+            pred_cls, second = shot_model.heads_from_tuples(pts, idx, feat_shot, normal, pp.pt_off, pp.tup_off,
                                                             lazy_scale=not keep, decode=draw)
         raw_cls = pred_cls
         if prior is not None and pred_cls is not None:
             pred_cls = pred_cls + prior
 
-        def scales(model=model, second=second):
-            s_ = second if keep else model.scale_head_rows(second, pipe.kept_rows32(),
-                                                           scatter=(pipe.kept_count, pipe.max_kept, scales_buf))
+        def scales():
+            s_ = second if keep else model.scale_head_rows(second, pp.kept_rows32(),
+                                                           scatter=(pp.kept_count, pp.max_kept, scales_buf))
             return (scale_prior + 1e-3 * s_).contiguous() if scale_prior is not None else s_.contiguous()
         pred_scales = scales() if keep else scales
-        pipe.vote(pts, idx, None if pred_cls is None else pred_cls.contiguous(), u, pred_scales)
+        pp.vote(pts, idx, None if pred_cls is None else pred_cls.contiguous(), u, pred_scales)
         if opt:
-            pipe.refine(pts, idx, up_sym)                                                  # eval.py:319-355
-        pipe.alignment_loss(pts, idx, up_sym)                  # eval.py:358-363; the DINO pass' scale scores both passes
+            pp.refine(pts, idx, up_sym)                                                    # eval.py:319-355
+        if two and model_idx == 0:
+            dino_scored.record()                     # the DINO pass' records (scale) are final
+        if two and model_idx == 1:
+            torch.cuda.current_stream(dev).wait_event(dino_scored)
+        pp.alignment_loss(pts, idx, up_sym)                    # eval.py:358-363; the DINO pass' scale scores both passes
         if keep:
-            kept.append(dict(bins=pipe.bins.cpu().numpy(), mask=pipe.mask.cpu().numpy().astype(bool),
+            kept.append(dict(bins=pp.bins.cpu().numpy(), mask=pp.mask.cpu().numpy().astype(bool),
                              pred_cls=pred_cls.cpu().numpy(), raw_cls=raw_cls.cpu().numpy(), pred_scales=pred_scales.cpu().numpy(), u=u.cpu().numpy(),
-                             counts=pipe.counts.cpu().numpy()))
+                             counts=pp.counts.cpu().numpy()))
+
+    for model_idx in (0, 1):                                                               # eval.py:219
+        with torch.cuda.stream(streams[model_idx]):
+            one_pass(model_idx)
+    for st_ in streams:
+        main.wait_stream(st_)
     # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first -- on the device ---------
     pipe.select(geo_branch, visual_branch)
     records = [pipe.results_to_numpy(pipe.result_slots[m]) for m in (0, 1)]                # the 160-byte records: the first read
@@ -186,7 +221,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                scale_norm=scale_norm.astype(np.float64), idx=idx, pipe=pipe, pts=pts)
     if keep:
         out["kept"] = kept
-        out["shot_feat"], out["normal"] = shot_feat.cpu().numpy(), normal.cpu().numpy()
+        out["shot_feat"], out["normal"] = extra["shot_feat"].cpu().numpy(), extra["normal"].cpu().numpy()
     return out
 
 

@@ -27,14 +27,14 @@ _LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_A
                "CPPF_DIST_FORCE_COLLECTIVE")
 
 
-def _start_bench(tmpdir, tag, argv, **env_add):
+def _start_bench(tmpdir, tag, argv, scenes=4, counters=False, **env_add):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
     env.update(env_add)
     out = open(os.path.join(tmpdir, tag + ".out"), "w")
     err = open(os.path.join(tmpdir, tag + ".err"), "w")
-    small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", "4", "--cpu-scenes", "0", "--no-reference-order",
-             "--no-native-arith"]
+    small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
+             "--no-native-arith"] + ([] if counters else ["--no-counters"])
     return (subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + argv + small, env=env, stdout=out,
                              stderr=err, cwd=ROOT), out.name, err.name)
 
@@ -46,8 +46,16 @@ def _start_bench_jobs(tmpdir):
       GPU 0, so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks);
     * rccl_one_rank: `bench.py --gpus 1` with CPPF_DIST_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...) and
       the path's all_gather (plus the bench's barrier and all_reduce) really run through RCCL, in a one-rank group;
-    * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly."""
+    * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly;
+    * eight_ranks / one_rank_16: the 8-rank launch path without 8 GPUs -- `bench.py --gpus 8 --scenes-per-gpu 2` starts eight
+      fresh ranks that share GPU 0 over gloo (port allocation, LOCAL_RANK % visible GPUs, per-rank core slices and TunableOp
+      directories); its 16 gathered records must equal, in global scene order, those of one rank holding all 16 scenes."""
     return {
+        # the counter passes of a default run: bench.py starts rocprofv3 children of itself before it touches the GPU
+        "counters": _start_bench(tmpdir, "counters", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], counters=True),
+        "eight_ranks": _start_bench(tmpdir, "eight_ranks", ["--gpus", "8", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=2,
+                                    CPPF_BENCH_BACKEND="gloo"),
+        "one_rank_16": _start_bench(tmpdir, "one_rank_16", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=16),
         "two_ranks": _start_bench(tmpdir, "two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo"),
         "rccl_one_rank": _start_bench(tmpdir, "rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1",
                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),

@@ -192,3 +192,24 @@ def test_run_ensemble_is_the_same_with_the_bin_draw_fused_into_the_mlp(ev):
     for m in (0, 1):
         assert a["records"][m].tobytes() == b["records"][m].tobytes()
     assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["pick"], b["pick"])
+
+
+def test_run_ensemble_on_two_streams_equals_the_one_stream_order(ev):
+    """The product's batch mode (DINO pass and SHOT pass on two HIP streams, twin pipelines) writes the same records, losses and
+    picks as the one-stream order -- three times in a row (the streams and their scratch buffers are reused)."""
+    N, T, R, seed = 2048, 12000, 90, 1
+    torch.manual_seed(5)
+    cfg, dino_model, shot_model = ev.load_category("mug")
+    scene_ids = [3, 4, 5]
+    scenes = [synth.make_scene(seed, s_, N) for s_ in scene_ids]
+    g = torch.Generator(device="cpu").manual_seed(9)
+    descs = [torch.nn.functional.normalize(torch.randn((N, 1024), generator=g), dim=-1).numpy() for _ in scenes]
+    priors = ev._teacher_prior(np.concatenate([s_["pc_canon"] for s_ in scenes]), torch.device("cuda"))
+    kw = dict(opt=True, up_sym=False, priors=priors, scale_priors=np.stack([s_["extent"] for s_ in scenes]))
+    a = ev.run_ensemble(cfg, dino_model, shot_model, [s_["pc"] for s_ in scenes], descs, seed, scene_ids, T, R, two_streams=False, **kw)
+    for _ in range(3):
+        b = ev.run_ensemble(cfg, dino_model, shot_model, [s_["pc"] for s_ in scenes], descs, seed, scene_ids, T, R, two_streams=True, **kw)
+        for m in (0, 1):
+            assert a["records"][m].tobytes() == b["records"][m].tobytes()
+        assert a["selected"].tobytes() == b["selected"].tobytes()
+        assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["pick"], b["pick"])

@@ -140,6 +140,41 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["pose_5deg5cm_vs_gt"] == 1.0
 
 
+def test_bench_measures_its_counters_in_the_run():
+    """roofline.traffic and the per-kernel unit activity come from rocprofv3 passes bench.py runs itself (fresh children, before
+    it initialises the GPU) -- not from files under profiles/."""
+    rc, out, err = _job("counters")
+    assert rc == 0, err[-3000:]
+    j = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    r = j["roofline"]
+    assert r["traffic"] is not None and r["traffic"] > 0, r.get("hbm", {}).get("traffic_source")
+    assert "counter passes of this run" in r["hbm"]["traffic_source"]
+    vc = r["per_kernel"]["vote_center"]
+    assert vc["bound"] in ("valu", "lds") and 0.05 < vc["frac"] <= 1.0 and vc["work"]["votes_per_s"] > 0
+    assert vc["activity"]["valu_busy"] > 0 and vc["pmc_MB"] is not None
+    assert r["per_kernel"]["encode_tuples"]["bound"] == "hbm" and r["per_kernel"]["assemble_pose"]["bound"] == "latency"
+    busy = [v.get("mfma_busy") for v in r["mfma_busy_per_launch"].values()]
+    assert all(b is not None and 0.05 < b < 1.0 for b in busy), busy
+
+
+def test_bench_eight_ranks_dry_run_equals_one_rank():
+    """SURVEY 8e on the hardware there is: eight fresh rank processes (bench.py's own launcher) sharing GPU 0 over gloo, two
+    scenes each; the 16 records gathered in global scene order are byte-identical to one rank's 16 (records_sha256)."""
+    rc8, out8, err8 = _job("eight_ranks")
+    assert rc8 == 0, err8[-3000:]
+    rc1, out1, err1 = _job("one_rank_16")
+    assert rc1 == 0, err1[-3000:]
+    j8 = json.loads([ln for ln in out8.splitlines() if ln.startswith("{")][0])
+    j1 = json.loads([ln for ln in out1.splitlines() if ln.startswith("{")][0])
+    assert j8["n_gpus"] == 8 and j8["records_gathered"] == 16 and j8["collective"]["world"] == 8 and j8["config"]["scenes_per_gpu"] == 2
+    assert j1["n_gpus"] == 1 and j1["records_gathered"] == 16
+    assert j8["records_sha256"] == j1["records_sha256"]
+    assert j8["pose_5deg5cm_vs_gt"] == 1.0 and j8["ok"] and j1["ok"]
+    # rank 0 of eight was pinned to its slice of the host cores (an eighth of them; None only if the box exposes < 8 cores)
+    cores = j8["host_cores_of_rank0"]
+    assert cores is None or cores[0] == min(cores)
+
+
 def test_bench_gathers_through_rccl_in_a_one_rank_group():
     """The `nccl` branch of bench.py / cppf2_amd.dist on the hardware there is: init_process_group("nccl", device_id=...),
     all_gather_into_tensor of the device-resident records, barrier and all_reduce, world size 1.  bench.py itself asserts
