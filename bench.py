@@ -121,10 +121,12 @@ def parse():
     ap.add_argument("--no-counters", action="store_true",
                     help="skip the rocprofv3 counter passes (roofline.traffic and the unit-activity fractions are then null)")
     ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)      # set by collect_counters for its children
-    ap.add_argument("--workload", choices=("shot", "ensemble"), default="shot",
+    ap.add_argument("--workload", choices=("shot", "ensemble", "dense64k"), default="shot",
                     help="shot (default, the headline): BASELINE configs[1], the SHOT model; ensemble: BASELINE configs[2], the "
                          "reference's real per-instance loop (eval.py:219-372) -- the DINO model AND the SHOT model vote every "
-                         "instance, the pose with the smaller alignment loss is kept; value = instances/s")
+                         "instance, the pose with the smaller alignment loss is kept; value = instances/s; dense64k: BASELINE "
+                         "configs[4], 65 536 pairs per scene, float16 feature table, uncertainty-weighted centre votes (extensions "
+                         "the reference does not have; --tuples is ignored, --scenes-per-gpu defaults to 16)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-stage table to stderr")
     return ap.parse_args()
 
@@ -355,6 +357,127 @@ class EnsembleStep(Step):
         return self.ev
 
 
+class DenseStep(Step):
+    """BASELINE configs[4] (YCB-V instance-level: 65 536 pairs per scene, float16 per-point features, uncertainty-weighted centre
+    votes -- extensions, pinned by the oracle's restatement only: tests/test_gpu_parity.py).  The SHOT model's path with the tuple
+    rows materialised from the float16 table (cppf_encode_tuples_shot_f16) and per-pair vote weights in [0, 4] (fixed-point
+    accumulator, cppf_vote_center's vote_wt); the weights here are a resident synthetic confidence per pair."""
+
+    STAGES = ["sample_tuples", "shot_frames", "shot352", "shot_encoder", "cast_f16", "encode_tuples_f16", "tuple_mlp", "decode_bins",
+              "vote_frames", "vote_center_weighted", "backvote_filter", "rot_bins", "scale_head", "assemble_pose", "gather"]
+
+    def __init__(self, args, rank, world, dev):
+        args.tuples = 65536
+        super().__init__(args, rank, world, dev)
+        ids = tuple(range(self.scene0, self.scene0 + self.B))
+        self.vote_wt = (self.ops.philox_uniform(self.T, 1, args.seed, 7, ids, dev).reshape(-1) * 2.0).contiguous()    # untimed setup
+        self.feat16 = torch.empty((self.B * self.N, 64), dtype=torch.float16, device=dev)
+
+    @torch.no_grad()
+    def run(self, timed=None):
+        from cppf2_amd import shot as shotmod
+        from cppf2_amd.models import fused_stack
+        ops, pipe, a = self.ops, self.pipe, self.args
+        B, N, T = self.B, self.N, self.T
+        ids = tuple(range(self.scene0, self.scene0 + B))
+        self.ev = [] if timed is not None else None
+        self.ev_slot = timed
+        self._mark("start")
+        idx = ops.sample_tuples(N, T, 5, a.seed, ids, self.dev)
+        self._mark("sample_tuples")
+        shotmod.prepare_device(self.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, self.normal)
+        self._mark("shot_frames")
+        shot = shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot, nan_to_zero=True)
+        self._mark("shot352")
+        normal = ops.nan_to_zero_(self.normal)
+        feat = self.model.encode_points(shot)
+        self._mark("shot_encoder")
+        ops.cast_f16(feat, out=self.feat16)
+        self._mark("cast_f16")
+        u = ops.philox_uniform(T, 6, a.seed, 1, ids, self.dev)
+        x = ops.encode_tuples_shot(self.pts, idx, self.feat16, normal, pipe.pt_off, pipe.tup_off)      # [T, 360] float32 rows
+        self._mark("encode_tuples_f16")
+        _, tf = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), x, decode=(u, self.prior, pipe.bins))
+        self._mark("tuple_mlp")
+        pipe.decode_from_bins(self.pts, idx)
+        self._mark("decode_bins")
+        pipe.vote_center(self.pts, idx, vote_wt=self.vote_wt, phase=1)
+        self._mark("vote_frames")
+        pipe.vote_center(self.pts, idx, vote_wt=self.vote_wt, phase=2)
+        self._mark("vote_center_weighted")
+        pipe.backvote(self.pts, idx)
+        self._mark("backvote_filter")
+        pipe.rot_bins(self.pts, idx)
+        self._mark("rot_bins")
+        scales = self.model.scale_head_rows(tf, pipe.kept_rows32(), scatter=(pipe.kept_count, pipe.max_kept, self.scales_buf))
+        self._mark("scale_head")
+        pipe.assemble(scales)
+        self._mark("assemble_pose")
+        self.all_records = self.dist.gather_results(pipe.results, B * self.world, out=self.records_buf)
+        self._mark("gather")
+        return self.ev
+
+
+def report_dense(args, step, dt, evs, world, backend):
+    """The JSON line of --workload dense64k (rank 0): contract fields, per-stage times, the two extension kernels' rooflines."""
+    from cppf2_amd import models as _models
+    B, N, T, R = step.B, step.N, step.T, args.rots
+    stage_ms = {}
+    for ev in evs:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
+    rec = step.pipe.results_to_numpy()
+    all_rec = step.pipe.results_to_numpy(step.all_records)
+    assert all_rec.shape[0] == B * world and np.array_equal(all_rec[:B].tobytes(), rec.tobytes())
+    ok = 0
+    for b in range(B):
+        sc = step.scenes[b]
+        terr = np.linalg.norm(rec["t"][b] - sc["t"])
+        cosang = abs(float(rec["R"][b][:, 1] @ sc["R"][:, 1]))
+        ok += int(terr < 0.05 and np.degrees(np.arccos(min(cosang, 1.0))) < 5.0)
+    nprod = 6.0 if _models.MLP_ARITH == "split" else 3.0
+    ex, al = tuple_mlp_flops("shot", B, T, N, nprod)
+    enc_bytes = B * (T * 5 * 4 + N * 24 + N * 64 * 2 + T * 360 * 4)                 # indices + points + normals + f16 table in, rows out
+    enc_ms, vc_ms, mlp_ms = stage_ms["encode_tuples_f16"], stage_ms["vote_center_weighted"], stage_ms["tuple_mlp"]
+    enc_c = counter_entry("encode_shot_f16_kernel")
+    vc_act = unit_activity(counter_entry("vote_center_persist_kernel<true>"))
+    total = B * world * args.steps
+    line = {
+        "metric": "scenes/sec (1/2/4/8 GPU) at 4096 pts x 20k tuples; 5deg5cm match vs ref",
+        "value": total / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: dense pairs -- %d scenes/GPU x %d pts x %d tuples x %d rots, SHOT model, float16 "
+                               "per-point feature table (tuple rows materialised from it), per-pair vote weights in [0, 4] on the "
+                               "fixed-point centre accumulator (extensions the reference does not have); random-init weights + teacher "
+                               "prior; MLP arithmetic %s; one HIP stream" % (B, N, T, R, _models.MLP_ARITH),
+                   "scenes_per_gpu": B, "points": N, "tuples": T, "rots": R, "parallelism": "scene-sharded x%d" % world},
+        "pairs_per_s": total * T / dt,
+        "roofline": dict(bound="mfma", kernel="tuple_mlp", kernel_name="reslayer_split_kernel", achieved=ex / 1e12 / (mlp_ms / 1e3),
+                         peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ex / 1e12 / (mlp_ms / 1e3) / BF16_MFMA_PEAK_TFLOPS,
+                         traffic=None, launch_ms=mlp_ms, launches=3, frac_kind="executed_bf16_mfma" if nprod == 6.0 else "executed_fp16_mfma",
+                         algorithmic_f32_flops_per_step=al,
+                         per_kernel={
+                             "encode_tuples_f16": dict(kernel="encode_shot_f16_kernel", bound="hbm", ms=round(enc_ms, 4), alg_MB=round(enc_bytes / 1e6, 1),
+                                                       alg_GBs=round(enc_bytes / 1e9 / (enc_ms / 1e3), 1),
+                                                       frac=round(enc_bytes / 1e9 / (enc_ms / 1e3) / HBM_PEAK_GBS, 4),
+                                                       pmc_MB=None if hbm_bytes(enc_c) is None else round(hbm_bytes(enc_c) / 1e6, 1)),
+                             "vote_center_weighted": dict(kernel="vote_center_persist_kernel<true>", bound="valu", ms=round(vc_ms, 4),
+                                                          frac=None if vc_act is None else vc_act["valu_busy"], activity=vc_act,
+                                                          work={"votes_per_launch": B * T * R, "votes_per_s": B * T * R / (vc_ms / 1e3)}),
+                         },
+                         counters=("this run's rocprofv3 passes" if "reason" not in COUNTERS else "null: " + str(COUNTERS.get("reason"))),
+                         per_stage_ms={s_: round(stage_ms.get(s_, 0.0), 4) for s_ in DenseStep.STAGES}),
+        "cpu_baseline": None, "cpu_baseline_note": "the extensions have no reference path to time; their oracle restatements are "
+                                                   "checked in tests/test_gpu_parity.py",
+        "pose_5deg5cm_vs_gt": ok / B,
+        "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
+                       "records_gathered": int(all_rec.shape[0])},
+        "ok": True, "problems": [],
+    }
+    print(json.dumps(line))
+
+
 def tuple_mlp_flops(model, B, T, N, nprod):
     """(executed MFMA flops, algorithmic float32 flops) of one pass' tuple MLP launches (the three reslayer_split launches; for
     the DINO model also the two per-point Linear launches), K padded to 16 in the executed figure."""
@@ -400,26 +523,7 @@ def report_ensemble(args, step, dt, evs, world, backend):
     for ev in evs:
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs)
-    stage_ms_single = {}
-    for ev in evs_single:
-        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
-            stage_ms_single[n1] = stage_ms_single.get(n1, 0.0) + e0.elapsed_time(e1) / len(evs_single)
     step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
-    # With two streams a stage's HIP-event time on its own stream includes the time its kernels wait for the other stream's (two
-    # persistent matrix-core kernels do not fit a CU together): the kernels' own durations -- what the roofline divides by -- are
-    # the stage times of the single-stream loop of the same run (rocprofv3 shows the same durations in both modes,
-    # profiles/r4_two_stream_trace.txt).  stage_ms_2s keeps the two-stream stage times for the record.
-    stage_ms_2s = stage_ms
-    if dt_single is not None:
-        stage_ms = stage_ms_single
-    step_times = sorted(ev[0][1].elapsed_time(ev[-1][1]) for ev in evs)
-    # With two streams a stage's HIP-event time on its own stream includes the time its kernels wait for the other stream's (two
-    # persistent matrix-core kernels do not fit a CU together): the kernels' own durations -- what the roofline divides by -- are
-    # the stage times of the single-stream loop of the same run (rocprofv3 shows the same durations in both modes,
-    # profiles/r4_two_stream_trace.txt).  stage_ms_2s keeps the two-stream stage times for the record.
-    stage_ms_2s = stage_ms
-    if dt_single is not None:
-        stage_ms = stage_ms_single
     shared = ["sample_tuples", "shot_frames", "shot352"]
     dino_ms = stage_ms.get("dino_point_transforms", 0.0) + sum(stage_ms.get("dino_" + n, 0.0) for n in EnsembleStep.PASS)
     shot_ms = stage_ms.get("shot_encoder", 0.0) + sum(stage_ms.get("shot_" + n, 0.0) for n in EnsembleStep.PASS)
@@ -864,6 +968,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.workload == "dense64k" and "--scenes-per-gpu" not in sys.argv:
+        args.scenes_per_gpu = 16
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -906,9 +1012,9 @@ def main():
     from cppf2_amd import models as _models
     if args.mlp_arith:
         _models.MLP_ARITH = args.mlp_arith
-    if args.workload == "ensemble":
-        assert _models.MLP_ARITH in ("split", "split16"), "--workload ensemble runs the library's kernels (split arithmetic)"
-        step = EnsembleStep(args, rank, world, dev)
+    if args.workload in ("ensemble", "dense64k"):
+        assert _models.MLP_ARITH in ("split", "split16"), "--workload %s runs the library's kernels (split arithmetic)" % args.workload
+        step = EnsembleStep(args, rank, world, dev) if args.workload == "ensemble" else DenseStep(args, rank, world, dev)
         step.prepare_events()
         step.run()
         torch.cuda.synchronize()
@@ -937,7 +1043,7 @@ def main():
                 tmax = tmax.cpu()
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         if rank == 0:
-            report_ensemble(args, step, float(tmax.item()), evs, world, backend)
+            (report_ensemble if args.workload == "ensemble" else report_dense)(args, step, float(tmax.item()), evs, world, backend)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return

@@ -91,6 +91,7 @@ SIGNATURES = {
     "cppf_reslayer_split16": (_i, [_p]),
     "cppf_kept_rows32": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_nan_to_zero": (_i, [_p, _i64, _p]),
+    "cppf_cast_f16": (_i, [_p, _p, _i64, _p]),
     "cppf_reslayer_tail": (_i, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cppf_vote_rotation": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "cppf_sphere_counts": (_i, [_p, _i64, _p, _p, _i, _f, _i, _p, _p, _i64, _p]),

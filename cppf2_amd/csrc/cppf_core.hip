@@ -104,6 +104,22 @@ extern "C" int cppf_nan_to_zero(float* x, int64_t n, void* stream) {
   return CPPF_OK;
 }
 
+// float32 -> float16 (round to nearest even): the per-point feature table of BASELINE config 5 ("fp16 features") as
+// cppf_encode_tuples_shot_f16 gathers it.
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (_Float16)x[i];
+}
+
+extern "C" int cppf_cast_f16(const float* x, void* out_half, int64_t n, void* stream) {
+  CPPF_CHECK_ARG(((x != nullptr && out_half != nullptr) || n == 0) && n >= 0);
+  if (n == 0) return CPPF_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                     (_Float16*)out_half, n);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // scene bounds (train_dino.py:172-173): one workgroup per scene, min/max over the cloud.
 // ---------------------------------------------------------------------------------------------

@@ -298,6 +298,15 @@ def nan_to_zero_(x):
     return x
 
 
+def cast_f16(x, out=None):
+    """float16 copy of a float32 device tensor (round to nearest even) as a library kernel: BASELINE config 5's feature table."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device) if out is None else out
+    assert out.dtype == torch.float16 and out.is_contiguous() and out.numel() == x.numel()
+    _lib.check(_L.cppf_cast_f16(_p(x), _p(out), x.numel(), _stream()), "cppf_cast_f16")
+    return out
+
+
 def reslayer_split_supported(k_in, n_out, proj, chain=0):
     """True when cppf_reslayer_split has a kernel for a ResLayer of these dims (k_in = columns of x it reads) followed by
     `chain` identity layers of the same width."""

@@ -122,6 +122,9 @@ int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t t
                        int64_t workspace_bytes, void* stream);
 /* x[isnan(x)] = 0 in place, n floats: eval.py:216 on the normals (after the descriptor has read them). */
 int cppf_nan_to_zero(float* x, int64_t n, void* stream);
+/* out_half[i] = (float16) x[i], n elements (round to nearest even): the float16 feature table of BASELINE config 5 from the
+ * point encoder's float32 output (cppf_encode_tuples_shot_f16 gathers it). */
+int cppf_cast_f16(const float* x, void* out_half, int64_t n, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                           float* out_normal, void* workspace, int64_t workspace_bytes, int flags, void* stream);
