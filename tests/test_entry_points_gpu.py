@@ -58,6 +58,15 @@ def test_dino_model_forward_matches_reference_golden():
     # transform-then-gather (ours) vs gather-then-transform (reference): same rows through the same Linear
     assert np.allclose(cls.cpu().numpy(), g["pred_cls"], atol=1e-4)
     assert np.allclose(sc.cpu().numpy(), g["pred_scales"], atol=1e-4)
+    # the library-only form eval.run_ensemble runs since round 4 (per-point slot tables from host-folded weights, summed by the
+    # first ResLayer's kernel; no rows, no BLAS) against the REFERENCE module's own outputs, same tolerance
+    from cppf2_amd import models
+    with torch.no_grad():
+        assert models.MLP_ARITH != "split" or m.sum_supported(g["idx"].shape[1])
+        cls2, sc2 = m.heads_from_tuples(torch.from_numpy(g["pc"]).cuda(), torch.from_numpy(g["desc"].astype(np.float32)).cuda(),
+                                        torch.from_numpy(g["idx"]).cuda())
+    assert np.allclose(cls2.cpu().numpy(), g["pred_cls"], atol=1e-4)
+    assert np.allclose(sc2.cpu().numpy(), g["pred_scales"], atol=1e-4)
 
 
 def test_encode_backward_matches_torch_gather():
