@@ -291,8 +291,8 @@ class EnsembleStep(Step):
         self.desc = torch.nn.functional.normalize(torch.randn((self.B * self.N, 1024), generator=g), dim=-1).to(dev)
         self.scales_buf2 = torch.zeros((self.B * self.T, 3), dtype=torch.float32, device=dev)
 
-    def _vote_pass(self, pre, model, tf, idx, scales_buf):
-        pipe = self.pipe
+    def _vote_pass(self, pre, model, tf, idx, scales_buf, pipe=None, before_loss=None):
+        pipe = pipe or self.pipe
         pipe.decode_from_bins(self.pts, idx)
         self._mark(pre + "decode_bins")
         pipe.vote_center(self.pts, idx, phase=1)
@@ -307,8 +307,59 @@ class EnsembleStep(Step):
         self._mark(pre + "scale_head")
         pipe.assemble(scales)
         self._mark(pre + "assemble_pose")
+        if before_loss is not None:
+            before_loss()
         pipe.alignment_loss(self.pts, idx, True)          # bottle: up-symmetric, y only (eval.py:360-361)
         self._mark(pre + "alignment_loss")
+
+    @torch.no_grad()
+    def run_two_streams(self, streams):
+        """The same step as run() the way eval.run_ensemble runs it: the DINO pass on streams[0], the SHOT descriptors + SHOT
+        pass on streams[1] (twin pipeline: own working buffers, shared record slots), one event for the DINO pass' scale (it
+        scores the SHOT pass too, eval.py:308-310), selection and gather on the calling stream.  No per-stage events."""
+        from cppf2_amd import shot as shotmod
+        from cppf2_amd.models import fused_stack
+        ops, pipe, a = self.ops, self.pipe, self.args
+        B, N, T = self.B, self.N, self.T
+        ids = tuple(range(self.scene0, self.scene0 + B))
+        if getattr(self, "pipe_b", None) is None:
+            self.pipe_b = pipe.twin()
+            self.dino_done = torch.cuda.Event()
+        pipe_b = self.pipe_b
+        self.ev = None
+        main = torch.cuda.current_stream()
+        idx = ops.sample_tuples(N, T, 5, a.seed, ids, self.dev)
+        for st_ in streams:
+            st_.wait_stream(main)
+        with torch.cuda.stream(streams[0]):
+            pipe.use_slot(0)
+            fold = self.dino.first_layer_fold(5)
+            tables = fold.tables(self.dino.transform_points(self.desc))
+            u = ops.philox_uniform(T, 6, a.seed, 1, ids, self.dev)
+            heads, gidx = ops.encode_tuples_coord_heads(self.pts, idx, pipe.pt_off, pipe.tup_off)
+            _, tf = fused_stack((self.dino.tuple_encoder, self.dino.logit_encoder), None, gather=(heads, gidx, tables, fold),
+                                decode=(u, self.prior, pipe.bins))
+            self._vote_pass("dino_", self.dino, tf, idx, self.scales_buf, pipe=pipe, before_loss=self.dino_done.record)
+        with torch.cuda.stream(streams[1]):
+            shotmod.prepare_device(self.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, self.normal)
+            shot = shotmod.describe_device(self.pts, pipe.pt_off, self.normal, Cfg.res * 10, out=self.shot, nan_to_zero=True)
+            normal = ops.nan_to_zero_(self.normal)
+            feat = self.model.encode_points(shot)
+            pipe_b.use_slot(1)
+            u2 = ops.philox_uniform(T, 6, a.seed, 2, ids, self.dev)
+            heads2, gidx2 = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+            _, tf2 = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), None, gather=(heads2, gidx2, feat),
+                                 decode=(u2, self.prior, pipe_b.bins))
+            self._vote_pass("shot_", self.model, tf2, idx, self.scales_buf2, pipe=pipe_b,
+                            before_loss=lambda: torch.cuda.current_stream().wait_event(self.dino_done))
+        for st_ in streams:
+            main.wait_stream(st_)
+        pipe.select(True, True)
+        self.all_records = self.dist.gather_results(pipe.selected, B * self.world, out=self.records_buf)
+        # the per-pass tensors were allocated on the side streams and are released here, on the calling stream: keep them alive
+        # until the side streams are done with them (the next call's wait_stream orders the reuse)
+        self._keep = (idx, tables, u, heads, gidx, tf, shot, feat, u2, heads2, gidx2, tf2)
+        return None
 
     @torch.no_grad()
     def run(self, timed=None):
@@ -618,7 +669,11 @@ def report_ensemble(args, step, dt, evs, world, backend):
         "collective": {"backend": backend or "none (one rank: the local records are the result)", "world": world,
                        "records_gathered": int(all_rec.shape[0]), "bytes_per_rank": int(B * 160),
                        "gather_us": round(1e3 * stage_ms.get("gather", 0.0), 2)},
-        "ok": True, "problems": [],
+        "two_streams": getattr(step, "two", None),
+        "value_single_stream": (step.two or {}).get("value_single_stream") if getattr(step, "two", None) else None,
+        "ok": not (getattr(step, "two", None) and not step.two["records_identical_to_single_stream"]),
+        "problems": (["two_streams: records differ from the single-stream ones"]
+                     if (getattr(step, "two", None) and not step.two["records_identical_to_single_stream"]) else []),
     }
     print(json.dumps(line))
 
@@ -1028,20 +1083,41 @@ def main():
             if torch.distributed.is_initialized():
                 torch.distributed.barrier()
                 torch.cuda.synchronize()
-        sync_()
-        t0 = time.perf_counter()
-        evs = []
-        for i_ in range(args.steps):
-            ev_ = step.run(timed=sampled.get(i_))
-            if ev_ is not None:
-                evs.append(ev_)
-        sync_()
-        dt = time.perf_counter() - t0
+
+        def loop_(fn):
+            sync_()
+            t0_ = time.perf_counter()
+            evs_ = []
+            for i_ in range(args.steps):
+                ev_ = fn(i_)
+                if ev_ is not None:
+                    evs_.append(ev_)
+            sync_()
+            tm_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+            if torch.distributed.is_initialized():
+                if torch.distributed.get_backend() == "gloo":
+                    tm_ = tm_.cpu()
+                torch.distributed.all_reduce(tm_, op=torch.distributed.ReduceOp.MAX)
+            return float(tm_.item()), evs_
+        # single stream: per-stage events, kernel durations
+        dt1, evs = loop_(lambda i_: step.run(timed=sampled.get(i_)))
+        step.two = None
+        dt = dt1
+        if args.workload == "ensemble" and not args.single_stream:
+            # the product's batch mode (eval.run_ensemble): the two model passes on two HIP streams with twin pipelines
+            torch.cuda.synchronize()
+            ref_sel = step.pipe.selected.clone()
+            ref_slots = step.pipe.result_slots.clone()
+            streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            for _ in range(max(2, args.warmup)):
+                step.run_two_streams(streams)
+            dt, _ = loop_(lambda i_: step.run_two_streams(streams))
+            same = bool(torch.equal(step.pipe.selected, ref_sel) and torch.equal(step.pipe.result_slots, ref_slots))
+            step.two = {"streams": 2, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
+                        "ms_per_step_single_stream": 1e3 * dt1 / args.steps,
+                        "note": "the DINO pass and the SHOT pass (descriptors included) on two HIP streams, twin pipelines, one event "
+                                "for the DINO scale; per-stage times come from the single-stream loop of the same run"}
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if torch.distributed.is_initialized():
-            if torch.distributed.get_backend() == "gloo":
-                tmax = tmax.cpu()
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         if rank == 0:
             (report_ensemble if args.workload == "ensemble" else report_dense)(args, step, float(tmax.item()), evs, world, backend)
         if torch.distributed.is_initialized():
@@ -1139,8 +1215,9 @@ def main():
         evs_single = evs
     # the other placement of the scale head (see --eager-scale-head), measured the same way right after the headline
     # loop (untimed for the headline): the reference's forward order when the headline uses the kept-pairs-only order
+    # (the comparison loops below are one-rank diagnostics: a multi-GPU run times the headline loop only)
     dt_other = None
-    if not args.no_reference_order:
+    if not args.no_reference_order and world == 1:
         step.eager = not step.eager
         step.run()
         dt_other, _ = timed_loop(args.steps, sample=False)
@@ -1149,7 +1226,7 @@ def main():
     # the same step with the tuple MLP on the f32-input matrix cores (the arithmetic of rounds 1-2), same loop protocol
     dt_native = None
     headline_arith = _models.MLP_ARITH
-    if _models.MLP_ARITH == "split" and not args.no_native_arith:
+    if _models.MLP_ARITH == "split" and not args.no_native_arith and world == 1:
         _models.MLP_ARITH = "native"
         step.run()
         dt_native, _ = timed_loop(args.steps, sample=False)
@@ -1159,7 +1236,7 @@ def main():
     # error against float64 reported under mlp_error_vs_f64.split_f16x2); same loop protocol; not the headline
     dt_f16 = None
     f16_agreement = None
-    if _models.MLP_ARITH == "split" and not args.no_f16x2:
+    if _models.MLP_ARITH == "split" and not args.no_f16x2 and world == 1:
         _models.MLP_ARITH = "split16"
         step.run()
         dt_f16, _ = timed_loop(args.steps, sample=False)
