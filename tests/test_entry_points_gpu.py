@@ -275,6 +275,98 @@ def test_eval_main_nocs_layout_instance_loop(tmp_path, monkeypatch):
     assert rep3["evaluated"] == 3 and rep3["picked"]["shot"] == 0
 
 
+def _write_nocs_fixture_rendered(root, images=5):
+    """A larger synthetic set in the REAL275 layout: per image three bottle-like objects (cppf2_amd.synth clouds at their seeded
+    poses) and, in image 0, a 0.6 m x 0.45 m slab that back-projects to > 50 000 voxels of 2 mm (eval.py:194-197 caps it), rendered
+    into 640 x 480 16-bit depth maps (millimetres) with the REAL intrinsics by point splatting; detections = the objects' pixel
+    sets, classes cycling through the six categories."""
+    import pickle
+    from PIL import Image
+    from cppf2_amd import synth
+    K = np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]])
+    os.makedirs(os.path.join(root, "real_test", "scene_2"))
+    os.makedirs(os.path.join(root, "log"))
+    recs, n_inst = [], 0
+    for im in range(images):
+        depth = np.zeros((480, 640), np.float64)
+        masks, cls, gts = [], [], []
+        objs = [synth.make_scene(20 + im, j, 60000) for j in range(3)]
+        shifts = [np.array([-0.18, -0.05, 0.0]), np.array([0.0, 0.06, 0.05]), np.array([0.19, -0.02, -0.03])]
+        clouds = [o["pc"].astype(np.float64) + sh for o, sh in zip(objs, shifts)]
+        if im == 0:                                               # the slab: a tilted plane 1.05 m away
+            g = np.stack(np.meshgrid(np.linspace(-0.3, 0.3, 900), np.linspace(-0.225, 0.225, 700)), -1).reshape(-1, 2)
+            clouds.append(np.concatenate([g, 1.25 + 0.1 * g[:, :1]], -1))
+        for j, pc in enumerate(clouds):
+            # (the x / y negations of utils/util.py:2604-2605 and eval.py:187-188 cancel: a pixel (u, v) at depth z comes back as
+            # ((u - cx) z / fx, (v - cy) z / fy, z))
+            u = np.round(K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2]).astype(int)
+            v = np.round(K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]).astype(int)
+            ok = (u >= 0) & (u < 640) & (v >= 0) & (v < 480)
+            m = np.zeros((480, 640), bool)
+            order = np.argsort(-pc[ok, 2])                        # nearest point wins a pixel
+            depth_j = np.zeros((480, 640))
+            depth_j[v[ok][order], u[ok][order]] = pc[ok, 2][order]
+            m[v[ok], u[ok]] = True
+            closer = m & ((depth == 0) | (depth_j < depth))
+            depth[closer] = depth_j[closer]
+            masks.append(m)
+            cls.append(1 + (n_inst % 6))
+            gt = np.eye(4)
+            if j < 3:
+                gt[:3, :3] = objs[j]["R"] * objs[j]["diag"]
+                gt[:3, 3] = objs[j]["t"] + shifts[j]
+            gts.append(gt)
+            n_inst += 1
+        Image.fromarray(np.round(depth * 1000).astype(np.uint16)).save(os.path.join(root, "real_test", "scene_2", "%04d_depth.png" % im))
+        bbox = lambda mm: np.array([np.nonzero(mm)[0].min(), np.nonzero(mm)[1].min(), np.nonzero(mm)[0].max(), np.nonzero(mm)[1].max()])
+        recs.append(dict(image_path="data/real/test/scene_2/%04d" % im, pred_bboxes=np.stack([bbox(m) for m in masks]),
+                         pred_masks=np.stack(masks, -1), pred_class_ids=np.array(cls), pred_scores=np.full(len(cls), 0.9),
+                         gt_class_ids=np.array(cls), gt_RTs=np.stack(gts), gt_scales=np.ones((len(cls), 3)) * 0.5,
+                         gt_bboxes=np.stack([bbox(m) for m in masks])))
+    with open(os.path.join(root, "log", "results_real_test_scene_2.pkl"), "wb") as f:
+        pickle.dump(recs, f)
+    return recs
+
+
+def test_eval_main_nocs_layout_rendered_set(tmp_path, monkeypatch):
+    """The REAL275 loop at a size that exercises what the two-image fixture cannot: 16 detections over five rendered images and
+    all six categories (several instances per category batch, batch_instances smaller than a category's count: multiple
+    run_ensemble calls per category), the 50 000-point cap (eval.py:194-197) on a slab that back-projects to more voxels than that,
+    both models on two streams; poses land inside their instances' clouds; the same run with batch_instances = 16 gives the same
+    records (global instance ids key the RNG streams)."""
+    monkeypatch.chdir(ROOT)
+    sys.path.insert(0, ROOT)
+    import eval as ev
+    recs = _write_nocs_fixture_rendered(str(tmp_path))
+    seen = []
+    orig = ev.run_ensemble
+
+    def spy(cfg, dino_model, shot_model, pcs, *a, **k):
+        seen.append([p.shape[0] for p in pcs])
+        return orig(cfg, dino_model, shot_model, pcs, *a, **k)
+    monkeypatch.setattr(ev, "run_ensemble", spy)
+    rep = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), num_pairs=4000, num_rots=36,
+                  opt=True, batch_instances=2)
+    assert rep["images"] == 5 and rep["detections"] == 16 and rep["evaluated"] == 16 and rep["skipped"] == 0
+    assert sorted(rep["categories"]) == sorted(ev.WHITELIST) and sum(rep["picked"].values()) == 16
+    sizes = [n for call in seen for n in call]
+    assert len(seen) >= 8 and max(len(c) for c in seen) == 2                      # category batches of at most two instances
+    assert max(sizes) == 50000 and sorted(sizes)[-2] < 50000                     # the slab was capped, nothing else
+    assert min(sizes) > 2000
+    for r_, rec in zip(rep["final_results"], recs):
+        n = len(rec["pred_class_ids"])
+        assert r_["pred_RTs"].shape == (n, 4, 4) and np.all(np.isfinite(r_["pred_RTs"])) and np.all(np.isfinite(r_["pred_scales"]))
+        for j in range(min(n, 3)):
+            # the voted (and refined) centre lies within the object's neighbourhood
+            assert np.linalg.norm(r_["pred_RTs"][j][:3, 3] - rec["gt_RTs"][j][:3, 3]) < 0.2
+    n_calls = len(seen)
+    rep16 = ev.main(data="nocs", log_dir=str(tmp_path / "log"), data_root=str(tmp_path / "real_test"), num_pairs=4000, num_rots=36,
+                    opt=True, batch_instances=16)
+    assert len(seen) - n_calls == 6                                              # one call per category
+    for a_, b_ in zip(rep["final_results"], rep16["final_results"]):
+        assert np.array_equal(a_["pred_RTs"], b_["pred_RTs"]) and np.array_equal(a_["pred_scales"], b_["pred_scales"])
+
+
 def test_eval_main_on_reference_example_depth(monkeypatch):
     """BASELINE config 1: the reference's example scene (depth + mask) through backproject -> voxel down-sample ->
     SHOT -> both models -> votes, via the eval.py entry point (random-init weights: plumbing, shapes, finiteness)."""
