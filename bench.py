@@ -1038,6 +1038,11 @@ def main():
     if args.counter_child:              # a child of collect_counters: the bare single-stream loop, nothing else
         args.single_stream = args.no_reference_order = args.no_native_arith = args.no_f16x2 = args.no_evidence = args.no_counters = True
         args.cpu_scenes = 0
+    profiled = any(k_.startswith(("ROCP_", "ROCPROF")) for k_ in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled and not args.no_counters:
+        # this process is itself being profiled (the tool's library is loaded and has initialised the GPU): no children from here
+        args.no_counters = True
+        COUNTERS["reason"] = "running under a profiler: the counter passes are started by unprofiled runs only"
     if world == 1 and rank == 0 and not args.no_counters and not cdist_forced():
         # BEFORE this process initialises the GPU: fresh children under rocprofv3, one counter pass each
         wl = ["--scenes-per-gpu", str(args.scenes_per_gpu), "--points", str(args.points), "--tuples", str(args.tuples), "--rots",
@@ -1048,7 +1053,9 @@ def main():
         COUNTERS.clear()
         COUNTERS.update(collect_counters(wl))
     elif args.no_counters:
-        COUNTERS["reason"] = "--no-counters"
+        COUNTERS.setdefault("reason", "--no-counters")
+        if COUNTERS["reason"] == "not collected":
+            COUNTERS["reason"] = "--no-counters"
     else:
         COUNTERS["reason"] = "counter passes run at one rank only (N = 1)"
     assert torch.cuda.is_available(), "bench.py needs a GPU"

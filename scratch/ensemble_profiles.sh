@@ -2,12 +2,12 @@
 # Round profiles of the ensemble workload (BASELINE configs[2]) on the GPU box: kernel stats + launch order of one step, PMC traffic
 # passes (FETCH_SIZE / WRITE_SIZE separately), the bench line with the CPU baseline.  usage: bash scratch/ensemble_profiles.sh [r4]
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; RND=${1:-r4}; TAG=${RND}_ensemble
-ARGS="--workload ensemble --steps 5 --warmup 2 --cpu-scenes 0"
+ARGS="--workload ensemble --steps 5 --warmup 2 --cpu-scenes 0 --no-counters --single-stream"
 cd /tmp; rm -rf $R/gpurun_out/prof_ens
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ens -o $TAG -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_ens.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_ens_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_ens_$c -o p -- python3 $R/bench.py --workload ensemble --steps 2 --warmup 1 --cpu-scenes 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_ens_$c -o p -- python3 $R/bench.py --workload ensemble --steps 2 --warmup 1 --cpu-scenes 0 --no-counters --single-stream > /dev/null 2>&1
 done
 cd $R
 mkdir -p gpurun_out/profiles_new
