@@ -118,6 +118,8 @@ def parse():
                          "still measured and printed as value_single_stream")
     ap.add_argument("--no-evidence", action="store_true",
                     help="skip the untimed accuracy evidence (mlp_error_vs_f64, bin_flip_rate_vs_expf)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the headline loop rotates its steps over, each with its own resident state (default 2)")
     ap.add_argument("--no-counters", action="store_true",
                     help="skip the rocprofv3 counter passes (roofline.traffic and the unit-activity fractions are then null)")
     ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)      # set by collect_counters for its children
@@ -1165,8 +1167,8 @@ def main():
             if pair is None:
                 ev_ = step.run(timed=sampled.get(i_))
             else:
-                with torch.cuda.stream(pair[1][i_ & 1]):
-                    ev_ = pair[0][i_ & 1].run(timed=sampled.get(i_))
+                with torch.cuda.stream(pair[1][i_ % len(pair[1])]):
+                    ev_ = pair[0][i_ % len(pair[1])].run(timed=sampled.get(i_))
             if ev_ is not None:
                 evs_.append(ev_)
         sync()
@@ -1200,10 +1202,13 @@ def main():
         step.run()
         torch.cuda.synchronize()
         ref_rec = step.pipe.results.clone()
-        step_b = Step(args, rank, world, dev)
-        step_b.prepare_events()
-        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        pair = ([step, step_b], streams)
+        ns = max(2, int(args.streams))
+        others = [Step(args, rank, world, dev) for _ in range(ns - 1)]
+        for o_ in others:
+            o_.prepare_events()
+        step_b = others[0]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        pair = ([step] + others, streams)
         for s_, st_ in zip(*pair):
             st_.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st_):
@@ -1211,9 +1216,9 @@ def main():
                     s_.run()
         torch.cuda.synchronize()
         dt, evs = timed_loop(args.steps, pair=pair)
-        same = bool(torch.equal(step.pipe.results, ref_rec) and torch.equal(step_b.pipe.results, ref_rec))
+        same = bool(all(torch.equal(s_.pipe.results, ref_rec) for s_ in pair[0]))
         dt_single, evs_single = timed_loop(args.steps)
-        two = {"streams": 2, "records_identical_to_single_stream": same,
+        two = {"streams": ns, "records_identical_to_single_stream": same,
                "note": "steps alternate between two HIP streams with double-buffered state; records of both pipelines compared byte "
                        "for byte with a single-stream step's in this run; per-stage times of the headline are measured on the stage's "
                        "own stream while the other stream's kernels share the chip (per_stage_ms_single_stream: the same stages alone)"}
