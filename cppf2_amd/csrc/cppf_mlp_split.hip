@@ -102,6 +102,9 @@ __host__ __device__ constexpr int rs_tile_bytes(int pc) { return pc * RS_FRAG_BY
 #ifndef RS_EXACT_PMAX
 #define RS_EXACT_PMAX 1
 #endif
+#ifndef RS_XCD_BLOCKS
+#define RS_XCD_BLOCKS 1          // 0: row blocks dealt round-robin over all workgroups (rounds 2-3)
+#endif
 #ifndef RS_SIDE_INTERLEAVE
 #define RS_SIDE_INTERLEAVE 4     // vector instructions per MFMA gap in regions that carry side work (0: the scheduler's own order)
 #endif
@@ -814,7 +817,18 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   const int r = lane & 31, g = lane >> 5;
   const int ks1 = (k_in + 15) >> 4;
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
-  const int64_t mine = (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x;       // row blocks of this workgroup
+  // Row blocks of this workgroup: bfirst, bfirst + bstride, ... < bend.  Workgroup w runs on XCD w & 7 (round-robin dispatch, eight
+  // L2 caches): with a grid that is a multiple of 8, XCD j takes the j-th eighth of the row blocks and its workgroups sweep it side
+  // by side, so that the rows in flight on one XCD are neighbours -- the tuples of ONE scene, whose per-point table (1 MB for the
+  // SHOT model) then stays in that XCD's L2 instead of being fetched by all eight.  Other grids: plain round-robin.
+  int64_t bfirst = blockIdx.x, bstride = gridDim.x, bend = nblocks;
+  if (RS_XCD_BLOCKS && (gridDim.x & 7) == 0 && nblocks >= 64) {
+    const int64_t xcd = blockIdx.x & 7;
+    bfirst = nblocks * xcd / 8 + (blockIdx.x >> 3);
+    bend = nblocks * (xcd + 1) / 8;
+    bstride = gridDim.x >> 3;
+  }
+  const int64_t mine = bend > bfirst ? (bend - bfirst + bstride - 1) / bstride : 0;
 
   constexpr int STG = rs_stage_tiles(MODE), RING_BYTES = 2 * rs_stage_bytes(STG);
   RsStream<NT, T0, WAVES, PC, LIN, STG> ws;
@@ -875,19 +889,19 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     }
     return rw;
   };
-  RsRow cur = row_of(blockIdx.x < nblocks ? (int64_t)blockIdx.x : 0);
-  if (blockIdx.x < nblocks) {                     // x tiles of K steps 0, 1, 2 of the first row block into slots 0, 1, 2
+  RsRow cur = row_of(bfirst < bend ? bfirst : 0);
+  if (bfirst < bend) {                            // x tiles of K steps 0, 1, 2 of the first row block into slots 0, 1, 2
     xs.issue(0, 0, cur);
     xs.issue(1, 1, cur);
     xs.issue(2, 2, cur);
   }
   if constexpr (LIN) {
     // ---- plain Linear: per row block, one pass over x per column group; the accumulators go straight to memory -----------
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    for (int64_t blk = bfirst; blk < bend; blk += bstride) {
       const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
       const bool in = row < rows;
-      const bool more = blk + gridDim.x < nblocks;
-      const RsRow nxt = row_of(more ? blk + gridDim.x : blk);
+      const bool more = blk + bstride < bend;
+      const RsRow nxt = row_of(more ? blk + bstride : blk);
 #pragma unroll 1
       for (int grp = 0; grp < chain; ++grp) {
         f32x16 acc[NT];
@@ -925,12 +939,12 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   RsDraw draw;
   pend.row = -1;
   pend.in = false;
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  for (int64_t blk = bfirst; blk < bend; blk += bstride) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
     const float* xrow = cur.xrow;
-    const bool more = blk + gridDim.x < nblocks;
-    const RsRow nxt = row_of(more ? blk + gridDim.x : blk);         // (GATHER: its index loads are used after the first product)
+    const bool more = blk + bstride < bend;
+    const RsRow nxt = row_of(more ? blk + bstride : blk);         // (GATHER: its index loads are used after the first product)
     // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a projection layer] ----------------------------
     f32x16 acc[2 * NT];                         // h tiles, then the output tiles
     f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
