@@ -1154,6 +1154,19 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    # one completion event per step of the headline loops (recorded on the step's stream right after its last launch): the
+    # intervals between consecutive completions are the per-step figures of the line (step_interval_ms)
+    end_pool = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    step_ends = {}
+
+    def completion_intervals(ends):
+        if len(ends) < 3:
+            return None
+        t = sorted(ends[0].elapsed_time(e) for e in ends)
+        d = sorted(b_ - a_ for a_, b_ in zip(t[:-1], t[1:]))
+        return {"min": round(d[0], 4), "median": round(d[len(d) // 2], 4), "max": round(d[-1], 4), "n": len(d),
+                "p05": round(d[int(0.05 * len(d))], 4), "p95": round(d[int(0.95 * len(d))], 4)}
+
     def timed_loop(k, sample=True, pair=None):
         """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds.
         pair = ([step_a, step_b], [stream_a, stream_b]): step i runs on stream i & 1 with that stream's own state."""
@@ -1163,12 +1176,19 @@ def main():
         sync()
         t0 = time.perf_counter()
         evs_ = []
+        ends_ = step_ends[id(pair)] = []
         for i_ in range(k):
             if pair is None:
                 ev_ = step.run(timed=sampled.get(i_))
+                if sample:
+                    end_pool[i_].record()
             else:
                 with torch.cuda.stream(pair[1][i_ % len(pair[1])]):
                     ev_ = pair[0][i_ % len(pair[1])].run(timed=sampled.get(i_))
+                    if sample:
+                        end_pool[i_].record()
+            if sample:
+                ends_.append(end_pool[i_])
             if ev_ is not None:
                 evs_.append(ev_)
         sync()
@@ -1216,14 +1236,18 @@ def main():
                     s_.run()
         torch.cuda.synchronize()
         dt, evs = timed_loop(args.steps, pair=pair)
+        intervals = completion_intervals(step_ends[id(pair)])
         same = bool(all(torch.equal(s_.pipe.results, ref_rec) for s_ in pair[0]))
         dt_single, evs_single = timed_loop(args.steps)
+        intervals_single = completion_intervals(step_ends[id(None)])
         two = {"streams": ns, "records_identical_to_single_stream": same,
                "note": "steps alternate between two HIP streams with double-buffered state; records of both pipelines compared byte "
                        "for byte with a single-stream step's in this run; per-stage times of the headline are measured on the stage's "
                        "own stream while the other stream's kernels share the chip (per_stage_ms_single_stream: the same stages alone)"}
     else:
         dt, evs = timed_loop(args.steps)
+        intervals = completion_intervals(step_ends[id(None)])
+        intervals_single = None
         evs_single = evs
     # the other placement of the scale head (see --eager-scale-head), measured the same way right after the headline
     # loop (untimed for the headline): the reference's forward order when the headline uses the kept-pairs-only order
@@ -1478,8 +1502,13 @@ def main():
             "two_streams": two,
             "value_single_stream": (total_scenes / dt_single) if dt_single else None,
             "ms_per_step_single_stream": (1e3 * dt_single / args.steps) if dt_single else None,
-            # first-event to last-event time of the sampled steps on their own stream (with two streams a step overlaps the next)
-            "step_ms_sampled": {"min": round(step_times[0], 4), "median": round(step_times[len(step_times) // 2], 4),
+            # intervals between consecutive step completions inside the timed loop (one HIP event per step), and the same for the
+            # single-stream loop: the per-step spread of the headline
+            "step_interval_ms": intervals,
+            "step_interval_ms_single_stream": intervals_single,
+            # first-event to last-event time of the sampled steps on their own stream: a step's RESIDENCE on its stream (with two
+            # streams a step overlaps its neighbours, so this is about two step intervals -- not a per-step time)
+            "step_residence_ms_sampled": {"min": round(step_times[0], 4), "median": round(step_times[len(step_times) // 2], 4),
                                 "max": round(step_times[-1], 4), "n": len(step_times)},
             "records_gathered": int(all_rec.shape[0]),
             # SHA-256 of the gathered records in global scene order: equal for every world size and stream mode (the records

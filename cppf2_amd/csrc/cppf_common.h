@@ -169,6 +169,89 @@ __device__ __forceinline__ float softmax_exp(float x) {
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (CPPF_WAVE - 1); }
 
+// Wavefront idioms written with the instructions they are (hipcc's __ballot / __popcll(mask & lanes_below) / __shfl_up
+// detour through a materialised 0/1 predicate, two mask ANDs and the LDS crossbar respectively).
+// wave_ballot: the condition's lane mask straight from the comparison.
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// lanes_below: how many set bits of mask belong to lanes below this one (v_mbcnt_lo + v_mbcnt_hi).
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+// wave_inclusive_scan_u32: prefix sums over the 64 lanes on the DPP path (row shifts inside the rows of 16, then the last
+// lane of a row broadcast to the following rows): six v_add_u32 with a DPP operand, no LDS trip.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source (or outside row_mask) read `old` = 0
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+// upper_half: lane l < 32 gets lane l + 32's value (v_permlane32_swap, gfx950); lanes >= 32: unspecified.
+__device__ __forceinline__ uint32_t upper_half(uint32_t v) {
+  return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1];
+}
+__device__ __forceinline__ double upper_half(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = upper_half((uint32_t)u), hi = upper_half((uint32_t)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// row_down: a DPP row shift of a double (ctrl 0x101 / 0x102: lane l gets lane l + 1 / l + 2 of its row of 16; lanes without a
+// source get 0.0).
+template <int CTRL>
+__device__ __forceinline__ double row_down(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// wave_sum: the xor-butterfly sum over the 64 lanes (every lane ends with the same bits), each exchange on the cheapest path that
+// pairs a lane with a holder of its partner's value: quad permutes (xor 1, xor 2), half-row and row mirrors (after the quad steps
+// all lanes of a quad hold the quad's sum, so the mirror partner carries what lane ^ 4 / lane ^ 8 would), v_permlane16_swap and
+// v_permlane32_swap (both results added: own + partner in either order) -- no trip through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);                 // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);                // row_half_mirror
+  v += dpp_f64<0x140>(v);                // row_mirror
+  {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const auto l = __builtin_amdgcn_permlane16_swap((uint32_t)u, (uint32_t)u, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+    v = __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+        __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+  }
+  {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const auto l = __builtin_amdgcn_permlane32_swap((uint32_t)u, (uint32_t)u, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+    v = __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+        __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+  }
+  return v;
+}
+// sqrt_rn: correctly rounded float32 square root of a positive NORMAL finite x (the rounding step of the compiler's own
+// expansion -- the hardware root is within 1 ulp; pick the neighbour whose residual says so -- without its denormal
+// pre-scaling and zero / infinity fix-up: 9 instructions instead of 17).  Anything else goes through sqrtf.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (!(x >= 1e-30f && x <= 1e30f)) return __builtin_sqrtf(x);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+  float r = (rd <= 0.0f) ? dn : s;
+  r = (ru > 0.0f) ? up : r;
+  return r;
+}
+
 // first-maximum reduction on (value, index) pairs: larger value wins, ties -> smaller index.
 __device__ __forceinline__ void argmax_combine(uint32_t& v, int64_t& i, uint32_t ov, int64_t oi) {
   if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }

@@ -46,17 +46,6 @@ __device__ __forceinline__ int find_scene_pt(const int32_t* __restrict__ off, in
   return lo;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
 // Cyclic Jacobi, symmetric 3x3, float64; eigenvalues ascending, eigenvectors in columns.  Same operation
 // sequence as oracle/shot_oracle.c:jacobi3 (only + - * / sqrt: bit-identical on CPU and GPU).
@@ -389,7 +378,7 @@ __device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float 
   if (d2 < rs2) {
     a[18] += 1.0;                                             // all in-radius points (incl. self)
     if (!(qx == px && qy == py && qz == pz)) {
-      const double w = (double)rs - (double)__builtin_sqrtf(d2);
+      const double w = (double)rs - (double)sqrt_rn(d2);
       a[10] += w * (x * x); a[11] += w * (x * y); a[12] += w * (x * z);
       a[13] += w * (y * y); a[14] += w * (y * z); a[15] += w * (z * z);
       a[16] += w; a[17] += 1.0;
@@ -400,65 +389,77 @@ __device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float 
 // The candidates of the 9 runs are first compacted to the ones inside the larger radius (about a third of them), so
 // the float64 sums run over dense wavefronts; the compacted list (positions in the cell-sorted order, scan order) is
 // also left in the workspace for shot_hist, which needs the same neighbours.
+// wave_rank: the rank of each of the wavefront's keys (EMAX per lane; bkt < 0: no entry) among all of them, ascending.  The caller
+// supplies a bucket per key, monotone in the key (0..63): a counting sort over the buckets (LDS atomics + one prefix scan) leaves
+// exact 64-bit comparisons only against the keys of the own bucket.  buf: 128 + 128 + 2 x 64 EMAX words of LDS, free on entry
+// (the caller's barrier precedes the call) and again on return.  Returns the number of keys.
+template <int EMAX>
+__device__ __forceinline__ int wave_rank(int lane, uint32_t* buf, const unsigned long long (&key)[EMAX], const int (&bkt)[EMAX],
+                                         int (&rank)[EMAX]) {
+  uint32_t* s_hist = buf;                                              // [64] bucket counts
+  uint32_t* s_start = s_hist + 64;                                     // [64] bucket starts
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_start + 64);   // [<= 64 EMAX] keys by bucket
+  s_hist[lane] = 0;
+  __syncthreads();
+  int ep[EMAX];
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    ep[e] = 0;
+    if (bkt[e] >= 0) ep[e] = (int)atomicAdd(&s_hist[bkt[e]], 1u);
+  }
+  __syncthreads();
+  int total;
+  {
+    const uint32_t cnt = s_hist[lane];
+    const uint32_t incl = wave_inclusive_scan_u32(cnt);
+    s_start[lane] = incl - cnt;
+    total = (int)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e)
+    if (bkt[e] >= 0) s_key[s_start[bkt[e]] + ep[e]] = key[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    rank[e] = -1;
+    if (bkt[e] >= 0) {
+      const int s0 = (int)s_start[bkt[e]], n_b = (int)s_hist[bkt[e]];
+      int r = s0;
+#pragma unroll 1
+      for (int j = 0; j < n_b; ++j) r += (s_key[s0 + j] < key[e]) ? 1 : 0;
+      rank[e] = r;
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+// The 64-bit key of the (distance, original index) order: non-negative floats order like their bit patterns.
+__device__ __forceinline__ unsigned long long dist_index_key(float d2, int index) {
+  return ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)index;
+}
+
 // The float32 sums of pcl::NormalEstimation (see shot_cov_kernel<PCL>) over the entries the lanes hold (EMAX per lane; ed >= rn2
-// marks an unused entry) in (distance, index) order: counting sort on 64 distance buckets, exact comparisons inside a bucket,
+// marks an unused entry) in (distance, index) order: ranks from wave_rank (64 distance buckets),
 // addends written to LDS in rank order (windows of PCL_WIN ranks), nine lanes add one column each sequentially.
 // s_raw: the wavefront's 5016-byte LDS buffer (free on entry; a barrier precedes the call).  Returns the j-th sum in lane j < 9.
 template <int EMAX>
 __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn2, const float (&ex)[EMAX], const float (&ey)[EMAX],
                                                const float (&ez)[EMAX], const float (&ed)[EMAX], const int (&ei)[EMAX],
                                                float& pcl_sum, int& mn) {
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_raw);               // [64] bucket counts
-  uint32_t* s_start = s_hist + 64;                                     // [64] bucket starts
-  uint2* s_key = reinterpret_cast<uint2*>(s_start + 64);               // [<= 64 EMAX] (distance bits, index) by bucket
   float* s_add = reinterpret_cast<float*>(s_raw);                      // [9][PCL_WIN] addends of a rank window, column-major
   constexpr int PCL_WIN = 136;                                         // 9 x 136 x 4 = 4896 bytes of the 5016
   static_assert(512 + 64 * EMAX * 8 <= NSUM * 33 * 8, "keys fit the buffer");
-  s_hist[lane] = 0;
-  __syncthreads();
-  const float bscale = 64.0f / rn2;
-  int eb[EMAX], ep[EMAX];
+  const float bscale = 64.0f * __builtin_amdgcn_rcpf(rn2);     // (any positive scale gives the same ranks: buckets only pre-sort)
+  unsigned long long key[EMAX];
+  int eb[EMAX], er[EMAX];
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
-    eb[e] = 0; ep[e] = 0;
-    if (ed[e] < rn2) {
-      eb[e] = min(63, (int)(ed[e] * bscale));
-      ep[e] = (int)atomicAdd(&s_hist[eb[e]], 1u);
-    }
+    eb[e] = (ed[e] < rn2) ? min(63, (int)(ed[e] * bscale)) : -1;
+    key[e] = dist_index_key(ed[e], ei[e]);
   }
-  __syncthreads();
-  {
-    const uint32_t cnt = s_hist[lane];
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    s_start[lane] = incl - cnt;
-    mn = (int)__shfl(incl, 63);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < EMAX; ++e)
-    if (ed[e] < rn2) s_key[s_start[eb[e]] + ep[e]] = make_uint2(__float_as_uint(ed[e]), (uint32_t)ei[e]);
-  __syncthreads();
-  int er[EMAX];
-#pragma unroll
-  for (int e = 0; e < EMAX; ++e) {
-    er[e] = -1;
-    if (ed[e] < rn2) {
-      const int s0 = (int)s_start[eb[e]], n_b = (int)s_hist[eb[e]];
-      const uint32_t kd = __float_as_uint(ed[e]), ki = (uint32_t)ei[e];
-      int r = s0;
-      for (int j = 0; j < n_b; ++j) {
-        const uint2 o = s_key[s0 + j];
-        r += (o.x < kd || (o.x == kd && o.y < ki)) ? 1 : 0;
-      }
-      er[e] = r;
-    }
-  }
-  __syncthreads();                               // the keys are dead: the buffer becomes the addend windows
+  mn = wave_rank<EMAX>(lane, reinterpret_cast<uint32_t*>(s_raw), key, eb, er);
   for (int w0 = 0; w0 < mn; w0 += PCL_WIN) {
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
@@ -504,7 +505,7 @@ __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn
 #define PCL_EMAX_SHORT 2
 #define PCL_EMAX_LONG (NBR_CAP / 64)
 template <bool PCL>
-__global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
+__global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
                                                       const int32_t* __restrict__ pt_off,
                                                       const CellHdr* __restrict__ hdrs,
                                                       const int32_t* __restrict__ cell_start,
@@ -534,7 +535,10 @@ __global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const 
   query_runs(h, cs, px, py, pz, runs);
   double a[NSUM];
 #pragma unroll
-  for (int c = 0; c < NSUM; ++c) a[c] = 0.0;
+  for (int c = 0; c < NSUM; ++c) {
+    a[c] = 0.0;
+    asm("" : "+v"(a[c]));        // one zero per sum, here: otherwise every branch below re-creates the zeros it might need
+  }
   // The candidates of the 9 runs are tested in float32 and the hits (about a fifth of them) compacted (ballot + prefix popcount)
   // into LDS -- and into the workspace for shot_hist, which needs the same neighbours -- so that the float64 covariance sums run
   // over a dense list (two wavefront passes for the usual ~90 neighbours instead of seven to nine over the candidates).
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const 
     return j;
   };
   int m = 0;
+  int32_t* const my_list = nbr_list + (int64_t)qi * NBR_CAP;
   {
     // run by run (the same scan order as the flat range): the first 64 candidates of every run are requested up front -- nine
     // independent gathers in flight and no per-lane search for the run a flat index falls into; a run rarely has more than 64
@@ -557,20 +562,20 @@ __global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const 
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int j = runs.beg[k] + lane;
-      q0[k] = sp[j < runs.end[k] ? j : runs.beg[0]];
+      q0[k] = sp[(unsigned)(j < runs.end[k] ? j : runs.beg[0])];
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       for (int jb = runs.beg[k]; jb < runs.end[k]; jb += 64) {
         const int j = jb + lane;
         const bool valid = j < runs.end[k];
-        const float4 qv = (jb == runs.beg[k]) ? q0[k] : sp[valid ? j : jb];
+        const float4 qv = (jb == runs.beg[k]) ? q0[k] : sp[(unsigned)(valid ? j : jb)];
         const bool in = valid && sqdist3(px, py, pz, qv.x, qv.y, qv.z) < rm2;
-        const unsigned long long mask = __ballot(in);
+        const unsigned long long mask = wave_ballot(in);
         if (in) {
-          const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-          if (pos < COV_LIST) s_nb[pos] = qv;
-          if (!(SHOT_DBG & 256) && pos < NBR_CAP && nbr_list) nbr_list[(int64_t)qi * NBR_CAP + pos] = j;
+          const unsigned pos = (unsigned)(m + lanes_below(mask));
+          if (pos < (unsigned)COV_LIST) s_nb[pos] = qv;
+          if (!(SHOT_DBG & 256) && pos < (unsigned)NBR_CAP && nbr_list) my_list[pos] = j;
         }
         m += __popcll(mask);
       }
@@ -585,14 +590,13 @@ __global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const 
   } else if (pcl_list) {
 #pragma unroll
     for (int e = 0; e < PCL_EMAX_SHORT; ++e) {
+      // (every lane reads its slot -- 128 slots are inside the buffer -- and only ed says whether the entry exists)
       const int c = lane + 64 * e;
-      ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
-      if (c < m) {
-        const float4 qv = s_nb[c];
-        cov_accumulate<false>(qv, px, py, pz, rn2, rs2, rs, a);
-        const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
-        if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
-      }
+      const float4 qv = s_nb[c];
+      const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
+      ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ei[e] = __float_as_int(qv.w);
+      ed[e] = (c < m && d2 < rn2) ? d2 : INFINITY;
+      if (c < m) cov_accumulate<false>(qv, px, py, pz, rn2, rs2, rs, a);
     }
   } else if (m <= COV_LIST) {
     for (int c = lane; c < m; c += 64) cov_accumulate(s_nb[c], px, py, pz, rn2, rs2, rs, a);
@@ -610,28 +614,41 @@ __global__ __launch_bounds__(64, PCL ? 7 : 8) void shot_cov_kernel(int B, const 
     if (qi == 0) reinterpret_cast<float*>(nbr_cnt)[-1] = fmaxf(rn, rs);      // radius of the lists (slot before the counts)
   }
   if (SHOT_DBG & 128) { if (lane < NSUM) sums[(int64_t)qi * NSUM + lane] = a[lane % 3]; return; }
+  if (lane >= 32 && lane < 32 + NSUM) s_part[lane - 32][32] = 0.0;
+  // (a ranked list has its normal sums from pcl_float_sums: columns 0..9 of the float64 partials are not needed then)
+  if (pcl_list) {
 #pragma unroll
-  for (int c = 0; c < NSUM; ++c) {
-    a[c] += __shfl_xor(a[c], 32);                  // lane l < 32: its own partial + lane l + 32's
-    if (lane < 32) s_part[c][lane] = a[c];
+    for (int c = 10; c < NSUM; ++c) {
+      a[c] += upper_half(a[c]);
+      if (lane < 32) s_part[c][lane] = a[c];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NSUM; ++c) {
+      a[c] += upper_half(a[c]);                    // lane l < 32: its own partial + lane l + 32's
+      if (lane < 32) s_part[c][lane] = a[c];
+    }
   }
   __syncthreads();
   // column sums in a fixed order (run-to-run reproducible): three lanes per column add a third of the 32 partials each,
   // the first of them adds the three thirds.  All partials of a lane are requested first, then added in index order (as a
   // load-add loop every addition waits out one LDS round trip); entries past the end add an exact 0.0.
   {
-    const int c = min(lane / 3, NSUM - 1), part = lane - 3 * (lane / 3);
-    const int lo = part * 11, hi = min(32, lo + 11);
+    // (entries 0..10, 11..21, 22..32: the 33rd entry of a row is the pad slot, zeroed below, so every lane adds 11 entries)
+    // five columns per row of 16 lanes (lane 15 of a row idles): the three thirds of a column meet through DPP row shifts
+    const int in_row = lane & 15, c = min(5 * (lane >> 4) + in_row / 3, NSUM - 1), part = in_row - 3 * (in_row / 3);
+    const int lo = part * 11;
     double v[11];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) v[i] = s_part[c][min(lo + i, 31)];
+    for (int i = 0; i < 11; ++i) v[i] = s_part[c][lo + i];
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) t += (lo + i < hi) ? v[i] : 0.0;
-    const double t1 = __shfl_down(t, 1), t2 = __shfl_down(t, 2);
+    for (int i = 0; i < 11; ++i) t += v[i];
+    const double t1 = row_down<0x101>(t), t2 = row_down<0x102>(t);
     // (PCL, list too long for LDS: the float64 sums about the query point stand in, the count is marked with + 0.5)
     const double mark = (PCL && !pcl_list && rn > 0.0f && c == 9) ? 0.5 : 0.0;
-    if (lane < 3 * NSUM && part == 0 && !(pcl_list && c < 10)) sums[(int64_t)qi * NSUM + c] = ((t + t1) + t2) + mark;
+    if (5 * (lane >> 4) + in_row / 3 < NSUM && in_row < 15 && part == 0 && !(pcl_list && c < 10))
+      sums[(int64_t)qi * NSUM + c] = ((t + t1) + t2) + mark;
   }
   if (pcl_list) {
     if (lane < 9) sums[(int64_t)qi * NSUM + lane] = (double)pcl_sum;
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const 
       const double s9 = sums[(q0 + lane) * NSUM + 9];
       todo = s9 != floor(s9) && nbr_cnt[q0 + lane] <= NBR_CAP;      // (longer than this kernel's capacity: the float64 sums stay)
     }
-    unsigned long long mask = __ballot(todo);
+    unsigned long long mask = wave_ballot(todo);
     while (mask) {
       const int64_t qi = q0 + __builtin_ctzll(mask);
       mask &= mask - 1;
@@ -952,8 +969,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
         int j = 0;
         bool in = false;
         if (c < shared_cnt) { j = nl[c]; const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
-        const unsigned long long mask = __ballot(in);
-        if (in) s_list[m + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+        const unsigned long long mask = wave_ballot(in);
+        if (in) s_list[m + lanes_below(mask)] = j;
         m += __popcll(mask);
       }
     }
@@ -965,9 +982,9 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
         const int j = jb + lane;
         bool in = false;
         if (j < runs.end[k]) { const float4 qv = sp[j]; in = sqdist3(px, py, pz, qv.x, qv.y, qv.z) < r2; }
-        const unsigned long long mask = __ballot(in);
+        const unsigned long long mask = wave_ballot(in);
         if (in) {
-          const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+          const int pos = m + lanes_below(mask);
           if (pos < SH_LCAP) s_list[pos] = j;
         }
         m += __popcll(mask);
@@ -1032,45 +1049,42 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   } else if (small) {            // the two register-held neighbours, one after the other (no selection between them inside a loop)
     bool p1, p3;
     signs_of(cp0, lane < m, p1, p3);
-    plus1 += __popcll(__ballot(p1));
-    plus3 += __popcll(__ballot(p3));
+    plus1 += __popcll(wave_ballot(p1));
+    plus3 += __popcll(wave_ballot(p3));
     if (m > 64) {
       signs_of(cp1, lane + 64 < m, p1, p3);
-      plus1 += __popcll(__ballot(p1));
-      plus3 += __popcll(__ballot(p3));
+      plus1 += __popcll(wave_ballot(p1));
+      plus3 += __popcll(wave_ballot(p3));
     }
   } else {
   FOR_EACH_NEIGHBOUR({
     bool p1, p3;
     signs_of(sp[j], act, p1, p3);
-    plus1 += __popcll(__ballot(p1));
-    plus3 += __popcll(__ballot(p3));
+    plus1 += __popcll(wave_ballot(p1));
+    plus3 += __popcll(wave_ballot(p3));
   })
   }
   plus1 = 2 * plus1 - valid;
   plus3 = 2 * plus3 - valid;
   if ((plus1 == 0 || plus3 == 0) && small && !(SHOT_DBG & 16)) {
     // tie (one query in six: an even count splits evenly about as often as a fair coin does) with the neighbours in registers:
-    // a neighbour's rank in the (distance, original index) order is the number of smaller 64-bit keys (distance bits : index);
-    // the keys go through the unused upper part of the list buffer and every lane scans them for its two neighbours
-    static_assert(SH_LCAP >= 512, "the tie-break keys live in list entries 256..511");
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_list + 256);
-    auto key_of = [&](const float4 q, bool in) {
+    // a neighbour's rank in the (distance, original index) order is the number of smaller 64-bit keys (distance bits : index),
+    // counted by wave_rank (64 distance buckets; its tables live in the unused upper part of the list buffer)
+    static_assert(SH_LCAP >= 1024, "wave_rank's 768 words live in list entries 256..1023");
+    const float bscale = 64.0f * __builtin_amdgcn_rcpf(r2);
+    auto key_of = [&](const float4 q, bool in, int& bucket) {
       const bool self = (q.x == px && q.y == py && q.z == pz);
-      return (!in || self) ? ~0ull
-                           : (((unsigned long long)__float_as_uint(sqdist3(px, py, pz, q.x, q.y, q.z)) << 32) |
-                              (unsigned long long)(uint32_t)__float_as_int(q.w));
+      const float d2 = sqdist3(px, py, pz, q.x, q.y, q.z);
+      bucket = (!in || self) ? -1 : min(63, (int)(d2 * bscale));
+      return (!in || self) ? ~0ull : dist_index_key(d2, __float_as_int(q.w));
     };
-    const unsigned long long k0 = key_of(cp0, lane < m), k1 = key_of(cp1, lane + 64 < m);
-    s_key[lane] = k0;
-    s_key[lane + 64] = k1;
-    __syncthreads();
-    int rk0 = 0, rk1 = 0;
-    for (int c2 = 0; c2 < m; ++c2) {
-      const unsigned long long kk = s_key[c2];
-      rk0 += (kk < k0) ? 1 : 0;
-      rk1 += (kk < k1) ? 1 : 0;
-    }
+    unsigned long long key[2];
+    int bkt[2], rk[2];
+    key[0] = key_of(cp0, lane < m, bkt[0]);
+    key[1] = key_of(cp1, lane + 64 < m, bkt[1]);
+    wave_rank<2>(lane, reinterpret_cast<uint32_t*>(s_list + 256), key, bkt, rk);
+    const unsigned long long k0 = key[0], k1 = key[1];
+    const int rk0 = rk[0], rk1 = rk[1];
     auto decide = [&](const float4 q, unsigned long long key, int rank, bool& h1, bool& h3) {
       h1 = false; h3 = false;
       if (key != ~0ull && rank >= med - 2 && rank <= med + 2) {
@@ -1082,8 +1096,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     bool h1a, h3a, h1b, h3b;
     decide(cp0, k0, rk0, h1a, h3a);
     decide(cp1, k1, rk1, h1b, h3b);
-    c1 = __popcll(__ballot(h1a)) + __popcll(__ballot(h1b));
-    c3 = __popcll(__ballot(h3a)) + __popcll(__ballot(h3b));
+    c1 = __popcll(wave_ballot(h1a)) + __popcll(wave_ballot(h1b));
+    c3 = __popcll(wave_ballot(h3a)) + __popcll(wave_ballot(h3b));
     if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
     if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
   } else if (plus1 == 0 || plus3 == 0) {
@@ -1123,8 +1137,8 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
           }
         }
       }
-      c1 += __popcll(__ballot(h1));
-      c3 += __popcll(__ballot(h3));
+      c1 += __popcll(wave_ballot(h1));
+      c3 += __popcll(wave_ballot(h3));
     })
     if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
     if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
