@@ -25,3 +25,12 @@ with torch.no_grad():
     for _ in range(10): f()
     e1.record(); torch.cuda.synchronize()
     print("256 -> 192 + bin draw: %.3f ms   bins sha %s" % (e0.elapsed_time(e1) / 10, __import__("hashlib").sha256(bins.cpu().numpy().tobytes()).hexdigest()[:12]))
+    # the same layer with the logits written instead (no draw), and the draw without a prior
+    out = torch.empty((T, 192), device=dev)
+    for name, g in (("256 -> 192, logits written (no draw)", lambda: ops.reslayer_split(x, wq, b1, b0, 192, out=out)),
+                    ("256 -> 192 + bin draw, no prior", lambda: ops.reslayer_split_decode(x, wq, b1, b0, u, bins=bins))):
+        g(); g(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10): g()
+        e1.record(); torch.cuda.synchronize()
+        print("%s: %.3f ms" % (name, e0.elapsed_time(e1) / 10))
