@@ -31,7 +31,7 @@
 #endif
 #define SH_STRIDE 353
 #ifndef SHOT_DBG
-#define SHOT_DBG 0     // timing probes (scratch/shot_sections.sh): 1 = no sign pass, 2 = no accumulation, 4 = no normalisation, 8 = the compiler's float division, 16 = the general tie pass, 32 = float64 sign pass;
+#define SHOT_DBG 0     // timing probes (scratch/shot_sections.sh): 1 = no sign pass, 2 = no accumulation, 4 = no normalisation, 8 = the compiler's float division, 16 = the general tie pass, 32 = float64 sign pass, 512 = no general tie pass;
                        // shot_cov: 64 = no covariance sums, 128 = no reduction, 256 = no neighbour list to the workspace
 #endif
 // Neighbour lists handed from shot_cov to shot_hist through the workspace (entries per query; longer lists are rebuilt)
@@ -392,10 +392,11 @@ __device__ __forceinline__ void cov_accumulate(const float4 qv, float px, float 
 // wave_rank: the rank of each of the wavefront's keys (EMAX per lane; bkt < 0: no entry) among all of them, ascending.  The caller
 // supplies a bucket per key, monotone in the key (0..63): a counting sort over the buckets (LDS atomics + one prefix scan) leaves
 // exact 64-bit comparisons only against the keys of the own bucket.  buf: 128 + 128 + 2 x 64 EMAX words of LDS, free on entry
-// (the caller's barrier precedes the call) and again on return.  Returns the number of keys.
+// (the caller's barrier precedes the call) and again on return.  nent (wave-uniform): entry slots >= nent hold no key on any lane and
+// are skipped as a whole.  Returns the number of keys.
 template <int EMAX>
 __device__ __forceinline__ int wave_rank(int lane, uint32_t* buf, const unsigned long long (&key)[EMAX], const int (&bkt)[EMAX],
-                                         int (&rank)[EMAX]) {
+                                         int (&rank)[EMAX], int nent = EMAX) {
   uint32_t* s_hist = buf;                                              // [64] bucket counts
   uint32_t* s_start = s_hist + 64;                                     // [64] bucket starts
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_start + 64);   // [<= 64 EMAX] keys by bucket
@@ -405,7 +406,7 @@ __device__ __forceinline__ int wave_rank(int lane, uint32_t* buf, const unsigned
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
     ep[e] = 0;
-    if (bkt[e] >= 0) ep[e] = (int)atomicAdd(&s_hist[bkt[e]], 1u);
+    if (e < nent && bkt[e] >= 0) ep[e] = (int)atomicAdd(&s_hist[bkt[e]], 1u);
   }
   __syncthreads();
   int total;
@@ -418,12 +419,12 @@ __device__ __forceinline__ int wave_rank(int lane, uint32_t* buf, const unsigned
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < EMAX; ++e)
-    if (bkt[e] >= 0) s_key[s_start[bkt[e]] + ep[e]] = key[e];
+    if (e < nent && bkt[e] >= 0) s_key[s_start[bkt[e]] + ep[e]] = key[e];
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < EMAX; ++e) {
     rank[e] = -1;
-    if (bkt[e] >= 0) {
+    if (e < nent && bkt[e] >= 0) {
       const int s0 = (int)s_start[bkt[e]], n_b = (int)s_hist[bkt[e]];
       int r = s0;
 #pragma unroll 1
@@ -447,7 +448,7 @@ __device__ __forceinline__ unsigned long long dist_index_key(float d2, int index
 template <int EMAX>
 __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn2, const float (&ex)[EMAX], const float (&ey)[EMAX],
                                                const float (&ez)[EMAX], const float (&ed)[EMAX], const int (&ei)[EMAX],
-                                               float& pcl_sum, int& mn) {
+                                               float& pcl_sum, int& mn, int nent = EMAX) {
   float* s_add = reinterpret_cast<float*>(s_raw);                      // [9][PCL_WIN] addends of a rank window, column-major
   constexpr int PCL_WIN = 136;                                         // 9 x 136 x 4 = 4896 bytes of the 5016
   static_assert(512 + 64 * EMAX * 8 <= NSUM * 33 * 8, "keys fit the buffer");
@@ -459,12 +460,12 @@ __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn
     eb[e] = (ed[e] < rn2) ? min(63, (int)(ed[e] * bscale)) : -1;
     key[e] = dist_index_key(ed[e], ei[e]);
   }
-  mn = wave_rank<EMAX>(lane, reinterpret_cast<uint32_t*>(s_raw), key, eb, er);
+  mn = wave_rank<EMAX>(lane, reinterpret_cast<uint32_t*>(s_raw), key, eb, er, nent);
   for (int w0 = 0; w0 < mn; w0 += PCL_WIN) {
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
       const int r = er[e] - w0;
-      if (er[e] >= 0 && r >= 0 && r < PCL_WIN) {
+      if (e < nent && er[e] >= 0 && r >= 0 && r < PCL_WIN) {
         const float x = ex[e], y = ey[e], z = ez[e];
         s_add[0 * PCL_WIN + r] = x * x; s_add[1 * PCL_WIN + r] = x * y; s_add[2 * PCL_WIN + r] = x * z;
         s_add[3 * PCL_WIN + r] = y * y; s_add[4 * PCL_WIN + r] = y * z; s_add[5 * PCL_WIN + r] = z * z;
@@ -504,6 +505,7 @@ __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn
 // 2 mm voxel cloud has at most ~314 inside 2 cm; beyond that the float64 sums stay).
 #define PCL_EMAX_SHORT 2
 #define PCL_EMAX_LONG (NBR_CAP / 64)
+#define PCL_LONG_SCAN 16
 template <bool PCL>
 __global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __restrict__ pts,
                                                       const int32_t* __restrict__ pt_off,
@@ -657,8 +659,9 @@ __global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __r
 }
 
 // The queries shot_cov_kernel<true> marked (more than 128 neighbours): the same float32 sums from the workspace copy of the
-// neighbour list, eight entries per lane.  Every wavefront looks at 64 queries' marks at a time and redoes the marked ones, one
-// after the other (a launch of one workgroup per query cost 60 us just to find that most had nothing to do).
+// neighbour list, up to eight entries per lane.  Every wavefront looks at PCL_LONG_SCAN queries' marks at a time and redoes the
+// marked ones, one after the other (a launch of one workgroup per query cost 60 us just to find that most had nothing to do; 64
+// queries per wavefront left a cloud at voxel-grid density -- every query marked -- with four wavefronts per SIMD).
 __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const float* __restrict__ pts, const int32_t* __restrict__ pt_off,
                                                            const float4* __restrict__ sorted_pts,
                                                            const int32_t* __restrict__ scene_of, float rn,
@@ -667,9 +670,9 @@ __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const 
   __shared__ __attribute__((aligned(16))) double s_raw[NSUM * (32 + 1)];
   const int lane = threadIdx.x;
   const float rn2 = rn * rn;
-  for (int64_t q0 = (int64_t)blockIdx.x * 64; q0 < total; q0 += (int64_t)gridDim.x * 64) {
+  for (int64_t q0 = (int64_t)blockIdx.x * PCL_LONG_SCAN; q0 < total; q0 += (int64_t)gridDim.x * PCL_LONG_SCAN) {
     bool todo = false;
-    if (q0 + lane < total) {
+    if (lane < PCL_LONG_SCAN && q0 + lane < total) {
       const double s9 = sums[(q0 + lane) * NSUM + 9];
       todo = s9 != floor(s9) && nbr_cnt[q0 + lane] <= NBR_CAP;      // (longer than this kernel's capacity: the float64 sums stay)
     }
@@ -682,11 +685,12 @@ __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const 
       const float px = pts[3 * qi], py = pts[3 * qi + 1], pz = pts[3 * qi + 2];
       float ex[PCL_EMAX_LONG], ey[PCL_EMAX_LONG], ez[PCL_EMAX_LONG], ed[PCL_EMAX_LONG];
       int ei[PCL_EMAX_LONG];
+      const int nent = (m + 63) >> 6;              // entry slots in use (wave-uniform): the others are skipped, not masked
 #pragma unroll
       for (int e = 0; e < PCL_EMAX_LONG; ++e) {
         const int c = lane + 64 * e;
         ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
-        if (c < m) {
+        if (e < nent && c < m) {
           const float4 qv = sp[nbr_list[qi * NBR_CAP + c]];
           const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
           if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const 
       float pcl_sum = 0.0f;
       int mn = 0;
       __syncthreads();
-      pcl_float_sums<PCL_EMAX_LONG>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn);
+      pcl_float_sums<PCL_EMAX_LONG>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn, nent);
       if (lane < 9) sums[qi * NSUM + lane] = (double)pcl_sum;
       if (lane == 9) sums[qi * NSUM + 9] = (double)mn;
     }
@@ -926,7 +930,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
                                                        const float4* __restrict__ sorted_lab = nullptr) {
   constexpr int LEN = COLOR ? SHOT_COLOR_LEN : SHOT_LEN;
   constexpr int HWORDS = COLOR ? SHOT_COLOR_LEN + 1 : SH_COPIES * SH_STRIDE;
-  __shared__ uint32_t s_hist[HWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_hist[HWORDS];
   uint32_t* hist = COLOR ? s_hist : s_hist + (threadIdx.x & (SH_COPIES - 1)) * SH_STRIDE;
   __shared__ int s_list[SH_LCAP];       // positions in the cell-sorted order
   __shared__ float s_rf[9];
@@ -1100,8 +1104,78 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
     c3 = __popcll(wave_ballot(h3a)) + __popcll(wave_ballot(h3b));
     if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
     if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
-  } else if (plus1 == 0 || plus3 == 0) {
-    // tie: the 5 neighbours around the median of the (distance, original index)-sorted valid list decide
+  } else if ((plus1 == 0 || plus3 == 0) && !(SHOT_DBG & 512)) {
+    // tie: the 5 neighbours around the median of the (distance, original index)-sorted valid list decide.  Only those five ranks
+    // matter: a first sweep counts the neighbours per distance bucket (64 buckets; a prefix sum gives every bucket's rank range),
+    // a second sweep collects the keys of the buckets that overlap ranks med - 2 .. med + 2 -- a handful -- and these are ranked
+    // among themselves.  (Ranking every neighbour against every other was 0.46 of shot_hist's 0.94 ms on clouds at the density
+    // of a 2 mm voxel grid, ~250 neighbours.)  More than 64 keys in those buckets (many equal distances): the exhaustive count below.
+    static_assert(HWORDS >= 64 + 128 + 64, "the tie-break tables live in the histogram buffer, which is still unused here");
+    bool ranked = false;
+    {
+      uint32_t* s_cnt = s_hist;                                                             // [64] neighbours per bucket
+      unsigned long long* s_ck = reinterpret_cast<unsigned long long*>(s_hist + 64);        // [64] collected keys
+      int* s_cj = reinterpret_cast<int*>(s_hist + 64 + 128);                                // [64] their list positions
+      const float bscale = 64.0f * __builtin_amdgcn_rcpf(r2);
+      s_cnt[lane] = 0u;
+      __syncthreads();
+      FOR_EACH_NEIGHBOUR({
+        if (act) {
+          const float4 qv = sp[j];
+          if (!(qv.x == px && qv.y == py && qv.z == pz))
+            atomicAdd(&s_cnt[min(63, (int)(sqdist3(px, py, pz, qv.x, qv.y, qv.z) * bscale))], 1u);
+        }
+      })
+      __syncthreads();
+      const int cnt = (int)s_cnt[lane];
+      const int incl = (int)wave_inclusive_scan_u32((uint32_t)cnt), excl = incl - cnt;
+      const unsigned long long overlap = wave_ballot(cnt > 0 && excl <= med + 2 && incl > med - 2);
+      int nc = 0, base = 0, b_lo = 64, b_hi = -1;
+      if (overlap) {
+        b_lo = __builtin_ctzll(overlap);
+        b_hi = 63 - __builtin_clzll(overlap);
+        base = __shfl(excl, b_lo);
+        FOR_EACH_NEIGHBOUR({
+          bool cand = false;
+          unsigned long long key = 0ull;
+          if (act) {
+            const float4 qv = sp[j];
+            if (!(qv.x == px && qv.y == py && qv.z == pz)) {
+              const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
+              const int bk = min(63, (int)(d2 * bscale));
+              cand = bk >= b_lo && bk <= b_hi;
+              key = dist_index_key(d2, __float_as_int(qv.w));
+            }
+          }
+          const unsigned long long cmask = wave_ballot(cand);
+          if (cand) {
+            const int pos = nc + lanes_below(cmask);
+            if (pos < 64) { s_ck[pos] = key; s_cj[pos] = j; }
+          }
+          nc += __popcll(cmask);
+        })
+      }
+      __syncthreads();
+      if (nc <= 64) {
+        ranked = true;
+        bool h1 = false, h3 = false;
+        if (lane < nc) {
+          const unsigned long long key = s_ck[lane];
+          int rank = base;
+          for (int c2 = 0; c2 < nc; ++c2) rank += (s_ck[c2] < key) ? 1 : 0;
+          if (rank >= med - 2 && rank <= med + 2) {
+            const float4 qv = sp[s_cj[lane]];
+            const double x = (double)(qv.x - px), y = (double)(qv.y - py), z = (double)(qv.z - pz);
+            h1 = ((x * v1[0] + y * v1[1]) + z * v1[2]) > 0.0;
+            h3 = ((x * v3[0] + y * v3[1]) + z * v3[2]) > 0.0;
+          }
+        }
+        c1 = __popcll(wave_ballot(h1));
+        c3 = __popcll(wave_ballot(h3));
+      }
+      __syncthreads();
+    }
+    if (!ranked) {
     FOR_EACH_NEIGHBOUR({
       bool h1 = false, h3 = false;
       if (act) {
@@ -1140,6 +1214,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
       c1 += __popcll(wave_ballot(h1));
       c3 += __popcll(wave_ballot(h3));
     })
+    }
     if (plus1 == 0) plus1 = (c1 < 3) ? -1 : 1;
     if (plus3 == 0) plus3 = (c3 < 3) ? -1 : 1;
   }
@@ -1309,7 +1384,7 @@ static int shot_run(int B, const float* pts, const int32_t* pt_off, int64_t n, f
              (want_s || pcl) ? w.nbr_cnt : (int32_t*)nullptr);
   CPPF_LAUNCH_CHECK();
   if (pcl && want_n) {
-    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN < 16384 ? (n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN : 16384)), dim3(64), 0, st, n, pts, pt_off,
                        (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, rn, (const int32_t*)w.nbr_list,
                        (const int32_t*)w.nbr_cnt, w.sums);
     CPPF_LAUNCH_CHECK();
@@ -1380,7 +1455,7 @@ extern "C" int cppf_shot_prepare(int B, const float* pts, const int32_t* pt_off,
              (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
   CPPF_LAUNCH_CHECK();
   if (pcl) {
-    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN < 16384 ? (n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN : 16384)), dim3(64), 0, st, n, pts, pt_off,
                        (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, (const int32_t*)w.nbr_list,
                        (const int32_t*)w.nbr_cnt, w.sums);
     CPPF_LAUNCH_CHECK();
@@ -1440,7 +1515,7 @@ extern "C" int cppf_shot1344(int B, const float* pts, const float* colors, const
              (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, shot_r, w.sums, w.nbr_list, w.nbr_cnt);
   CPPF_LAUNCH_CHECK();
   if (pcl) {
-    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192)), dim3(64), 0, st, n, pts, pt_off,
+    hipLaunchKernelGGL(shot_pcl_long_kernel, dim3((unsigned)((n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN < 16384 ? (n + PCL_LONG_SCAN - 1) / PCL_LONG_SCAN : 16384)), dim3(64), 0, st, n, pts, pt_off,
                        (const float4*)w.sorted_pts, (const int32_t*)w.scene_of, normal_r, (const int32_t*)w.nbr_list,
                        (const int32_t*)w.nbr_cnt, w.sums);
     CPPF_LAUNCH_CHECK();

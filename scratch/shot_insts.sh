@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/si && mkdir -p /tmp/si
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/si/a -- python3 $R/scratch/shot_stage.py "$@" > /tmp/si/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/si/b -- python3 $R/scratch/shot_stage.py "$@" > /tmp/si/b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/si/a -- python3 $R/scratch/${SCRIPT:-shot_stage.py} "$@" > /tmp/si/a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/si/b -- python3 $R/scratch/${SCRIPT:-shot_stage.py} "$@" > /tmp/si/b.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()

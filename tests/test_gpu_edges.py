@@ -113,6 +113,33 @@ def test_shot_different_radii(arithmetic):
     assert _desc_close(hs.reshape(-1, 352)[ok], os_[ok], d[ok], arithmetic)
 
 
+@pytest.mark.parametrize("arithmetic", ["f64", "pcl"])
+def test_shot_tie_break_with_many_equal_distances(arithmetic):
+    """The sign tie-break of the local reference frame (the 5 neighbours around the median of the (distance, index) order) where
+    shot_hist's selection by distance buckets cannot narrow the candidates down: 220 neighbours in antipodal pairs on a ring around
+    the query (sign counts tie exactly; all distances fall into one or two of the 64 buckets, more than the 64 keys the selection
+    holds), so the exhaustive count decides -- against the oracle, like every other row of the cloud."""
+    q = 2.0 ** -14
+    rng = np.random.RandomState(3)
+    n_pairs = 110
+    th = rng.rand(n_pairs) * np.pi
+    off = np.stack([np.cos(th) * 0.01, np.sin(th) * 0.01, (rng.rand(n_pairs) - 0.5) * 0.004], 1)
+    off = (np.round(off / q) * q).astype(np.float32)
+    c = np.float32([0.5, 0.5, 0.5])
+    pc = np.concatenate([c[None], c + off, c - off]).astype(np.float32)
+    assert np.array_equal(pc[1:1 + n_pairs] - c, -(pc[1 + n_pairs:] - c))          # exact antipodal pairs in float32
+    d2 = ((pc[1:] - c) ** 2).sum(1)
+    assert d2.max() - d2.min() < 2 * 0.02 ** 2 / 64                                  # at most two distance buckets
+    hs, hn = shot.compute(pc, 0.02, 0.02, arithmetic=arithmetic)
+    os_, on, d = _shot_oracle(pc, 0.02, 0.02, arithmetic)
+    hs, hn = hs.reshape(-1, 352), hn.reshape(-1, 3)
+    assert np.array_equal(np.isnan(os_), np.isnan(hs)) and not np.isnan(os_[0]).any()
+    assert np.allclose(hn, on, atol=NORMAL_TOL[arithmetic], equal_nan=True)
+    ok = ~np.isnan(os_).any(1)
+    assert _desc_close(hs[ok], os_[ok], d[ok], arithmetic)
+    assert np.abs(hs[0] - os_[0]).max() < 5e-5                                       # the ring's centre: the tied query
+
+
 def test_vote_center_two_call_form_equals_single_call():
     """CPPF_VC_FRAMES_ONLY + CPPF_VC_FRAMES_READY (the form bench.py times the vote kernel with) == one call."""
     from cppf2_amd import ops, synth
