@@ -1159,13 +1159,15 @@ def main():
     end_pool = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     step_ends = {}
 
-    def completion_intervals(ends):
-        if len(ends) < 3:
+    def completion_intervals(ends, group=1):
+        """ms per step between step completions.  group = number of streams: concurrent steps run side by side and complete
+        within a millisecond of each other, so the figure is the time from completion i to completion i + group, divided by group."""
+        if len(ends) < group + 2:
             return None
         t = sorted(ends[0].elapsed_time(e) for e in ends)
-        d = sorted(b_ - a_ for a_, b_ in zip(t[:-1], t[1:]))
+        d = sorted((b_ - a_) / group for a_, b_ in zip(t[:-group], t[group:]))
         return {"min": round(d[0], 4), "median": round(d[len(d) // 2], 4), "max": round(d[-1], 4), "n": len(d),
-                "p05": round(d[int(0.05 * len(d))], 4), "p95": round(d[int(0.95 * len(d))], 4)}
+                "p05": round(d[int(0.05 * len(d))], 4), "p95": round(d[int(0.95 * len(d))], 4), "steps_per_interval": group}
 
     def timed_loop(k, sample=True, pair=None):
         """EXACTLY k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds.
@@ -1236,7 +1238,7 @@ def main():
                     s_.run()
         torch.cuda.synchronize()
         dt, evs = timed_loop(args.steps, pair=pair)
-        intervals = completion_intervals(step_ends[id(pair)])
+        intervals = completion_intervals(step_ends[id(pair)], group=len(pair[1]))
         same = bool(all(torch.equal(s_.pipe.results, ref_rec) for s_ in pair[0]))
         dt_single, evs_single = timed_loop(args.steps)
         intervals_single = completion_intervals(step_ends[id(None)])
