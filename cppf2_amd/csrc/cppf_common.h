@@ -189,7 +189,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
   return v;
 }
-// upper_half: lane l < 32 gets lane l + 32's value (v_permlane32_swap, gfx950); lanes >= 32: unspecified.
+// upper_half: lane l < 32 gets lane l + 32's value (v_permlane32_swap, gfx950); lanes >= 32: unspecified.  Call it with the whole
+// wavefront active (inside a branch only lanes < 32 take, the upper half's registers are not read).
 __device__ __forceinline__ uint32_t upper_half(uint32_t v) {
   return __builtin_amdgcn_permlane32_swap(v, v, false, false)[1];
 }
