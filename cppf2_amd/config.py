@@ -48,6 +48,12 @@ def _merge(dst, src):
 def load_config(config_dir="config", config_name="config", overrides=(), with_hydra=False):
     """Resolves `defaults:` groups and applies `a.b=value` overrides.  Returns a Cfg; with_hydra=True returns (cfg, hydra
     node) -- the `hydra:` block (run.dir etc., config/config.yaml:16-22) is not part of the cfg the code sees, as with hydra."""
+    if not os.path.isabs(config_dir) and not os.path.isdir(config_dir):
+        # a relative directory that does not exist under the working directory: the repository's own config/ tree (the entry
+        # points are started from anywhere; hydra resolves config_path relative to the script, train_shot.py:159)
+        here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), config_dir)
+        if os.path.isdir(here):
+            config_dir = here
     with open(os.path.join(config_dir, config_name + ".yaml")) as f:
         raw = yaml.safe_load(f) or {}
     groups = {}

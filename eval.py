@@ -112,7 +112,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                  imp_wt_margin=0.01, backproj_ratio=.1, opt=False, geo_branch=True, visual_branch=True, up_sym=False,
                  priors=None, keep=False, scale_priors=None, two_streams=True):
     """eval.py:207-372 for a batch of instances of one category.  pcs: list of float32 [N_b,3]; descs: list of float32
-    [N_b,1024] (DINOv2 features at the points: inputs to the path); priors: optional callable(idx_global, base) -> logit
+    [N_b,1024] arrays or (device) tensors (DINOv2 features at the points: inputs to the path); priors: optional callable(idx_global, base) -> logit
     prior [T,6,nb] added to both models' logits; scale_priors: optional float32 [B,3] teacher box extents that stand in for
     the scale head of random-init weights (the head's output stays in the sum at 1e-3).  Returns dict(records=[2 x
     structured array], losses float64 [2,B], pick int [B], scale, scale_norm, idx, pipe, ...).
@@ -137,7 +137,10 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                           cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
     # eval.py:207 -- one tuple table per instance, shared by both models
     idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in zip(scene_ids, Ns)])
-    desc = torch.from_numpy(np.concatenate(descs)).to(dev)
+    # descriptors: device tensors stay where they are (main_nocs samples them on the GPU), host arrays are uploaded one by one --
+    # the batch is assembled on the device, not by a host-side copy of its largest input (16.8 MB per 4096 points)
+    desc = torch.cat([d.to(dev) if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32)).to(dev)
+                      for d in descs])
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
     prior = priors(idx, base) if priors is not None else None
     scale_prior = None
@@ -320,7 +323,7 @@ def image_instances(res, data_root, cfgs, seed, image_index, intrinsics=REAL_INT
             kp_local = (np.linalg.inv(transform) @ np.concatenate([kp, np.ones((kp.shape[0], 1))], -1).T).T[:, :2]
             tok = np.asarray(tok, dtype=np.float32)
             desc = ops.interpolate_features(torch.from_numpy(tok)[None], kp_local.astype(np.float32)[None], strides=4)[0].T
-            desc = desc.contiguous().cpu().numpy()
+            desc = desc.contiguous()               # stays on the device until its batch is evaluated (run_ensemble)
         yield dict(i=i, cat=cat, pc=pc, desc=desc, pixels=idxs)
 
 
@@ -343,42 +346,57 @@ def main_nocs(setups, log_dir, data_root="NOCS/real_test", out_dir=None, desc_np
     token_maps = np.load(desc_npz) if desc_npz else None
     cfgs = {c: s[0] for c, s in setups.items()}
     K = REAL_INTRINSICS if intrinsics is None else intrinsics
-    todo = {c: [] for c in setups}                      # category -> [(image index, instance index, global instance id, pc, desc)]
+    # Instances are evaluated as they come: every category keeps at most `batch_instances` pending instances (point cloud +
+    # descriptors, the latter on the device) and is flushed through run_ensemble when the batch is full -- the same batches, in
+    # the same order per category, as collecting the whole list first, with memory bounded by the batch (a full REAL275 run has
+    # ~12 000 instances x up to 200 MB of descriptors).
+    pending = {c: [] for c in setups}               # category -> [(image index, instance index, global instance id, pc, desc)]
+    seen = {c: 0 for c in setups}
+    evaluated = 0
+    picks = {"dino": 0, "shot": 0, "none": 0}
+
+    def flush(cat):
+        nonlocal evaluated
+        chunk, pending[cat] = pending[cat], []
+        if not chunk:
+            return
+        cfg, dino_model, shot_model = setups[cat]
+        descs = []
+        for (_, _, g_, pc, desc) in chunk:
+            if desc is None:
+                gen = torch.Generator(device="cpu").manual_seed(seed * 7919 + g_ + 1)
+                desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen), dim=-1).numpy()
+            descs.append(desc)
+        r = run_ensemble(cfg, dino_model, shot_model, [c_[3] for c_ in chunk], descs, seed, [c_[2] for c_ in chunk],
+                         num_pairs, num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch,
+                         visual_branch, cat in UP_SYM)
+        for b, (n_img, i, _, _, _) in enumerate(chunk):
+            evaluated += 1
+            if r["pick"][b] < 0:
+                picks["none"] += 1
+                continue
+            picks[["dino", "shot"][r["pick"][b]]] += 1
+            rec = r["records"][r["pick"][b]][b]
+            res = final_results[n_img]
+            res["pred_RTs"][i][:3, :3] = rec["R"] * r["scale_norm"][b]                 # eval.py:370
+            res["pred_RTs"][i][:3, -1] = rec["t"]                                      # eval.py:371
+            if r["scale_norm"][b] > 0:
+                res["pred_scales"][i] = r["scale"][b] / r["scale_norm"][b]              # eval.py:372
+
     gid = 0
     for n_img, res in enumerate(final_results):
         nb = len(res["pred_bboxes"])
         res["pred_RTs"] = np.stack([np.eye(4) for _ in range(nb)]) if nb else np.zeros((0, 4, 4))      # eval.py:143
         res["pred_scales"] = np.stack([np.ones((3,)) for _ in range(nb)]) if nb else np.zeros((0, 3))  # eval.py:144
         for inst in image_instances(res, data_root, cfgs, seed, n_img, K, token_maps):
-            todo[inst["cat"]].append((n_img, inst["i"], gid + inst["i"], inst["pc"], inst["desc"]))
+            cat = inst["cat"]
+            pending[cat].append((n_img, inst["i"], gid + inst["i"], inst["pc"], inst["desc"]))
+            seen[cat] += 1
+            if len(pending[cat]) >= int(batch_instances):
+                flush(cat)
         gid += nb
-    evaluated = skipped = 0
-    picks = {"dino": 0, "shot": 0, "none": 0}
-    for cat, items in todo.items():
-        cfg, dino_model, shot_model = setups[cat]
-        for lo in range(0, len(items), int(batch_instances)):
-            chunk = items[lo:lo + int(batch_instances)]
-            descs = []
-            for (_, _, g_, pc, desc) in chunk:
-                if desc is None:
-                    gen = torch.Generator(device="cpu").manual_seed(seed * 7919 + g_ + 1)
-                    desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen), dim=-1).numpy()
-                descs.append(desc)
-            r = run_ensemble(cfg, dino_model, shot_model, [c_[3] for c_ in chunk], descs, seed, [c_[2] for c_ in chunk],
-                             num_pairs, num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch,
-                             visual_branch, cat in UP_SYM)
-            for b, (n_img, i, _, _, _) in enumerate(chunk):
-                evaluated += 1
-                if r["pick"][b] < 0:
-                    picks["none"] += 1
-                    continue
-                picks[["dino", "shot"][r["pick"][b]]] += 1
-                rec = r["records"][r["pick"][b]][b]
-                res = final_results[n_img]
-                res["pred_RTs"][i][:3, :3] = rec["R"] * r["scale_norm"][b]                 # eval.py:370
-                res["pred_RTs"][i][:3, -1] = rec["t"]                                      # eval.py:371
-                if r["scale_norm"][b] > 0:
-                    res["pred_scales"][i] = r["scale"][b] / r["scale_norm"][b]              # eval.py:372
+    for cat in setups:
+        flush(cat)
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
         for res in final_results:
@@ -388,7 +406,7 @@ def main_nocs(setups, log_dir, data_root="NOCS/real_test", out_dir=None, desc_np
     total = sum(len(r_["pred_bboxes"]) for r_ in final_results)
     iou_aps, aps = metrics.degree_cm_mAP(final_results, metrics.SYNSET_NAMES, (5, 10, 15), (5, 10, 15),
                                          np.linspace(0, 1, 101), 0.1, True)                # eval.py:400-411
-    cats = [c for c in setups if todo[c]]
+    cats = [c for c in setups if seen[c]]
 
     def mean_over(fn):
         v = [fn(category2id[c]) for c in cats]
