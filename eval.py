@@ -363,9 +363,9 @@ def main_nocs(setups, log_dir, data_root="NOCS/real_test", out_dir=None, desc_np
         cfg, dino_model, shot_model = setups[cat]
         descs = []
         for (_, _, g_, pc, desc) in chunk:
-            if desc is None:
-                gen = torch.Generator(device="cpu").manual_seed(seed * 7919 + g_ + 1)
-                desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen), dim=-1).numpy()
+            if desc is None:                      # no token maps: seeded unit vectors, drawn on the device (per-instance stream)
+                gen = torch.Generator(device=dev).manual_seed(seed * 7919 + g_ + 1)
+                desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen, device=dev), dim=-1)
             descs.append(desc)
         r = run_ensemble(cfg, dino_model, shot_model, [c_[3] for c_ in chunk], descs, seed, [c_[2] for c_ in chunk],
                          num_pairs, num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch,
