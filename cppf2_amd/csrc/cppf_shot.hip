@@ -662,6 +662,32 @@ __global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __r
 // neighbour list, up to eight entries per lane.  Every wavefront looks at PCL_LONG_SCAN queries' marks at a time and redoes the
 // marked ones, one after the other (a launch of one workgroup per query cost 60 us just to find that most had nothing to do; 64
 // queries per wavefront left a cloud at voxel-grid density -- every query marked -- with four wavefronts per SIMD).
+// One marked query with NENT entry slots per lane (lists of up to 64 NENT neighbours): gathered from the workspace list, ranked,
+// summed.  A template so that a list of 251 neighbours costs four slots of ranking and addend writes, not the capacity's eight.
+template <int NENT>
+__device__ __forceinline__ void pcl_long_query(int lane, double* s_raw, int64_t qi, int m, float rn2, const float4* __restrict__ sp,
+                                               float px, float py, float pz, const int32_t* __restrict__ my_list,
+                                               double* __restrict__ sums) {
+  float ex[NENT], ey[NENT], ez[NENT], ed[NENT];
+  int ei[NENT];
+#pragma unroll
+  for (int e = 0; e < NENT; ++e) {
+    const int c = lane + 64 * e;
+    ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
+    if (c < m) {
+      const float4 qv = sp[(unsigned)my_list[c]];
+      const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
+      if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
+    }
+  }
+  float pcl_sum = 0.0f;
+  int mn = 0;
+  __syncthreads();
+  pcl_float_sums<NENT>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn);
+  if (lane < 9) sums[qi * NSUM + lane] = (double)pcl_sum;
+  if (lane == 9) sums[qi * NSUM + 9] = (double)mn;
+}
+
 __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const float* __restrict__ pts, const int32_t* __restrict__ pt_off,
                                                            const float4* __restrict__ sorted_pts,
                                                            const int32_t* __restrict__ scene_of, float rn,
@@ -683,25 +709,15 @@ __global__ __launch_bounds__(64) void shot_pcl_long_kernel(int64_t total, const 
       const int m = nbr_cnt[qi];
       const float4* sp = sorted_pts + (int64_t)pt_off[scene_of[qi]];
       const float px = pts[3 * qi], py = pts[3 * qi + 1], pz = pts[3 * qi + 2];
-      float ex[PCL_EMAX_LONG], ey[PCL_EMAX_LONG], ez[PCL_EMAX_LONG], ed[PCL_EMAX_LONG];
-      int ei[PCL_EMAX_LONG];
-      const int nent = (m + 63) >> 6;              // entry slots in use (wave-uniform): the others are skipped, not masked
-#pragma unroll
-      for (int e = 0; e < PCL_EMAX_LONG; ++e) {
-        const int c = lane + 64 * e;
-        ed[e] = INFINITY; ex[e] = ey[e] = ez[e] = 0.0f; ei[e] = 0;
-        if (e < nent && c < m) {
-          const float4 qv = sp[nbr_list[qi * NBR_CAP + c]];
-          const float d2 = sqdist3(px, py, pz, qv.x, qv.y, qv.z);
-          if (d2 < rn2) { ex[e] = qv.x; ey[e] = qv.y; ez[e] = qv.z; ed[e] = d2; ei[e] = __float_as_int(qv.w); }
-        }
+      const int32_t* my_list = nbr_list + qi * NBR_CAP;
+      static_assert(PCL_EMAX_LONG == 8, "the dispatch below covers 3 .. 8 entry slots");
+      switch ((m + 63) >> 6) {                     // wave-uniform: m comes from a scalar load
+        case 0: case 1: case 2: case 3: pcl_long_query<3>(lane, s_raw, qi, m, rn2, sp, px, py, pz, my_list, sums); break;
+        case 4: pcl_long_query<4>(lane, s_raw, qi, m, rn2, sp, px, py, pz, my_list, sums); break;
+        case 5: pcl_long_query<5>(lane, s_raw, qi, m, rn2, sp, px, py, pz, my_list, sums); break;
+        case 6: pcl_long_query<6>(lane, s_raw, qi, m, rn2, sp, px, py, pz, my_list, sums); break;
+        default: pcl_long_query<8>(lane, s_raw, qi, m, rn2, sp, px, py, pz, my_list, sums); break;
       }
-      float pcl_sum = 0.0f;
-      int mn = 0;
-      __syncthreads();
-      pcl_float_sums<PCL_EMAX_LONG>(lane, s_raw, rn2, ex, ey, ez, ed, ei, pcl_sum, mn, nent);
-      if (lane < 9) sums[qi * NSUM + lane] = (double)pcl_sum;
-      if (lane == 9) sums[qi * NSUM + 9] = (double)mn;
     }
   }
 }
