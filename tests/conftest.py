@@ -27,7 +27,14 @@ _LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_A
                "CPPF_DIST_FORCE_COLLECTIVE")
 
 
-def _start_bench(tmpdir, tag, argv, scenes=4, counters=False, **env_add):
+# a job with delay > 0 is started by this stub (which never touches the GPU): it sleeps, runs bench.py as its child and exits with
+# the child's code -- the counter passes of the "counters" job then measure before the multi-rank jobs load the GPU
+_DELAYED = ("import subprocess, sys, time\n"
+            "time.sleep(float(sys.argv[1]))\n"
+            "sys.exit(subprocess.call([sys.executable] + sys.argv[2:]))\n")
+
+
+def _start_bench(tmpdir, tag, argv, scenes=4, counters=False, delay=0.0, **env_add):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
     env.update(env_add)
@@ -35,8 +42,9 @@ def _start_bench(tmpdir, tag, argv, scenes=4, counters=False, **env_add):
     err = open(os.path.join(tmpdir, tag + ".err"), "w")
     small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
              "--no-native-arith"] + ([] if counters else ["--no-counters"])
-    return (subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + argv + small, env=env, stdout=out,
-                             stderr=err, cwd=ROOT), out.name, err.name)
+    cmd = [os.path.join(ROOT, "bench.py")] + argv + small
+    cmd = [sys.executable] + cmd if delay <= 0 else [sys.executable, "-c", _DELAYED, str(delay)] + cmd
+    return (subprocess.Popen(cmd, env=env, stdout=out, stderr=err, cwd=ROOT), out.name, err.name)
 
 
 def _start_bench_jobs(tmpdir):
@@ -54,9 +62,9 @@ def _start_bench_jobs(tmpdir):
         # the counter passes of a default run: bench.py starts rocprofv3 children of itself before it touches the GPU
         "counters": _start_bench(tmpdir, "counters", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], counters=True),
         "eight_ranks": _start_bench(tmpdir, "eight_ranks", ["--gpus", "8", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=2,
-                                    CPPF_BENCH_BACKEND="gloo"),
+                                    delay=25.0, CPPF_BENCH_BACKEND="gloo"),
         "one_rank_16": _start_bench(tmpdir, "one_rank_16", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=16),
-        "two_ranks": _start_bench(tmpdir, "two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo"),
+        "two_ranks": _start_bench(tmpdir, "two_ranks", ["--gpus", "2"], delay=15.0, CPPF_BENCH_BACKEND="gloo"),
         "rccl_one_rank": _start_bench(tmpdir, "rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1",
                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
         "refuse_two_gpus": _start_bench(tmpdir, "refuse_two_gpus", ["--gpus", "2"]),
