@@ -948,7 +948,7 @@ __global__ __launch_bounds__(64) void shot_hist_kernel(int B, const float* __res
   constexpr int HWORDS = COLOR ? SHOT_COLOR_LEN + 1 : SH_COPIES * SH_STRIDE;
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[HWORDS];
   uint32_t* hist = COLOR ? s_hist : s_hist + (threadIdx.x & (SH_COPIES - 1)) * SH_STRIDE;
-  __shared__ int s_list[SH_LCAP];       // positions in the cell-sorted order
+  __shared__ __attribute__((aligned(16))) int s_list[SH_LCAP];       // positions in the cell-sorted order (its upper part doubles as 64-bit key storage)
   __shared__ float s_rf[9];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
