@@ -298,6 +298,63 @@ def test_pipeline_vs_oracle_ragged_batch(use_lut):
         t0 += T
 
 
+@pytest.mark.parametrize("cfg_seed", list(range(10)))
+def test_pipeline_vs_oracle_random_configurations(cfg_seed):
+    """The whole post-MLP path (bin draw, vote parameters, centre vote, arg-max, back-vote filter, both rotation votes, pose) on
+    configurations drawn from a seed -- batch size, ragged point / tuple counts down to a few dozen, rotation counts that are not a
+    multiple of the vote quantum, cell sizes, axis assignments, noisy teachers -- against the oracle, same bars as the ragged-batch
+    test (integers, masks, weights and translations bit for bit; rotation-bin counts up to the tanf cone flips)."""
+    rng = np.random.RandomState(1000 + cfg_seed)
+    B = int(rng.randint(1, 5))
+    Ns = [int(rng.randint(40, 1400)) for _ in range(B)]
+    Ts = [int(rng.randint(150, 3600)) for _ in range(B)]
+    R = int(rng.choice([5, 8, 13, 36, 59, 97, 120, 181]))
+    res = float(rng.choice([1.5e-3, 2e-3, 3e-3, 5e-3]))
+    axes = [[0, 1, 0], [1, 0, 0], [0, 0, 1]]
+    perm = rng.permutation(3)
+    up, right, front = axes[perm[0]], axes[perm[1]], axes[perm[2]]
+    sigma = float(rng.choice([0.4, 0.6, 1.5]))
+    scenes = [_scene_inputs(50 + cfg_seed, s, Ns[s], Ts[s], rng, sigma=sigma) for s in range(B)]
+    pipe = VotingPipeline(Ns, Ts, k=5, res=res, num_rots=R, cells_cap=1 << 21, cfg_up=tuple(up), cfg_right=tuple(right),
+                          cfg_front=tuple(front))
+    pts = dev(np.concatenate([s[0]["pc"] for s in scenes]), torch.float32)
+    idx = dev(np.concatenate([s[1] for s in scenes]), torch.int32)
+    logits = dev(np.concatenate([s[2] for s in scenes]), torch.float32)
+    u = dev(np.concatenate([s[3] for s in scenes]), torch.float32)
+    sc = dev(np.concatenate([s[4] for s in scenes]), torch.float32)
+    rec = pipe.results_to_numpy(pipe.vote(pts, idx, logits, u, sc))
+    trig = (pipe.cs.cpu().numpy(), pipe.sn.cpu().numpy())
+    bins_all = pipe.bins.cpu().numpy()
+    t0 = 0
+    for s, (scene, idx_s, lg, us, scl) in enumerate(scenes):
+        T = Ts[s]
+        ob = O.decode_bins(lg, us, scene["pc"][idx_s[:, :2]], return_margin=True)
+        flips = (ob[0] != bins_all[t0:t0 + T])
+        assert np.all(ob[4][flips] < 1e-5)
+        onehot = np.full((T, 6, 32), -1e4, np.float32)
+        np.put_along_axis(onehot, bins_all[t0:t0 + T, :, None].astype(np.int64), 0.0, -1)
+        want = O.run_scene(scene["pc"], idx_s, onehot, scl, us, up, right, front, res, num_rots=R, trig=trig)
+        r = rec[s]
+        assert r["argmax"] == want["argmax"] and r["peak"] == want["grid_obj"].max(), (cfg_seed, s)
+        assert np.array_equal(r["t"], want["T_est"])
+        assert r["kept"] == int(want["pairs_mask"].sum())
+        assert np.array_equal(pipe.mask.cpu().numpy()[t0:t0 + T].astype(bool), want["pairs_mask"])
+        assert np.array_equal(pipe.errs.cpu().numpy()[t0:t0 + T], want["back_errs"])
+        assert np.float32(pipe.thr.cpu().numpy()[s]) == np.float32(want["thr"])
+        kept = r["kept"]
+        assert np.array_equal(pipe.kept_wt.cpu().numpy()[t0:t0 + kept], want["imp_pair_wt"])
+        for a, name in ((0, "up"), (1, "right")):
+            got_c = pipe.counts[a, s].cpu().numpy()
+            d = np.abs(got_c - want[name + "_counts"])
+            assert (d > 0).sum() <= 4 and d.max() <= 2.0 / want["imp_pair_wt"].min(), (cfg_seed, s, name, int((d > 0).sum()), float(d.max()))
+            # the arg-max bin may legitimately differ only where the cone flips touch the top count
+            if int(r[name + "_idx"]) != want[name + "_idx"]:
+                top = np.sort(want[name + "_counts"])[-2:]
+                assert top[1] - top[0] <= 2.0 * d.max() + 1e-6, (cfg_seed, s, name)
+        assert np.array_equal(r["scale"], want["pred_scale"])
+        t0 += T
+
+
 def test_rot_bins_lut_equals_dense_full_size(full_summary):
     """Size-independent property at the full configuration (4096 x 20k x 180): the windowed search over
     cell->bins lookup table returns exactly the exhaustive counts; and both agree with the golden reference summary."""
