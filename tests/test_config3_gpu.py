@@ -194,6 +194,33 @@ def test_run_ensemble_is_the_same_with_the_bin_draw_fused_into_the_mlp(ev):
     assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["pick"], b["pick"])
 
 
+@pytest.mark.parametrize("cfg_seed", [0, 1, 2])
+def test_run_ensemble_ragged_random_sizes_fused_equals_materialised(ev, cfg_seed):
+    """The product path (rows gathered / tables summed inside the first layers, bins drawn in the output layers' epilogues, scale
+    head on the kept pairs, two streams) against the materialised one-stream form (keep=True) on batches drawn from a seed: 1-5
+    instances of 150-5000 points each (ragged), 700-9000 pairs (not a multiple of any tile), 24-180 rotations, a random category,
+    refinement on or off: records, losses and picks byte for byte."""
+    rng = np.random.RandomState(4000 + cfg_seed)
+    dev = torch.device("cuda:0")
+    cat = ["bottle", "bowl", "camera", "can", "laptop", "mug"][int(rng.randint(6))]
+    cfg, dino, shot_m = ev.load_category(cat, device=dev)
+    B = int(rng.randint(1, 6))
+    Ns = [int(rng.randint(150, 5000)) for _ in range(B)]
+    T = int(rng.randint(700, 9000))
+    R = int(rng.choice([24, 45, 72, 97, 180]))
+    ids = [int(x) for x in rng.randint(0, 1000, size=B)]
+    scenes = [synth.make_scene(7 + cfg_seed, i, n) for i, n in zip(ids, Ns)]
+    g = torch.Generator().manual_seed(cfg_seed)
+    descs = [torch.nn.functional.normalize(torch.randn((n, 1024), generator=g), dim=-1).numpy() for n in Ns]
+    prior = ev._teacher_prior(np.concatenate([s["pc_canon"] for s in scenes]), dev)
+    kw = dict(priors=prior, scale_priors=np.stack([s["extent"] for s in scenes]), opt=bool(rng.randint(2)), up_sym=cat in ev.UP_SYM)
+    a = ev.run_ensemble(cfg, dino, shot_m, [s["pc"] for s in scenes], descs, 11, ids, T, R, keep=True, **kw)
+    b = ev.run_ensemble(cfg, dino, shot_m, [s["pc"] for s in scenes], descs, 11, ids, T, R, keep=False, **kw)
+    for m in (0, 1):
+        assert a["records"][m].tobytes() == b["records"][m].tobytes(), (cat, B, Ns, T, R, m)
+    assert np.array_equal(a["losses"], b["losses"], equal_nan=True) and np.array_equal(a["pick"], b["pick"])
+
+
 def test_run_ensemble_on_two_streams_equals_the_one_stream_order(ev):
     """The product's batch mode (DINO pass and SHOT pass on two HIP streams, twin pipelines) writes the same records, losses and
     picks as the one-stream order -- three times in a row (the streams and their scratch buffers are reused)."""
