@@ -31,6 +31,7 @@ import torch
 from cppf2_amd import geometry, ops, shot, synth
 from cppf2_amd.config import load_checkpoint_config, load_config
 from cppf2_amd.models import BeyondCPPFDino, BeyondCPPFShot, load_reference_checkpoint
+from cppf2_amd.ops import get_topk_dir  # noqa: F401  (the reference defines it in this file, eval.py:37-51; demo.py and the notebook import it from here)
 from cppf2_amd.pipeline import VotingPipeline
 
 id2category = {1: "bottle", 2: "bowl", 3: "camera", 4: "can", 5: "laptop", 6: "mug"}     # dataset.py:29-37

@@ -20,6 +20,7 @@ import torch
 from cppf2_amd import ops, shot
 from cppf2_amd.config import load_config, run_dir, save_run_config
 from cppf2_amd.models import BeyondCPPFShot
+from cppf2_amd.models import BeyondCPPFShot as BeyondCPPF  # noqa: F401  (the class name in the reference's file: eval.py:18 imports it)
 from cppf2_amd.training import checkpoint_dir, cppf_losses, make_dataset, save_checkpoint
 
 
