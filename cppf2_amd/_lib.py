@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 if os.environ.get("CPPF_LIB"):           # a differently built library (probe builds under scratch/); same ABI version required
     LIB_PATH = os.path.abspath(os.environ["CPPF_LIB"])
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class CppfError(RuntimeError):
@@ -98,6 +98,7 @@ SIGNATURES = {
     "cppf_refine_pose": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p]),
     "cppf_interpolate_features": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _p, _i, _f, _i, _p, _i, _p]),
     "cppf_backproject": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "cppf_backproject64": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
     "cppf_voxel_downsample_workspace_bytes": (_i64, [_i64]),
     "cppf_voxel_downsample": (_i, [_p, _i, _f, _u64, _p, _p, _p, _i64, _p]),
     "cppf_reslayer128": (_i, [_p, _i64, _p, _p, _p, _p]),

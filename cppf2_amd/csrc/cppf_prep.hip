@@ -30,9 +30,12 @@ struct Mat3d {
 // One workgroup walks the image in row-major order (the order np.where returns) and compacts the masked pixels
 // with positive depth.  Arithmetic as the reference: float64 rays K^-1 [u, v, 1], xyz * z / xyz_z, then (after the
 // reference's double negation of x and y cancels) a cast to float32.
-__global__ __launch_bounds__(PREP_THREADS) void backproject_kernel(const float* __restrict__ depth,
+// REF64 (cppf_backproject64): float64 depth in, float64 points out WITH the reference's negated x and y -- utils/util.py:2586-2607
+// itself, bit for bit (every operation below is the one NumPy performs, in float64, in its order).
+template <typename TD, typename TO, bool REF64>
+__global__ __launch_bounds__(PREP_THREADS) void backproject_kernel(const TD* __restrict__ depth,
                                                                    const uint8_t* __restrict__ mask, int H, int W,
-                                                                   Mat3d kinv, int cap, float* __restrict__ pts,
+                                                                   Mat3d kinv, int cap, TO* __restrict__ pts,
                                                                    int32_t* __restrict__ rowcol,
                                                                    int32_t* __restrict__ count) {
   __shared__ int s_wave[PREP_THREADS / 64];
@@ -41,10 +44,10 @@ __global__ __launch_bounds__(PREP_THREADS) void backproject_kernel(const float* 
   for (int base = 0; base < n; base += PREP_THREADS) {
     const int i = base + threadIdx.x;
     bool keep = false;
-    float z = 0.0f;
+    TD z = 0;
     if (i < n) {
       z = depth[i];
-      keep = mask[i] != 0 && z > 0.0f;
+      keep = mask[i] != 0 && z > 0;
     }
     int tot;
     const int pos = written + prep_scan_flag(keep, s_wave, &tot);
@@ -55,9 +58,10 @@ __global__ __launch_bounds__(PREP_THREADS) void backproject_kernel(const float* 
       const double y = (kinv.m[3] * u + kinv.m[4] * v) + kinv.m[5];
       const double w = (kinv.m[6] * u + kinv.m[7] * v) + kinv.m[8];
       const double zd = (double)z;
-      pts[3 * pos + 0] = (float)(x * zd / w);
-      pts[3 * pos + 1] = (float)(y * zd / w);
-      pts[3 * pos + 2] = (float)(w * zd / w);
+      const double px = x * zd / w, py = y * zd / w;
+      pts[3 * pos + 0] = (TO)(REF64 ? -px : px);
+      pts[3 * pos + 1] = (TO)(REF64 ? -py : py);
+      pts[3 * pos + 2] = (TO)(w * zd / w);
       if (rowcol) { rowcol[2 * pos] = r; rowcol[2 * pos + 1] = c; }
     }
     written += tot;
@@ -71,8 +75,20 @@ extern "C" int cppf_backproject(const float* depth, const uint8_t* mask, int H, 
   CPPF_CHECK_ARG((int64_t)H * W < 0x7fffffffLL);
   Mat3d k;
   for (int i = 0; i < 9; ++i) k.m[i] = h_kinv[i];
-  hipLaunchKernelGGL(backproject_kernel, dim3(1), dim3(PREP_THREADS), 0, (hipStream_t)stream, depth, mask, H, W, k, cap,
-                     out_pts, out_rowcol, out_count);
+  hipLaunchKernelGGL((backproject_kernel<float, float, false>), dim3(1), dim3(PREP_THREADS), 0, (hipStream_t)stream, depth, mask, H, W,
+                     k, cap, out_pts, out_rowcol, out_count);
+  CPPF_LAUNCH_CHECK();
+  return CPPF_OK;
+}
+
+extern "C" int cppf_backproject64(const double* depth, const uint8_t* mask, int H, int W, const double* h_kinv, int cap,
+                                  double* out_pts, int32_t* out_rowcol, int32_t* out_count, void* stream) {
+  CPPF_CHECK_ARG(depth && mask && h_kinv && out_pts && out_count && H > 0 && W > 0 && cap > 0);
+  CPPF_CHECK_ARG((int64_t)H * W < 0x7fffffffLL);
+  Mat3d k;
+  for (int i = 0; i < 9; ++i) k.m[i] = h_kinv[i];
+  hipLaunchKernelGGL((backproject_kernel<double, double, true>), dim3(1), dim3(PREP_THREADS), 0, (hipStream_t)stream, depth, mask, H,
+                     W, k, cap, out_pts, out_rowcol, out_count);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
 }

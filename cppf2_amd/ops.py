@@ -741,6 +741,28 @@ def backproject(depth, intrinsics, instance_mask, return_device=False):
     return pts.cpu().numpy(), (rc[:, 0], rc[:, 1])
 
 
+def backproject_reference(depth, intrinsics, instance_mask):
+    """utils/util.py:2586-2607 as the reference returns it: (pts float64[n,3] with x and y negated, (rows, cols) int64) --
+    cppf_backproject64: float64 depth in, the reference's float64 operations in its order, bit-identical to NumPy's array."""
+    dev = _dev()
+    d = _t(depth, torch.float64, dev)
+    m = _t(np.asarray(instance_mask) != 0 if not isinstance(instance_mask, torch.Tensor) else instance_mask != 0,
+           torch.uint8, dev)
+    if d.dim() != 2 or d.shape != m.shape:
+        raise CppfError("backproject: depth and mask must be 2-D and of equal shape")
+    H, W = d.shape
+    kinv = (C.c_double * 9)(*np.linalg.inv(np.asarray(intrinsics, dtype=np.float64).reshape(3, 3)).reshape(9))
+    cap = H * W
+    pts = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+    rc = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_L.cppf_backproject64(_p(d), _p(m), H, W, kinv, cap, _p(pts), _p(rc), _p(cnt), _stream()),
+               "cppf_backproject64")
+    n = int(cnt.item())
+    rc = rc[:n].cpu().numpy().astype(np.int64)
+    return pts[:n].cpu().numpy(), (rc[:, 0], rc[:, 1])
+
+
 def downsample(pc, res, seed=0, return_device=False):
     """Indices of one uniformly random point per `res` voxel (utils/util.py:39-46), ascending.  The draw is
     Philox(seed, point index) instead of NumPy's global RandomState, so it is reproducible on any device."""

@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 8
+#define CPPF_ABI_VERSION 9
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -319,6 +319,11 @@ int cppf_ensemble_select(int B, const CppfSceneResult* rec0, const CppfSceneResu
  * out_rowcol int32[cap,2] (optional), out_count int32 (number of valid pixels; may exceed cap). */
 int cppf_backproject(const float* depth, const uint8_t* mask, int H, int W, const double* h_kinv, int cap,
                      float* out_pts, int32_t* out_rowcol, int32_t* out_count, void* stream);
+/* backproject() (utils/util.py:2586-2607) exactly as the reference returns it (ABI 9): depth float64[H,W], out_pts float64[cap,3]
+ * with x and y NEGATED (the reference's own convention; its callers negate them back, eval.py:187-188) -- the same float64
+ * operations in the same order, so the array is bit-identical to NumPy's.  What `utils.util.backproject` binds. */
+int cppf_backproject64(const double* depth, const uint8_t* mask, int H, int W, const double* h_kinv, int cap,
+                       double* out_pts, int32_t* out_rowcol, int32_t* out_count, void* stream);
 /* One uniformly random point per `res` voxel (anchored at the cloud's min corner): replaces downsample()
  * (utils/util.py:39-46, open3d voxel_down_sample_and_trace + np.random.choice).  The draw is Philox(seed, point
  * index), so the kept set does not depend on thread order; out_idx int32[n] holds the kept point indices in

@@ -30,13 +30,9 @@ def downsample(pc, res):
 
 def backproject(depth, intrinsics, instance_mask):
     """utils/util.py:2586-2607: (pts float64[n,3] with x and y negated, (rows, cols)) for the masked pixels with depth > 0, in
-    np.where's row-major order.  cppf_backproject computes K^-1 [u v 1]^T z in float64 and stores float32, so the values are the
-    reference's rounded to float32 -- what every caller keeps (eval.py:187-189: negate x, y back, `.astype(np.float32)`)."""
-    pts, (rows, cols) = _ops.backproject(depth, intrinsics, instance_mask)      # already in the callers' sign convention
-    pts = pts.astype(np.float64)
-    pts[:, 0] = -pts[:, 0]
-    pts[:, 1] = -pts[:, 1]
-    return pts, (rows, cols)
+    np.where's row-major order.  cppf_backproject64 on the GPU: the reference's float64 operations in the reference's order, so
+    the array is the reference's bit for bit (callers negate x, y back and cast to float32, eval.py:187-189)."""
+    return _ops.backproject_reference(depth, intrinsics, instance_mask)
 
 
 def real2prob(val, max_val, num_bins, circular=False):
