@@ -1,0 +1,60 @@
+"""Untimed accuracy evidence bench.py attaches to the headline line, measured on the bench's own tuples after the timed loops."""
+import torch
+
+from .workloads import Cfg
+
+
+def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
+    """Untimed evidence for the line's `dtype` and parity claims, measured on the bench's own tuples (rank 0, after timing):
+    * mlp_error_vs_f64: the tuple MLP's logits (tuple_encoder + logit_encoder, train_shot.py:56-66) of the first `rows_err`
+      tuples in split arithmetic (what the step runs) and on PyTorch's float32 library GEMMs, each against a float64 evaluation
+      of the same weights and rows; errors relative to the largest |logit|;
+    * bin_flip_rate_vs_expf: the bins the decode kernel draws (softmax_exp: hardware exp2, ~1.5 ulp) against the same draw
+      with torch.exp (libm-accurate expf) in the same float32 running-sum order, over `scenes_flip` scenes x T tuples x 6."""
+    import copy
+    from cppf2_amd import models as M
+    ops, pipe, a, dev = step.ops, step.pipe, step.args, step.dev
+    N, T = step.N, step.T
+    sc = min(scenes_flip, step.B)
+    ids = tuple(range(step.scene0, step.scene0 + sc))
+    idx = ops.sample_tuples(N, T, 5, a.seed, ids, dev)
+    pt_off, tup_off = ops._uniform_offsets(N, sc, dev), ops._uniform_offsets(T, sc, dev)
+    feat = step.model.encode_points(step.shot[:sc * N])
+    x = ops.encode_tuples_shot(step.pts[:sc * N], idx, feat, step.normal[:sc * N], pt_off, tup_off)
+    out = {}
+    if M.MLP_ARITH in ("split", "split16"):
+        arith0 = M.MLP_ARITH
+        xe = x[:rows_err].contiguous()
+        m64 = copy.deepcopy(step.model).double()
+        want = m64.logit_encoder(m64.tuple_encoder(xe.double()))
+        scale = want.abs().max().item()
+        M.MLP_ARITH = "split"
+        split = M.fused_stack(step.model.logit_encoder, M.fused_stack(step.model.tuple_encoder, xe.clone()))
+        M.MLP_ARITH = "split16"
+        split16 = M.fused_stack(step.model.logit_encoder, M.fused_stack(step.model.tuple_encoder, xe.clone()))
+        M.MLP_ARITH = arith0
+        native = step.model.logit_encoder(step.model.tuple_encoder(xe))              # plain nn.Linear: library f32 GEMMs
+
+        def err(t):
+            d = t.double() - want
+            return {"max": d.abs().max().item() / scale, "rms": d.pow(2).mean().sqrt().item() / scale}
+        out["mlp_error_vs_f64"] = {"rows": int(xe.shape[0]), "logit_scale": scale, "split_bf16x3": err(split),
+                                   "split_f16x2": err(split16), "library_f32_gemm": err(native),
+                                   "note": "relative to max |logit|; the timed step runs " + ("split_bf16x3" if arith0 == "split" else "split_f16x2")}
+    logits = step.model.heads(x, lazy_scale=True)[0].contiguous()                  # [sc*T, 6, 32]
+    u = ops.philox_uniform(T, 6, a.seed, 1, ids, dev)
+    prior = step.prior[:sc * T]
+    got = ops.decode_bins(logits, u, step.pts[:sc * N], idx, Cfg.up, Cfg.front, Cfg.right, pt_off, tup_off, prior=prior)["bins"]
+    e = logits + prior
+    p = torch.exp(e - e.max(-1, keepdim=True).values)
+    cdf = torch.empty_like(p)
+    run = torch.zeros_like(p[..., 0])
+    for j in range(p.shape[-1]):                                                   # the kernel's float32 running sum, in bin order
+        run = run + p[..., j]
+        cdf[..., j] = run
+    target = u.reshape(-1, 6) * run
+    ref = (cdf <= target[..., None]).sum(-1).clamp(max=p.shape[-1] - 1).to(torch.int32)
+    flips = int((ref != got).sum().item())
+    out["bin_flip_rate_vs_expf"] = {"draws": int(ref.numel()), "flips": flips, "rate": flips / ref.numel(),
+                                    "max_bin_distance": int((ref - got).abs().max().item())}
+    return out

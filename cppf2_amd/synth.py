@@ -104,6 +104,27 @@ def make_scene(seed, scene_id, n_points=4096, max_tilt_deg=25.0):
     return dict(pc=pc, pc_canon=pc_canon, R=R, t=t, diag=DIAG, extent=np.array([2 * RADIUS, HEIGHT, 2 * RADIUS]))
 
 
+VOXEL_RADIUS = 0.03
+VOXEL_HEIGHT = 0.10
+
+
+def make_scene_voxel2mm(seed, scene_id, n_points=4096, res=2e-3, max_tilt_deg=25.0):
+    """A scene at the point density the reference's pre-processing gives real inputs: eval.py:185-201 keeps one depth pixel per 2 mm
+    voxel, so neighbouring points are ~`res` apart and the 10 x res SHOT / normal support (eval.py:210) holds ~250 of them, not the
+    ~90 of make_scene()'s uniform surface samples.  The side of a cylinder (radius 0.03 m, height 0.10 m: ~4 700 surface cells of
+    res x res for the default 4096 points) under the scene's pose, every point snapped to the `res` lattice of the camera frame and
+    jittered by +-0.1 res (a voxel keeps one of its real points, not its centre).  Same keys as make_scene()."""
+    u = uniforms(seed, scene_id, 3, n_points, 8)
+    ang = 2 * np.pi * u[:, 0]
+    obj = np.stack([VOXEL_RADIUS * np.cos(ang), (u[:, 1] - 0.5) * VOXEL_HEIGHT, VOXEL_RADIUS * np.sin(ang)], -1)
+    R, t = scene_pose(seed, scene_id, max_tilt_deg)
+    world = obj @ R.T + t
+    pc = (np.round(world / res) * res + (u[:, 2:5] - 0.5) * (0.2 * res)).astype(np.float32)
+    diag = float(np.sqrt((2 * VOXEL_RADIUS) ** 2 * 2 + VOXEL_HEIGHT ** 2))
+    pc_canon = ((pc.astype(np.float64) - t) @ R / diag).astype(np.float32)
+    return dict(pc=pc, pc_canon=pc_canon, R=R, t=t, diag=diag, extent=np.array([2 * VOXEL_RADIUS, VOXEL_HEIGHT, 2 * VOXEL_RADIUS]))
+
+
 def teacher_logits(pc_canon, idx, num_bins=32, sigma_bins=0.6, noise=None):
     """Logit prior peaked at the true canonical coordinates of each tuple's first two points
     (layout [T, 6, num_bins] = 2 points x xyz, eval.py:225; bin value = k/(B-1) - 0.5, eval.py:230)."""

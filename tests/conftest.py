@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-BENCH2 = {}      # handles of the bench jobs started in pytest_configure (GPU runs only)
+BENCH2 = {}      # the bench jobs of a GPU run: {"dir", "proc", "gpus"} (tests/_bench_jobs.py runs them one after another)
 
 
 def _free_port():
@@ -23,66 +23,78 @@ def _free_port():
     return p
 
 
-_LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CPPF_BENCH_BACKEND",
-               "CPPF_DIST_FORCE_COLLECTIVE")
-
-
-# a job with delay > 0 is started by this stub (which never touches the GPU): it sleeps, runs bench.py as its child and exits with
-# the child's code -- the counter passes of the "counters" job then measure before the multi-rank jobs load the GPU
-_DELAYED = ("import subprocess, sys, time\n"
-            "time.sleep(float(sys.argv[1]))\n"
-            "sys.exit(subprocess.call([sys.executable] + sys.argv[2:]))\n")
-
-
-def _start_bench(tmpdir, tag, argv, scenes=4, counters=False, delay=0.0, **env_add):
-    import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV}
-    env.update(env_add)
-    out = open(os.path.join(tmpdir, tag + ".out"), "w")
-    err = open(os.path.join(tmpdir, tag + ".err"), "w")
-    small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
-             "--no-native-arith"] + ([] if counters else ["--no-counters"])
-    cmd = [os.path.join(ROOT, "bench.py")] + argv + small
-    cmd = [sys.executable] + cmd if delay <= 0 else [sys.executable, "-c", _DELAYED, str(delay)] + cmd
-    return (subprocess.Popen(cmd, env=env, stdout=out, stderr=err, cwd=ROOT), out.name, err.name)
-
-
-def _start_bench_jobs(tmpdir):
-    """FRESH child processes, started here, before this process initialises the GPU -- a process that has done so must not
-    fork+exec on this pool -- and collected by tests/test_multi_rank_gpu.py:
-    * two_ranks: plain `python bench.py --gpus 2` (no launcher environment): bench.py starts its two ranks itself; they share
-      GPU 0, so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks);
-    * rccl_one_rank: `bench.py --gpus 1` with CPPF_DIST_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...) and
-      the path's all_gather (plus the bench's barrier and all_reduce) really run through RCCL, in a one-rank group;
+def _bench_jobs():
+    """The bench.py runs tests/test_multi_rank_gpu.py reads, in the order they run (each alone on the GPU):
+    * counters: the counter passes of a default run -- bench.py starts rocprofv3 children of itself before it touches the GPU;
+    * one_rank_16 / eight_ranks: the 8-rank launch path without 8 GPUs -- `bench.py --gpus 8 --scenes-per-gpu 2` starts eight fresh
+      ranks that share GPU 0 over gloo (port allocation, LOCAL_RANK % visible GPUs, per-rank core slices and TunableOp directories);
+      its 16 gathered records must equal, in global scene order, those of one rank holding all 16 scenes;
+    * rccl_one_rank: `bench.py --gpus 1` with CPPF_DIST_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...) and the path's
+      all_gather (plus the bench's barrier and all_reduce) really run through RCCL, in a one-rank group;
     * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly;
-    * eight_ranks / one_rank_16: the 8-rank launch path without 8 GPUs -- `bench.py --gpus 8 --scenes-per-gpu 2` starts eight
-      fresh ranks that share GPU 0 over gloo (port allocation, LOCAL_RANK % visible GPUs, per-rank core slices and TunableOp
-      directories); its 16 gathered records must equal, in global scene order, those of one rank holding all 16 scenes."""
-    return {
-        # the counter passes of a default run: bench.py starts rocprofv3 children of itself before it touches the GPU
-        "counters": _start_bench(tmpdir, "counters", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], counters=True),
-        "eight_ranks": _start_bench(tmpdir, "eight_ranks", ["--gpus", "8", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=2,
-                                    delay=25.0, CPPF_BENCH_BACKEND="gloo"),
-        "one_rank_16": _start_bench(tmpdir, "one_rank_16", ["--gpus", "1", "--no-f16x2", "--no-evidence", "--single-stream"], scenes=16),
-        "two_ranks": _start_bench(tmpdir, "two_ranks", ["--gpus", "2"], delay=15.0, CPPF_BENCH_BACKEND="gloo"),
-        "rccl_one_rank": _start_bench(tmpdir, "rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1",
-                                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
-        "refuse_two_gpus": _start_bench(tmpdir, "refuse_two_gpus", ["--gpus", "2"]),
-    }
+    * two_ranks: plain `python bench.py --gpus 2` (no launcher environment): bench.py starts its two ranks itself; they share GPU 0,
+      so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks)."""
+    def job(tag, argv, scenes=4, counters=False, **env):
+        small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
+                 "--no-native-arith", "--no-voxel-density"] + ([] if counters else ["--no-counters"])
+        return {"tag": tag, "argv": argv + small, "env": env}
+    one = ["--no-f16x2", "--no-evidence", "--single-stream"]
+    return [job("counters", ["--gpus", "1"] + one, counters=True),
+            job("one_rank_16", ["--gpus", "1"] + one, scenes=16),
+            job("eight_ranks", ["--gpus", "8"] + one, scenes=2, CPPF_BENCH_BACKEND="gloo"),
+            job("rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+            job("refuse_two_gpus", ["--gpus", "2"]),
+            job("two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo")]
+
+
+def _wants_bench_jobs(config):
+    """A GPU run that may reach tests/test_multi_rank_gpu.py (no file arguments, the tests directory, or that file)."""
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return False
+    files = [os.path.basename(a.split("::")[0]) for a in config.args]
+    named = [f for f in files if f.startswith("test_") and f.endswith(".py")]
+    return not named or "test_multi_rank_gpu.py" in named
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    expr = config.getoption("markexpr", "") or ""
-    if "gpu" in expr and "not gpu" not in expr:
-        try:
-            import tempfile
-            import torch
-            if torch.cuda.device_count() > 0:            # counting devices does not initialise the GPU
-                BENCH2["jobs"] = _start_bench_jobs(tempfile.mkdtemp(prefix="cppf_bench2_"))
-                BENCH2["gpus"] = torch.cuda.device_count()
-        except Exception as e:                            # pragma: no cover
-            BENCH2["error"] = repr(e)
+    if not _wants_bench_jobs(config):
+        return
+    try:
+        import json
+        import subprocess
+        import tempfile
+        import torch
+        if torch.cuda.device_count() > 0:            # counting devices does not initialise the GPU
+            d = tempfile.mkdtemp(prefix="cppf_bench2_")
+            with open(os.path.join(d, "jobs.json"), "w") as f:
+                json.dump(_bench_jobs(), f)
+            # ONE fresh child, started before this process initialises the GPU; it runs the jobs sequentially
+            BENCH2["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_bench_jobs.py"), d], cwd=ROOT)
+            BENCH2["dir"] = d
+            BENCH2["gpus"] = torch.cuda.device_count()
+    except Exception as e:                            # pragma: no cover
+        BENCH2["error"] = repr(e)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def bench_jobs_finished():
+    """The bench jobs run to completion BEFORE the first test: they never share the GPU with a test (waiting is not fork + exec)."""
+    proc = BENCH2.get("proc")
+    if proc is not None:
+        BENCH2["runner_rc"] = proc.wait(timeout=1800)
+    yield
+
+
+def bench_job(name):
+    """(exit code, stdout, stderr) of one finished bench job, or a skip when the jobs were not started."""
+    if "dir" not in BENCH2:
+        pytest.skip("bench jobs were not started (%s)" % BENCH2.get("error", "not a full -m gpu run"))
+    d = BENCH2["dir"]
+    assert os.path.exists(os.path.join(d, "done")), "the bench job runner did not finish (rc %r)" % BENCH2.get("runner_rc")
+    rc = int(open(os.path.join(d, name + ".rc")).read().split()[0])
+    return rc, open(os.path.join(d, name + ".out")).read(), open(os.path.join(d, name + ".err")).read()
 
 
 @pytest.fixture(scope="session")

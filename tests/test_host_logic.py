@@ -235,3 +235,43 @@ def test_run_dir_layout_and_saved_config(tmp_path):
     back = load_checkpoint_config(path)
     assert back == cfg2 and list(back.right) == [0, 0, 1] and back.res == 2e-3        # mug votes its second axis about z
     assert checkpoint_dir("a/b").replace(os.sep, "/") == "a/b/lightning_logs/version_0/checkpoints"
+
+
+def test_core_slice_partitions_any_allowed_core_set():
+    """bench.py pins rank r of W to the r-th run of the process' allowed cores (cppf2_amd/benchlib/launch.py:core_slice): every
+    allowed core goes to exactly one rank, sizes differ by at most one, whatever sched_getaffinity returns -- a non-contiguous
+    cpuset, SMT siblings removed, fewer cores than ranks."""
+    from cppf2_amd.benchlib.launch import core_slice
+    for cores in (range(256), range(8), [3, 5, 6, 7, 40, 41, 42, 43, 44, 100, 101], set(range(0, 128, 2)), [7, 2, 9]):
+        cores = list(cores)
+        for W in (1, 2, 3, 8):
+            parts = [core_slice(cores, r, W) for r in range(W)]
+            if len(set(cores)) >= W:
+                assert sorted(c for p in parts for c in p) == sorted(set(cores))            # a partition
+                sizes = [len(p) for p in parts]
+                assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+                assert all(p == sorted(p) for p in parts)
+                assert all(a[-1] < b[0] for a, b in zip(parts[:-1], parts[1:]))             # runs of the sorted ids, in rank order
+            else:                                                                           # fewer cores than ranks: shared, never empty
+                assert all(len(p) == 1 and p[0] in cores for p in parts)
+                assert {p[0] for p in parts} == set(cores)
+    assert core_slice([], 0, 8) == [] and core_slice(range(8), 8, 8) == [] and core_slice(range(8), -1, 8) == []
+    # the usual 8-GPU host: 2 sockets x 64 cores, socket-major ids -> ranks 0-3 on socket 0, 4-7 on socket 1
+    assert core_slice(range(128), 3, 8) == list(range(48, 64)) and core_slice(range(128), 4, 8) == list(range(64, 80))
+
+
+def test_pin_rank_to_cores_reports_what_it_set(monkeypatch):
+    import os
+    from cppf2_amd.benchlib import launch
+    allowed = {1, 2, 3, 10, 11, 12, 13}
+    seen = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(allowed))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: seen.update(cores=list(cores)))
+    monkeypatch.delenv("CPPF_BENCH_NO_AFFINITY", raising=False)
+    got = launch.pin_rank_to_cores(1, 2)
+    assert seen["cores"] == [10, 11, 12, 13] and got == {"cores": 4, "first": 10, "last": 13, "contiguous": True}
+    got = launch.pin_rank_to_cores(0, 2)
+    assert seen["cores"] == [1, 2, 3] and got["contiguous"]
+    assert launch.pin_rank_to_cores(0, 1) is None                                           # one rank: affinity left alone
+    monkeypatch.setenv("CPPF_BENCH_NO_AFFINITY", "1")
+    assert launch.pin_rank_to_cores(1, 2) is None

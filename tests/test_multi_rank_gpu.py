@@ -30,7 +30,7 @@ def _args(scenes_per_gpu, points=2048, tuples=8000, rots=90):
 
 
 def test_records_do_not_depend_on_the_world_size():
-    import bench
+    from cppf2_amd.benchlib import workloads as bench
     dev = torch.device("cuda")
     whole = bench.Step(_args(8), 0, 1, dev)
     whole.run()
@@ -65,28 +65,32 @@ def test_two_streams_give_the_single_stream_records():
     records of both must be byte-identical to a sequential run -- the library keeps no global device state, every entry point
     takes its stream, the SHOT scratch buffer is per (device, stream).  (Regression guard for DESIGN.md section 11: the
     rotation-vote kernel once produced different votes when it shared a CU with the MLP workgroups of the other stream.)"""
-    import bench
+    from cppf2_amd.benchlib import workloads as bench
     dev = torch.device("cuda")
     a = _args(16, points=4096, tuples=20000, rots=180)
-    steps = [bench.Step(a, 0, 1, dev) for _ in range(2)]
-    steps[0].run()
-    torch.cuda.synchronize()
-    want = steps[0].pipe.results.clone()
+    # the two pipelines hold DIFFERENT scene batches (like bench.py's headline loop since round 5): an aliased buffer would show
+    steps = [bench.Step(a, 0, 1, dev), bench.Step(a, 0, 1, dev, scene_shift=16)]
+    want = []
+    for s in steps:
+        s.run()
+        torch.cuda.synchronize()
+        want.append(s.pipe.results.clone())
+    assert not torch.equal(want[0], want[1]) and steps[1].scene0 == 16
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for trial in range(3):
         for i in range(6):
             with torch.cuda.stream(streams[i & 1]):
                 steps[i & 1].run()
         torch.cuda.synchronize()
-        for s in steps:
-            assert torch.equal(s.pipe.results, want), trial
+        for s, w in zip(steps, want):
+            assert torch.equal(s.pipe.results, w), trial
 
 
 def test_rotation_vote_beside_the_wide_mlp_kernels_of_another_stream():
     """The kernel-level form of the guard above (scratch/rot_race_probe3.py): both rotation votes launched while a second stream
     runs a 256-wide / a 256 -> 192 MLP kernel (one 448- / 416-register wavefront per SIMD) give the counts of the solo launch.
     Before the packed-float32 erratum forms were built out (profiles/r3_pk_op_sel_erratum.md) 10 launches of 10 differed."""
-    import bench
+    from cppf2_amd.benchlib import workloads as bench
     from cppf2_amd import models, ops
     dev = torch.device("cuda")
     st = bench.Step(_args(64, points=4096, tuples=20000, rots=180), 0, 1, dev)
@@ -116,12 +120,8 @@ def test_rotation_vote_beside_the_wide_mlp_kernels_of_another_stream():
 
 
 def _job(name):
-    from conftest import BENCH2
-    if "jobs" not in BENCH2:
-        pytest.skip("bench jobs were not started (%s)" % BENCH2.get("error", "not a -m gpu run"))
-    proc, out, err = BENCH2["jobs"][name]
-    rc = proc.wait(timeout=900)
-    return rc, open(out).read(), open(err).read()
+    from conftest import bench_job
+    return bench_job(name)
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -147,14 +147,29 @@ def test_bench_measures_its_counters_in_the_run():
     assert rc == 0, err[-3000:]
     j = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
     r = j["roofline"]
-    # (this job shares the GPU with the other bench jobs and with the test process: the counters are per dispatch, but fractions of
-    # busy cycles dip while other processes' kernels hold the chip -- the bounds below are what holds under that load)
+    # (the job ran alone on the GPU: tests/conftest.py runs the bench jobs one after another before the first test)
+    assert j["ok"], j["problems"]
+    assert j["counter_children_started"] == 3
     assert r["traffic"] is not None and r["traffic"] > 0, (r.get("hbm", {}).get("traffic_source"), err[-1500:])
     assert "counter passes of this run" in r["hbm"]["traffic_source"]
+    # what `frac` means: algorithmic float32 flops over the bf16 pipe's peak; the executed fraction and the reading
+    # against the f32-input matrix instruction beside it, as scalars of `roofline`
+    assert r["bound"] == "mfma" and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] < r["frac_executed"] <= 1.0
+    assert r["frac_executed"] == pytest.approx(6.0 * r["frac"], rel=0.05)          # 6 products per float32 product (+ K padding)
+    assert r["frac_vs_f32_mfma_peak"] == pytest.approx(r["frac"] * 2500.0 / 157.0, rel=1e-6)
+    # EVERY per-kernel fraction is a fraction
+    fr = {k: e["frac"] for k, e in r["per_kernel"].items()}
+    assert all(f is None or 0.0 < f <= 1.0 for f in fr.values()), fr
+    assert sum(f is not None for f in fr.values()) >= 8, fr
+    for k in ("shot_frames", "shot352", "vote_center", "rot_bins"):
+        e = r["per_kernel"][k]
+        assert e["bound"] in ("valu", "lds") and e["frac"] is not None and e["activity"]["invalid"] is None, (k, e)
+        assert e["activity"]["valu_issue"] <= e["activity"]["valu_busy"] * 1.001 + 1e-3, e      # issue rate: a lower bound of busy
     vc = r["per_kernel"]["vote_center"]
-    assert vc["bound"] in ("valu", "lds") and 0.0 < vc["frac"] <= 1.0 and vc["work"]["votes_per_s"] > 0, vc
-    assert vc["activity"]["valu_busy"] > 0 and vc["pmc_MB"] is not None, vc
-    assert r["per_kernel"]["encode_tuples"]["bound"] == "hbm" and r["per_kernel"]["assemble_pose"]["bound"] == "latency"
+    assert vc["work"]["votes_per_s"] > 0 and vc["pmc_MB"] is not None, vc
+    enc = r["per_kernel"]["encode_tuples"]
+    assert enc["bound"] == "hbm" and "rocprofv3 dispatch timestamps" in enc["frac_kind"] and 0 < enc["kernel_ms"] <= enc["event_ms"] * 1.5
+    assert r["per_kernel"]["assemble_pose"]["bound"] == "latency"
     busy = [v.get("mfma_busy") for v in r["mfma_busy_per_launch"].values()]
     assert all(b is not None and 0.0 < b <= 1.0 for b in busy), r["mfma_busy_per_launch"]
 
@@ -172,9 +187,16 @@ def test_bench_eight_ranks_dry_run_equals_one_rank():
     assert j1["n_gpus"] == 1 and j1["records_gathered"] == 16
     assert j8["records_sha256"] == j1["records_sha256"]
     assert j8["pose_5deg5cm_vs_gt"] == 1.0 and j8["ok"] and j1["ok"]
-    # rank 0 of eight was pinned to its slice of the host cores (an eighth of them; None only if the box exposes < 8 cores)
+    # the line of a multi-rank run diagnoses itself: backend, world, op, per-rank step times, the records' hash
+    c8 = j8["collective"]
+    assert c8["backend"] == "gloo" and c8["op"] == "all_gather" and c8["records_sha256"] == j8["records_sha256"]
+    assert 0 < c8["ms_per_step_per_rank"]["min"] <= c8["ms_per_step_per_rank"]["max"] == pytest.approx(j8["ms_per_step"], rel=1e-6)
+    # no rank of a multi-rank run starts profiler children (bench.py guards on world == 1), and says so
+    assert j8["counter_children_started"] == 0 and j8["roofline"]["traffic"] is None
+    assert "one rank only" in j8["roofline"]["hbm"]["traffic_source"]
+    # rank 0 of eight was pinned to its run of the host cores (an eighth of them)
     cores = j8["host_cores_of_rank0"]
-    assert cores is None or cores[0] == min(cores)
+    assert cores is None or (cores["cores"] >= 1 and cores["first"] <= cores["last"])
 
 
 def test_bench_gathers_through_rccl_in_a_one_rank_group():
