@@ -41,7 +41,8 @@ def _bench_jobs():
     one = ["--no-f16x2", "--no-evidence", "--single-stream"]
     return [job("counters", ["--gpus", "1"] + one, counters=True),
             job("one_rank_16", ["--gpus", "1"] + one, scenes=16),
-            job("eight_ranks", ["--gpus", "8"] + one, scenes=2, CPPF_BENCH_BACKEND="gloo"),
+            # (no --no-counters here: the ranks of a multi-rank run must decline the counter passes by themselves)
+            job("eight_ranks", ["--gpus", "8"] + one, scenes=2, counters=True, CPPF_BENCH_BACKEND="gloo"),
             job("rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
             job("refuse_two_gpus", ["--gpus", "2"]),
             job("two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo")]
