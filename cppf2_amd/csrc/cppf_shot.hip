@@ -600,6 +600,10 @@ __global__ __launch_bounds__(64, 8) void shot_cov_kernel(int B, const float* __r
       ed[e] = (c < m && d2 < rn2) ? d2 : INFINITY;
       if (c < m) cov_accumulate<false>(qv, px, py, pz, rn2, rs2, rs, a);
     }
+  } else if (PCL && rn > 0.0f && m <= COV_LIST) {
+    // (m <= COV_LIST < NBR_CAP: shot_pcl_long_kernel redoes this query's normal sums in PCL's arithmetic -- the float64 ones about
+    // the query point would be overwritten: only the LRF columns are summed here; the count is marked below as before)
+    for (int c = lane; c < m; c += 64) cov_accumulate<false>(s_nb[c], px, py, pz, rn2, rs2, rs, a);
   } else if (m <= COV_LIST) {
     for (int c = lane; c < m; c += 64) cov_accumulate(s_nb[c], px, py, pz, rn2, rs2, rs, a);
   } else {
