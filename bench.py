@@ -255,6 +255,7 @@ def main():
         wl += ["--mlp-arith", args.mlp_arith] if args.mlp_arith else []
         wl += ["--eager-scale-head"] if args.eager_scale_head else []
         wl += ["--materialize-tuples"] if args.materialize_tuples else []
+        wl += ["--separate-encode"] if args.separate_encode else []
         COUNTERS.clear()
         COUNTERS.update(counters.collect_counters(wl))
         counter_children = len(counters.COUNTER_PASSES)
@@ -293,6 +294,7 @@ def main():
         report.GATHERED_TUPLES = step.gather
         if report.GATHERED_TUPLES:
             counters.STAGE_KERNEL["encode_tuples"] = "encode_shot_heads_tile_kernel"
+            report.ENCODE_FOLDED = (not args.separate_encode) and _models.MLP_ARITH == "split"
             from cppf2_amd.models import decode_supported
             report.FUSED_DRAW = decode_supported(step.model.logit_encoder, torch.empty((1, 256), device=dev))
             if report.FUSED_DRAW:

@@ -211,18 +211,20 @@ def kernel_us(name, pass_name="FETCH_SIZE"):
     return a.get(pass_name) or a.get("WRITE_SIZE") or a.get("SQ")
 
 
-TUPLE_MLP_KERNELS = ("reslayer_split_kernel<4, true, true, false, 3, 0>#large", "reslayer_split_kernel<8, true, false, false, 3, 0>",
-                     "reslayer_split_kernel<6, true, false, true, 3, 0>")
+def tuple_mlp_kernels(pieces=3, folded=True):
+    """Counter keys of the tuple MLP's three launches: the gathered 360 -> 128 chain (MODE 3 = RS_ENCODE since round 5 -- the pair
+    features are built in the kernel; with --separate-encode or f16x2 arithmetic MODE 0, whose key is shared with the ~20 x shorter
+    scale-head launch on the kept pairs: `#large`), 128 -> 256 with the two 256-wide identity layers behind it, 256 -> 192 + bin draw."""
+    first = ("reslayer_split_kernel<4, true, true, false, 3, 3>" if (folded and pieces == 3)
+             else "reslayer_split_kernel<4, true, true, false, %d, 0>#large" % pieces)
+    return (first, "reslayer_split_kernel<8, true, false, false, %d, 0>" % pieces, "reslayer_split_kernel<6, true, false, true, %d, 0>" % pieces)
 
 
-def pmc_traffic_mlp(pieces=3):
-    """HBM bytes per step of the tuple MLP's three cppf_reslayer_split launches (the gathered 360 -> 128 chain; 128 -> 256 with
-    the two 256-wide identity layers behind it; 256 -> 192 + bin draw: the launches `launch_ms` times), from this run's counter
-    passes; the gathering kernel also runs the scale head's first layer on the kept pairs, a ~20 x shorter launch kept under
-    its own key.  None when the passes did not run."""
+def pmc_traffic_mlp(pieces=3, folded=True):
+    """HBM bytes per step of the tuple MLP's three launches (tuple_mlp_kernels: the launches `launch_ms` times), from this run's
+    counter passes.  None when the passes did not run."""
     tot = 0.0
-    for k_ in TUPLE_MLP_KERNELS:
-        k_ = k_.replace(", 3, 0>", ", %d, 0>" % pieces)
+    for k_ in tuple_mlp_kernels(pieces, folded):
         b_ = hbm_bytes(COUNTERS.get(k_) or COUNTERS.get(k_.replace("#large", "")))
         if b_ is None:
             return None

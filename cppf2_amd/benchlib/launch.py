@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--materialize-tuples", action="store_true",
                     help="write the [T, 360] tuple rows (cppf_encode_tuples_shot) and let the MLP read them back, instead of "
                          "gathering them inside the first ResLayer's kernel (cppf_reslayer_split_gather)")
+    ap.add_argument("--separate-encode", action="store_true",
+                    help="write the 40 pair features + global indices per tuple with their own kernel (cppf_encode_tuples_shot_heads, "
+                         "rounds 3-4) instead of building them inside the first ResLayer's kernel (cppf_reslayer_split_encode)")
     ap.add_argument("--no-native-arith", action="store_true",
                     help="skip the extra timed loop with the MLP on the f32-input matrix cores (value_f32_input_mfma)")
     ap.add_argument("--two-streams", action="store_true", help="(the default since round 4; kept for old command lines)")

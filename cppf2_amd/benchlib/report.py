@@ -23,10 +23,13 @@ F32_MFMA_PEAK_TFLOPS = 157.0    # f32-input MFMA: 256 CUs x 4 SIMDs x 64 flops/c
 
 GATHERED_TUPLES = False         # set by main(): the encode stage writes pair features + indices only
 FUSED_DRAW = False              # set by main(): the bins are drawn inside the MLP's output layer, the decode stage starts from them
+ENCODE_FOLDED = False           # set by main(): the pair features are built inside the tuple MLP's first launch (no encode kernel)
 
 
 def algorithmic_bytes(stage, B, N, T, R, S, G):
     """Compulsory bytes one launch of the stage's kernel moves for B scenes (SURVEY.md 8d per-scene figures)."""
+    if stage == "encode_tuples" and ENCODE_FOLDED:
+        return (T * 5 * 4 + N * 12 + N * 12) * B          # indices, points, normals in -- read by the MLP's first launch; nothing out
     if stage == "encode_tuples" and GATHERED_TUPLES:
         return (T * 5 * 4 + N * 12 + N * 12 + T * 40 * 4 + T * 5 * 4) * B
     if stage == "decode_bins" and FUSED_DRAW:
@@ -253,7 +256,11 @@ def per_kernel_table(stage_ms, B, N, T, R, S, G, stages):
         e = dict(kernel=STAGE_KERNEL.get(s), ms=round(ms, 4), alg_MB=round(ab / 1e6, 2),
                  pmc_MB=None if tr is None else round(tr / 1e6, 2), activity=act)
         kind = STAGE_BOUND.get(s, "latency")
-        if kind == "hbm":
+        if s == "encode_tuples" and ENCODE_FOLDED:
+            e.update(bound="fused", frac=None, kernel=None,
+                     frac_kind="no kernel: the pair features are built by the tuple MLP's first launch (cppf_reslayer_split_encode) "
+                               "from the sampler's indices; the stage's event gap is host time between two launches")
+        elif kind == "hbm":
             kus = kernel_us(STAGE_KERNEL.get(s, ""))
             kms = kus / 1e3 if kus else ms
             kgbs = (ab / 1e9) / (kms / 1e3) if kms > 0 and ab else 0.0
@@ -317,7 +324,7 @@ def report_shot(run):
     hip_stages = [s for s in Step.STAGES if s not in mlp_stages and s != "gather"]
     # the HBM roofline object describes the longest of the kernels that ARE bandwidth-bound (section 4 of DESIGN.md); the
     # voting and descriptor kernels (VALU / LDS bound) have their fractions in per_kernel
-    hbm_bound = ("decode_bins", "encode_tuples", "sample_tuples")
+    hbm_bound = ("decode_bins", "sample_tuples") if ENCODE_FOLDED else ("decode_bins", "encode_tuples", "sample_tuples")
     dominant = max(hbm_bound, key=lambda s: stage_ms.get(s, 0.0))
     rows, per_kernel = per_kernel_table(stage_ms, B, N, T, R, S, G, hip_stages)
     dk = per_kernel[dominant]
@@ -333,10 +340,11 @@ def report_shot(run):
                     frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dominant), launch_ms=dom_ms, launch_ms_kind=dk["frac_kind"],
                     kernel_name=STAGE_KERNEL.get(dominant), algorithmic_bytes_per_launch=dom_bytes,
                     algorithmic_model=("compulsory bytes of the stage as it runs here x %d scenes per launch (benchlib/report.py:"
-                                       "algorithmic_bytes): SURVEY.md 8d's per-scene figures, except the tuple encode in its "
-                                       "gathered form (indices + points + normals in, 40 pair features + 5 global indices per "
-                                       "tuple out: 4.1 MB per scene instead of 8d's 30.35 MB of rows) and the decode behind "
-                                       "the fused bin draw (bins in, vote parameters out)" % B),
+                                       "algorithmic_bytes): SURVEY.md 8d's per-scene figures, except the tuple encode -- folded into "
+                                       "the tuple MLP's first launch (indices + points + normals in, nothing out) or, with "
+                                       "--separate-encode, in its gathered form (40 pair features + 5 global indices per tuple out: "
+                                       "4.1 MB per scene instead of 8d's 30.35 MB of rows) -- and the decode behind the fused bin "
+                                       "draw (bins in, vote parameters out)" % B),
                     traffic_source=counters_src,
                     # the whole path's algorithmic bytes (HIP stages; ~54 MB/scene) over the whole step
                     # (MLP included) and over the HIP stages alone, as fractions of the HBM peak
@@ -364,11 +372,10 @@ def report_shot(run):
         hbm = {k_: roofline[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launch_ms_kind",
                                            "kernel_name", "algorithmic_bytes_per_launch", "algorithmic_model", "traffic_source")}
         busy = {}
-        for k_ in C.TUPLE_MLP_KERNELS:
-            kk = k_.replace(", 3, 0>", ", %d, 0>" % pcs)
-            busy[k_] = unit_activity(COUNTERS.get(kk) or COUNTERS.get(kk.replace("#large", ""))) or {}
+        for k_ in C.tuple_mlp_kernels(pcs, ENCODE_FOLDED):
+            busy[k_] = unit_activity(COUNTERS.get(k_) or COUNTERS.get(k_.replace("#large", ""))) or {}
         roofline.update(mfma_roofline(
-            executed, algorithmic, stage_ms["tuple_mlp"], nprod, C.pmc_traffic_mlp(pcs), 3,
+            executed, algorithmic, stage_ms["tuple_mlp"], nprod, C.pmc_traffic_mlp(pcs, ENCODE_FOLDED), 3,
             traffic_covers="the same 3 launches as launch_ms (counter passes of this run: 2 x FETCH_SIZE + WRITE_SIZE)",
             traffic_source=counters_src, mfma_busy_per_launch=busy,
             executed_flops_per_step=executed, algorithmic_f32_flops_per_step=algorithmic,
@@ -402,7 +409,9 @@ def report_shot(run):
                                   ("float32 operands as fp16 pairs (22-23 significant bits), 3 products on the fp16 matrix "
                                    "cores, float32 accumulate (error vs float64 at the library float32 GEMMs' level; NOT exact "
                                    "products)" if _models.MLP_ARITH == "split16" else "f32-input matrix cores"),
-                                  ("gathered inside the first ResLayer's kernel (never written)" if GATHERED_TUPLES
+                                  (("built and gathered inside the first ResLayer's kernel (pair features and descriptors: no per-tuple "
+                                    "array between sampler and MLP)" if ENCODE_FOLDED else
+                                    "gathered inside the first ResLayer's kernel (never written)") if GATHERED_TUPLES
                                    else "materialised ([T, 360] float32)")
                                   + ("; bins drawn in the epilogue of the logit head's output layer (logits never written)"
                                      if FUSED_DRAW else "")),

@@ -113,7 +113,12 @@ class Step:
         drawn = False
         if self.gather:
             # train_shot.py:75-83 without its 1.8 GB of rows: pair features + global indices, the first ResLayer gathers
-            heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+            # round 5: the 40 pair features too are built by the first ResLayer's kernel (cppf_reslayer_split_encode): no launch, no
+            # per-tuple array between the sampler and the tuple encoder (--separate-encode: the two-kernel form of rounds 3-4)
+            if getattr(a, "separate_encode", False):
+                heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+            else:
+                heads, gidx = ops.TupleSource(self.pts, idx, normal, pipe.pt_off, pipe.tup_off), None
             self._mark("encode_tuples")
             # tuple encoder + logit head: [gathered 360 -> 128 + 4 x 128] [128 -> 256 (tapped: the tuple features) + 2 x 256]
             # [256 -> 192 + bin draw]; eval.py:225-229 is the epilogue of the last kernel, the logits are never written
@@ -235,7 +240,7 @@ class EnsembleStep(Step):
             feat = self.model.encode_points(shot)
             pipe_b.use_slot(1)
             u2 = ops.philox_uniform(T, 6, a.seed, 2, ids, self.dev)
-            heads2, gidx2 = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+            heads2, gidx2 = ops.TupleSource(self.pts, idx, normal, pipe.pt_off, pipe.tup_off), None
             _, tf2 = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), None, gather=(heads2, gidx2, feat),
                                  decode=(u2, self.prior, pipe_b.bins))
             self._vote_pass("shot_", self.model, tf2, idx, self.scales_buf2, pipe=pipe_b,
@@ -283,7 +288,7 @@ class EnsembleStep(Step):
         # ---- model 1: SHOT (train_shot.py:75-83, 117-122; eval.py:223) -------------------------------------------
         pipe.use_slot(1)
         u = ops.philox_uniform(T, 6, a.seed, 2, ids, self.dev)
-        heads, gidx = ops.encode_tuples_shot_heads(self.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+        heads, gidx = ops.TupleSource(self.pts, idx, normal, pipe.pt_off, pipe.tup_off), None
         self._mark("shot_encode")
         _, tf = fused_stack((self.model.tuple_encoder, self.model.logit_encoder), None, gather=(heads, gidx, feat),
                             decode=(u, self.prior, pipe.bins))

@@ -56,9 +56,16 @@ __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 //                 belongs to the tuple's points has been evaluated once per POINT and slot (a table [points, slots, 2 x 32 NT],
 //                 RS_LINEAR writes it), so the accumulators start from bias + sum_i table[gidx[t, i]][i] and only the head
 //                 columns go through the matrix cores.
+//   RS_ENCODE     the GATHER launch that also builds the tuple's pair features itself (train_shot.py:75-83): the 30 coordinate
+//                 differences and the 10 |n_i . n_j| of the tuple's points -- the first 40 input columns, which the GATHER form
+//                 reads from a [rows, 40] array a separate kernel wrote (cppf_encode_tuples_shot_heads: 262 MB per 64 scenes out
+//                 and in again) -- are computed by the lanes of a row from pts / normals (L2-resident) with the encode kernel's
+//                 arithmetic, bit for bit, and stored straight into the x-tile slots of K steps 0, 1, 2 (with the first 8
+//                 descriptor columns, which share K step 2).  Input: the sampler's scene-local indices.
 #define RS_RESLAYER 0
 #define RS_LINEAR 1
 #define RS_SUMGATHER 2
+#define RS_ENCODE 3
 // (RS_SUMGATHER keeps the 8-wavefront workgroup of the other 128-wide launches.  Its table loads -- 160 sixteen-byte loads per lane
 // and row block, 32 distinct rows per wavefront instruction -- occupy the CU's texture-address unit for ~25 us per 256 rows while
 // no wavefront of the CU multiplies: 2.5 ms per launch against 1.85 ms with the loads removed and 2.4 ms with every load an L2 hit,
@@ -784,11 +791,75 @@ struct RsTap {                  // optional second output: the activation after 
 };
 
 struct RsGather {               // GATHER launches: see RsX; RS_SUMGATHER: the per-point slot tables
-  const int32_t* gidx = nullptr;   // [rows, slots] global point indices
+  const int32_t* gidx = nullptr;   // [rows, slots] global point indices (RS_ENCODE: scene-local ones, as the sampler writes them)
   const float* table = nullptr;    // GATHER: [points, 1 << fshift]; RS_SUMGATHER: [points, slots, 2 x 32 NT] (row pitch tld floats)
   int slots = 0, head = 0, fshift = 0;
   int64_t tld = 0;
+  // RS_ENCODE: the cloud's points and normals [points, 3], the scenes' point / tuple offsets [B + 1]
+  const float* pts = nullptr;
+  const float* nrm = nullptr;
+  const int32_t* pt_off = nullptr;
+  const int32_t* tup_off = nullptr;
+  int B = 0;
 };
+
+struct RsRow3 {                  // a 12-byte row of a [points, 3] array (4-byte aligned): one load instruction
+  float x, y, z;
+};
+
+// RS_ENCODE: the x tiles of K steps 0, 1, 2 of this lane's row -- input columns 0 .. 47 = [30 coordinate differences p_i - p_j over
+// the pairs (i, j) in itertools.combinations order | 10 max(n_i . n_j, -(n_i . n_j)) | the first 8 descriptor columns of point 0]
+// -- computed and stored into the wavefront's three slots in the layout the LDS-DMA form leaves there (lane (r, g) holds columns
+// 16 s + 8 g + 0..7 of K step s: two 16-byte halves 1 KiB apart).  Arithmetic = encode_shot_heads_tile_kernel's (cppf_core.hip):
+// plain float32 subtractions; (x x' + y y') + z z' without contraction; fmaxf(s, -s).
+__device__ __forceinline__ void rs_encode_tiles(char* slots, int lane, int g, const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                const float* __restrict__ table, int fshift, int g0, int g1, int g2, int g3, int g4) {
+  constexpr int PI_[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, PJ_[10] = {1, 2, 3, 4, 2, 3, 4, 3, 4, 4};
+  const int gi[5] = {g0, g1, g2, g3, g4};
+  float v[48];
+  {
+    float p[5][3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const RsRow3 r = *reinterpret_cast<const RsRow3*>(pts + 3 * (int64_t)gi[q]);
+      p[q][0] = r.x; p[q][1] = r.y; p[q][2] = r.z;
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[3 * q + c] = p[PI_[q]][c] - p[PJ_[q]][c];
+  }
+  {
+    float n[5][3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const RsRow3 r = *reinterpret_cast<const RsRow3*>(nrm + 3 * (int64_t)gi[q]);
+      n[q][0] = r.x; n[q][1] = r.y; n[q][2] = r.z;
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const float* ni = n[PI_[q]];
+      const float* nj = n[PJ_[q]];
+      const float s_ = (ni[0] * nj[0] + ni[1] * nj[1]) + ni[2] * nj[2];
+      v[30 + q] = fmaxf(s_, -s_);
+    }
+  }
+  {
+    const float* d0 = table + ((int64_t)g0 << fshift);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(d0), b = *reinterpret_cast<const f32x4*>(d0 + 4);
+    v[40] = a.x; v[41] = a.y; v[42] = a.z; v[43] = a.w; v[44] = b.x; v[45] = b.y; v[46] = b.z; v[47] = b.w;
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    f32x4 lo, hi;
+    lo.x = g ? v[16 * s + 8] : v[16 * s + 0]; lo.y = g ? v[16 * s + 9] : v[16 * s + 1];
+    lo.z = g ? v[16 * s + 10] : v[16 * s + 2]; lo.w = g ? v[16 * s + 11] : v[16 * s + 3];
+    hi.x = g ? v[16 * s + 12] : v[16 * s + 4]; hi.y = g ? v[16 * s + 13] : v[16 * s + 5];
+    hi.z = g ? v[16 * s + 14] : v[16 * s + 6]; hi.w = g ? v[16 * s + 15] : v[16 * s + 7];
+    *reinterpret_cast<f32x4*>(slots + s * 2048 + lane * 16) = lo;
+    *reinterpret_cast<f32x4*>(slots + s * 2048 + 1024 + lane * 16) = hi;
+  }
+}
 
 // f16x2 (PC == 2, CPPF_MLP_ARITH=split16): every float32 operand as an fp16 pair hi + lo (22-23 significant bits), three
 // products per K step, float32 accumulate.  fp16 has five exponent bits, so the weights are multiplied by a power of two
@@ -810,6 +881,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   constexpr bool LIN = MODE == RS_LINEAR;
   static_assert(!LIN || (!PROJ && !GATHER && !DECODE), "a plain Linear has one product");
   static_assert(MODE != RS_SUMGATHER || (PROJ && !GATHER), "the table sums stand for columns of a projection layer's input");
+  static_assert(MODE != RS_ENCODE || (GATHER && !DECODE), "RS_ENCODE is a form of the gathering launch");
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
   const int lane = threadIdx.x & 63;
@@ -878,23 +950,41 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const int64_t rc = row < rows ? row : rows - 1;
     RsRow rw;
-    rw.xrow = x + rc * ldx;
+    rw.xrow = (MODE == RS_ENCODE) ? ga.table : x + rc * ldx;      // (RS_ENCODE has no head array: any valid address for masked loads)
     rw.g0 = rw.g1 = rw.g2 = rw.g3 = rw.g4 = rw.g5 = rw.g6 = rw.g7 = 0;
     if (GATHER || MODE == RS_SUMGATHER) {
       const int32_t* p = ga.gidx + rc * ga.slots;
+      int p0 = 0;
+      if (MODE == RS_ENCODE) {                      // scene-local indices: + the point offset of the row's scene
+        int lo = 0, hi = ga.B;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if ((int64_t)ga.tup_off[mid] <= rc) lo = mid; else hi = mid;
+        }
+        p0 = ga.pt_off[lo];
+      }
       rw.g0 = p[0];
       rw.g1 = ga.slots > 1 ? p[1] : 0; rw.g2 = ga.slots > 2 ? p[2] : 0; rw.g3 = ga.slots > 3 ? p[3] : 0;
       rw.g4 = ga.slots > 4 ? p[4] : 0; rw.g5 = ga.slots > 5 ? p[5] : 0; rw.g6 = ga.slots > 6 ? p[6] : 0;
       rw.g7 = ga.slots > 7 ? p[7] : 0;
+      if (MODE == RS_ENCODE) {
+        rw.g0 += p0; rw.g1 += ga.slots > 1 ? p0 : 0; rw.g2 += ga.slots > 2 ? p0 : 0; rw.g3 += ga.slots > 3 ? p0 : 0;
+        rw.g4 += ga.slots > 4 ? p0 : 0; rw.g5 += ga.slots > 5 ? p0 : 0; rw.g6 += ga.slots > 6 ? p0 : 0; rw.g7 += ga.slots > 7 ? p0 : 0;
+      }
     }
     return rw;
   };
   RsRow cur = row_of(bfirst < bend ? bfirst : 0);
-  if (bfirst < bend) {                            // x tiles of K steps 0, 1, 2 of the first row block into slots 0, 1, 2
-    xs.issue(0, 0, cur);
-    xs.issue(1, 1, cur);
-    xs.issue(2, 2, cur);
-  }
+  auto first_tiles = [&](const RsRow rw) {        // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
+    if constexpr (MODE == RS_ENCODE) {
+      rs_encode_tiles(xs.slots, lane, g, ga.pts, ga.nrm, ga.table, ga.fshift, rw.g0, rw.g1, rw.g2, rw.g3, rw.g4);
+    } else {
+      xs.issue(0, 0, rw);
+      xs.issue(1, 1, rw);
+      xs.issue(2, 2, rw);
+    }
+  };
+  if (bfirst < bend) first_tiles(cur);
   if constexpr (LIN) {
     // ---- plain Linear: per row block, one pass over x per column group; the accumulators go straight to memory -----------
     for (int64_t blk = bfirst; blk < bend; blk += bstride) {
@@ -1035,11 +1125,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
       }
     }
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
-    if (more) {
-      xs.issue(0, 0, nxt);
-      xs.issue(1, 1, nxt);
-      xs.issue(2, 2, nxt);
-    }
+    if (more) first_tiles(nxt);
     cur = nxt;
     // ---- y^T = skip^T + W2 h^T --------------------------------------------------------------------------
     rs_product_h<NT, NT, PF, PC>(o, h, ws, bs);
@@ -1282,6 +1368,40 @@ extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, 
   ga.fshift = __builtin_ctz((unsigned)fdim);
   return rs_launch<4, true, true>(heads, ld_heads, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
                                   n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga);
+}
+
+// cppf_reslayer_split_gather with the pair features built inside the kernel (RS_ENCODE): prepare_tuple_inputs (train_shot.py:75-83)
+// + the tuple encoder's first launch without any per-tuple array in between.  pts / normals float32 [points, 3], idx int32
+// [rows, 5] scene-local tuple indices (the sampler's), pt_off / tup_off int32 [B + 1]; table / fdim / out / wq / b1 / b0 / chain as
+// cppf_reslayer_split_gather with head_cols = 40 (wq = cppf_reslayer_split_stream_bytes(40 + 5 fdim, 128, 1, chain) bytes).
+extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, const int32_t* idx, int32_t k,
+                                          const int32_t* pt_off, const int32_t* tup_off, const float* table, int32_t fdim,
+                                          float* out, int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes,
+                                          const float* b1, const float* b0, int32_t chain, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && normals && idx && pt_off && tup_off && table && out && wq && b1 && b0 && rows >= 0);
+  CPPF_CHECK_ARG(fdim >= 8 && (fdim & (fdim - 1)) == 0 && (ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
+  CPPF_CHECK_ARG((((uintptr_t)table | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
+  if (k != 5 || n_out != 128) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_reslayer_split_encode: k = %d, n_out = %d (the kernel builds the 40 pair features of "
+             "5-point tuples for the 128-wide projection layer of the tuple encoder)", k, n_out);
+    return CPPF_EUNSUPPORTED;
+  }
+  const int k_in = 40 + k * fdim;
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, n_out, 1, chain));
+  if (rows == 0) return CPPF_OK;
+  RsGather ga;
+  ga.gidx = idx;
+  ga.table = table;
+  ga.slots = k;
+  ga.head = 40;
+  ga.fshift = __builtin_ctz((unsigned)fdim);
+  ga.pts = pts;
+  ga.nrm = normals;
+  ga.pt_off = pt_off;
+  ga.tup_off = tup_off;
+  ga.B = B;
+  return rs_launch<4, true, true, false, 3, RS_ENCODE>(nullptr, 0, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
+                                                       rs_cus(), (hipStream_t)stream, ga);
 }
 
 // The output layer of the logit head (train_shot.py:62-66: a 192-wide projection ResLayer = 6 coordinates x 32 bins) with the

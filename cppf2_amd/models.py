@@ -283,6 +283,14 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         # per-point parts of the first products come from slot tables (fold: _FoldedFirstLayer) and are summed into the accumulators
         fold = gather[3] if len(gather) > 3 else None
         heads, gidx, table = gather[:3]
+        source = None
+        if isinstance(heads, ops.TupleSource):
+            # the pair features are built inside the first launch (cppf_reslayer_split_encode) where that kernel exists; the
+            # other launch forms read them from the array the separate kernel writes
+            if fold is None and MLP_ARITH == "split" and ops.reslayer_split_encode_supported(heads.k, 128):
+                source = heads
+            else:
+                heads, gidx = heads.heads()
         entry = plan[0]
         w1t, b1, w0t, b0, w2t = entry[:5]
         if fold is not None:
@@ -290,7 +298,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
             assert _kernel_arith() and w0t is not None and w1t.shape[1] == 128 and k_in % 8 == 0, "table-fed first layer: see sum_supported"
             w1t, w0t = fold.w1_heads.t(), fold.w0_heads.t()
         else:
-            k_in = heads.shape[1] + gidx.shape[1] * table.shape[1]
+            k_in = heads.shape[1] + (source.k if source is not None else gidx.shape[1]) * table.shape[1]
             assert _kernel_arith() and w0t is not None and w1t.shape == (k_in, 128), "gathered first layer: see gather_supported"
         cache = _entry_cache(entry)
 
@@ -310,6 +318,8 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                                              scale=sc if MLP_ARITH == "split16" else None)
         elif MLP_ARITH == "split16":
             x = ops.reslayer_split16(heads, wq, bb1, bb0, 128, sc, chain=chain, gather=(gidx, table))
+        elif source is not None:
+            x = ops.reslayer_split_encode(source, table, wq, bb1, bb0, 128, chain=chain)
         else:
             x = ops.reslayer_split_gather(heads, gidx, table, wq, bb1, bb0, 128, chain=chain)
         li = 1 + chain
@@ -543,9 +553,9 @@ class BeyondCPPFShot(nn.Module):
 
     def heads_from_tuples(self, points, point_idxs_all, feat, normal, pt_off=None, tup_off=None, lazy_scale=False, decode=None,
                           sum_tables=False):
-        """heads(prepare_tuple_inputs(...)) with the [T, 360] tuple rows never written: the pair features (40 columns) and the
-        tuples' global point indices go to the first ResLayer's kernel, which reads the per-point descriptors `feat` itself
-        (same values, same arithmetic, bit-identical logits).  Falls back to the materialised rows when the first layer has
+        """heads(prepare_tuple_inputs(...)) with the [T, 360] tuple rows never written: the first ResLayer's kernel computes the
+        pair features (40 columns) of its rows from points / normals / the sampler's indices and reads the per-point descriptors
+        `feat` itself (cppf_reslayer_split_encode; same values, same arithmetic, bit-identical logits).  Falls back to the materialised rows when the first layer has
         no gathering kernel (other widths, training, native arithmetic).
         sum_tables=True: the descriptor columns' products with the first layer's weights are evaluated once per point and slot
         (first_layer_fold) and summed into the kernel's accumulators: the same multiplications in another order (float32-level
@@ -556,14 +566,16 @@ class BeyondCPPFShot(nn.Module):
         idx = point_idxs_all.to(torch.int32)
         if not (points.is_cuda and self.gather_supported(feat.shape[1], idx.shape[1])):
             return self.heads(ops.encode_tuples_shot(points, idx, feat, normal, pt_off, tup_off), lazy_scale=lazy_scale)
-        heads, gidx = ops.encode_tuples_shot_heads(points, idx, normal, pt_off, tup_off)
+        tuples = ops.TupleSource(points, idx, normal, pt_off, tup_off)
         draw = decode if (decode is not None and decode_supported(self.logit_encoder, feat)) else None
         if sum_tables and self.sum_supported(feat.shape[1], idx.shape[1]):
             # the descriptor columns' share of the first products, once per point and slot instead of once per tuple
             fold = self.first_layer_fold(feat.shape[1], idx.shape[1])
+            heads, gidx = tuples.heads()
             src = (heads, gidx, fold.tables(feat.contiguous()), fold)
         else:
-            src = (heads, gidx, feat.contiguous())
+            # (round 5: the pair features are built by the first launch itself -- no per-tuple array between sampler and encoder)
+            src = (tuples, None, feat.contiguous())
         preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=src, decode=draw)
         second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
         if draw is not None:

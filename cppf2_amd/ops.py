@@ -451,6 +451,48 @@ def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
     return out
 
 
+class TupleSource:
+    """What prepare_tuple_inputs (train_shot.py:75-83) reads besides the descriptors: points, normals, the sampler's tuple indices
+    (scene-local with pt_off / tup_off: a batch; global without).  Handed to fused_stack(gather=(TupleSource, None, table)) the
+    first tuple-encoder launch builds the 40 pair features itself (reslayer_split_encode); heads() materialises them through
+    the separate kernel for the launch forms that read an array (f16x2 arithmetic, the table-fed first layer)."""
+
+    def __init__(self, points, point_idxs_all, normal, pt_off=None, tup_off=None):
+        dev = _dev()
+        self.pts = _t(points, torch.float32, dev)
+        self.nrm = _t(normal, torch.float32, dev)
+        self.idx = _t(point_idxs_all, torch.int32, dev)
+        T, self.k = self.idx.shape
+        if pt_off is None:
+            pt_off, tup_off = _offsets([self.pts.shape[0]], dev), _offsets([T], dev)
+        self.pt_off, self.tup_off = pt_off, tup_off
+        self.B = pt_off.numel() - 1
+        self.shape = (T, self.k * (self.k - 1) // 2 * 4)           # of the pair-feature block it stands for
+
+    def heads(self):
+        return encode_tuples_shot_heads(self.pts, self.idx, self.nrm, self.pt_off, self.tup_off)
+
+
+def reslayer_split_encode_supported(k, n_out):
+    return int(k) == 5 and int(n_out) == 128
+
+
+def reslayer_split_encode(src, table, wq, b1, b0, n_out, chain=0):
+    """reslayer_split_gather with the pair features built inside the kernel (cppf_reslayer_split_encode): rows
+    [40 pair features of src | table[idx[:, 0]] | ...], bit-identical to the two-kernel form.  Returns float32 [T, n_out]."""
+    assert isinstance(src, TupleSource) and table.dtype == torch.float32 and table.is_contiguous() and table.is_cuda
+    rows = src.idx.shape[0]
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=table.device)
+    b1 = b1.contiguous()
+    b0 = b0.contiguous()
+    assert b1.numel() == (1 + chain) * n_out
+    _lib.check(_L.cppf_reslayer_split_encode(src.B, _p(src.pts), _p(src.nrm), _p(src.idx), src.k, _p(src.pt_off), _p(src.tup_off),
+                                             _p(table), table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
+                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+               "cppf_reslayer_split_encode")
+    return out
+
+
 def linear_split_supported(k_in, n_out):
     """True when cppf_linear_split evaluates an nn.Linear of these dims (input columns a multiple of 8, outputs of 256)."""
     return k_in % 8 == 0 and _L.cppf_linear_split_stream_bytes(int(k_in), int(n_out)) > 0

@@ -401,6 +401,15 @@ int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t hea
                                const float* table, int32_t fdim, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                                const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
                                void* stream);
+/* prepare_tuple_inputs (train_shot.py:75-83) and the tuple encoder's first launch in ONE kernel (ABI 9): the 40 pair features of a
+ * 5-point tuple -- what cppf_encode_tuples_shot_heads writes, bit for bit -- are computed by the ResLayer kernel's own lanes from
+ * pts / normals float32 [points, 3] and the sampler's scene-local idx int32 [rows, 5] (pt_off / tup_off int32 [B + 1]) and go
+ * straight into its x tiles; the descriptors are gathered from `table` as in cppf_reslayer_split_gather.  No per-tuple array exists
+ * between the sampler and the tuple encoder.  k = 5, n_out = 128; wq / b1 / b0 / chain for k_in = 40 + 5 fdim. */
+int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, const int32_t* idx, int32_t k,
+                               const int32_t* pt_off, const int32_t* tup_off, const float* table, int32_t fdim, float* out,
+                               int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
+                               const float* b0, int32_t chain, void* stream);
 
 /* ---- the DINO model's tuple encode without its rows, and every Linear of both models on the matrix cores (train_dino.py:86-97,
  * 128-133; reference call site eval.py:221).

@@ -116,7 +116,8 @@ def test_missing_profiler_or_failed_pass_gives_a_reason_not_a_number(bench, monk
     assert "rocprofv3 exit 3" in out["reason"] and "boom" in out["reason"]
     bench.COUNTERS.clear()
     bench.COUNTERS.update(out)
-    assert bench.pmc_traffic_mlp() is None and bench.pmc_traffic("vote_center") is None
+    assert bench.pmc_traffic_mlp() is None and bench.pmc_traffic_mlp(3, False) is None and bench.pmc_traffic("vote_center") is None
+    assert bench.tuple_mlp_kernels(3, True)[0].endswith("3, 3>") and bench.tuple_mlp_kernels(2, True)[0].endswith("2, 0>#large")
 
 
 def test_a_hanging_pass_is_stopped_as_a_whole_process_group(bench, monkeypatch, tmp_path):

@@ -264,6 +264,62 @@ def test_gathered_first_layer_is_bit_identical_to_the_materialised_rows():
 
 
 @pytest.mark.gpu
+def test_pair_features_built_inside_the_first_launch(small):
+    """cppf_reslayer_split_encode (round 5: prepare_tuple_inputs, train_shot.py:75-83, and the tuple encoder's first launch in ONE
+    kernel -- the 40 pair features are computed by the kernel's lanes and go straight into its x tiles) against the two-kernel form
+    (cppf_encode_tuples_shot_heads + cppf_reslayer_split_gather) and against the materialised rows: the same outputs bit for bit.
+    Cases: the reference's golden tuples (small_encode_shot: its rows ARE the reference's prepare_tuple_inputs output), a ragged
+    batch with one-row and empty-ish scenes, and a batch large enough for every workgroup to walk several row blocks (XCD block map)."""
+    from cppf2_amd import models, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w1 = (torch.randn(128, 360, generator=g) / 360 ** 0.5).to(dev)
+    w0 = (torch.randn(128, 360, generator=g) / 360 ** 0.5).to(dev)
+    w2 = (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev)
+    chain = [((torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev), (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev))
+             for _ in range(2)]
+    b1 = torch.randn(3 * 128, generator=g).to(dev)
+    b0 = torch.randn(128, generator=g).to(dev)
+    wq = models.pack_split(w1, w0, w2, 360, chain=chain)
+
+    def both(pts, nrm, feat, idx, Ns, Ts):
+        pt_off, tup_off = ops._offsets(Ns, dev), ops._offsets(Ts, dev)
+        heads, gidx = ops.encode_tuples_shot_heads(pts, idx, nrm, pt_off, tup_off)
+        want = ops.reslayer_split_gather(heads, gidx, feat, wq, b1, b0, 128, chain=2)
+        src = ops.TupleSource(pts, idx, nrm, pt_off, tup_off)
+        assert src.B == len(Ns) and src.shape == (idx.shape[0], 40)
+        got = ops.reslayer_split_encode(src, feat, wq, b1, b0, 128, chain=2)
+        assert got.shape == want.shape and torch.equal(got, want)
+        return got, heads
+
+    # the reference's own rows
+    pts, nrm, feat = (torch.from_numpy(small[k]).to(dev) for k in ("small_pc", "small_normal", "small_feat"))
+    idx = torch.from_numpy(small["small_idx"]).to(dev, torch.int32)
+    got, heads = both(pts, nrm, feat, idx, [256], [512])
+    assert np.array_equal(heads.cpu().numpy(), small["small_encode_shot"][:, :40])
+    rows = torch.from_numpy(small["small_encode_shot"]).to(dev)
+    assert torch.equal(got, ops.reslayer_split(rows, wq, b1, b0, 128, chain=2))
+    # ragged: scenes of 1 row, 255 / 256 / 257 rows (row-block edges), one point
+    Ns, Ts = [300, 1, 77, 512, 5], [255, 1, 256, 257, 33]
+    pts = torch.randn(sum(Ns), 3, device=dev)
+    nrm = torch.nn.functional.normalize(torch.randn(sum(Ns), 3, device=dev), dim=-1)
+    nrm[7] = 0.0                                                       # a NaN-cleaned normal (eval.py:216)
+    feat = torch.randn(sum(Ns), 64, device=dev)
+    idx = torch.cat([torch.randint(0, n, (t, 5), device=dev, dtype=torch.int32) for n, t in zip(Ns, Ts)])
+    both(pts, nrm, feat, idx, Ns, Ts)
+    # many row blocks per workgroup: 40 scenes x 20 000 tuples = 3 125 row blocks over 256 workgroups
+    Ns, Ts = [1024] * 40, [20000] * 40
+    pts = torch.randn(sum(Ns), 3, device=dev)
+    nrm = torch.nn.functional.normalize(torch.randn(sum(Ns), 3, device=dev), dim=-1)
+    feat = torch.randn(sum(Ns), 64, device=dev)
+    idx = torch.randint(0, 1024, (sum(Ts), 5), device=dev, dtype=torch.int32)
+    both(pts, nrm, feat, idx, Ns, Ts)
+    # unsupported shapes are refused, not approximated
+    assert not ops.reslayer_split_encode_supported(4, 128) and not ops.reslayer_split_encode_supported(5, 256)
+
+
+@pytest.mark.gpu
 def test_bin_draw_fused_into_the_output_layer_equals_decode_bins():
     """cppf_reslayer_split_decode + cppf_decode_from_bins against cppf_reslayer_split + cppf_decode_bins (eval.py:225-240):
     the same bins and vote parameters bit for bit, with and without a logit prior, on a ragged batch."""

@@ -160,15 +160,20 @@ def test_bench_measures_its_counters_in_the_run():
     # EVERY per-kernel fraction is a fraction
     fr = {k: e["frac"] for k, e in r["per_kernel"].items()}
     assert all(f is None or 0.0 < f <= 1.0 for f in fr.values()), fr
-    assert sum(f is not None for f in fr.values()) >= 8, fr
+    assert sum(f is not None for f in fr.values()) >= 7, fr
     for k in ("shot_frames", "shot352", "vote_center", "rot_bins"):
         e = r["per_kernel"][k]
         assert e["bound"] in ("valu", "lds") and e["frac"] is not None and e["activity"]["invalid"] is None, (k, e)
         assert e["activity"]["valu_issue"] <= e["activity"]["valu_busy"] * 1.001 + 1e-3, e      # issue rate: a lower bound of busy
     vc = r["per_kernel"]["vote_center"]
     assert vc["work"]["votes_per_s"] > 0 and vc["pmc_MB"] is not None, vc
+    # the tuple encode has no kernel of its own since round 5 (built inside the MLP's first launch); the streaming kernels' fractions
+    # are on the kernel's own duration (rocprofv3 dispatch timestamps of this run), not on the HIP-event gap of the stage
     enc = r["per_kernel"]["encode_tuples"]
-    assert enc["bound"] == "hbm" and "rocprofv3 dispatch timestamps" in enc["frac_kind"] and 0 < enc["kernel_ms"] <= enc["event_ms"] * 1.5
+    assert enc["bound"] == "fused" and enc["frac"] is None and enc["kernel"] is None
+    dec = r["per_kernel"]["decode_bins"]
+    assert dec["bound"] == "hbm" and "rocprofv3 dispatch timestamps" in dec["frac_kind"] and 0 < dec["kernel_ms"] <= dec["event_ms"] * 1.5
+    assert r["hbm"]["kernel"] in ("decode_bins", "sample_tuples")
     assert r["per_kernel"]["assemble_pose"]["bound"] == "latency"
     busy = [v.get("mfma_busy") for v in r["mfma_busy_per_launch"].values()]
     assert all(b is not None and 0.0 < b <= 1.0 for b in busy), r["mfma_busy_per_launch"]
