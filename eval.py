@@ -108,6 +108,32 @@ def _side_streams(dev):
     return _SIDE_STREAMS[key]
 
 
+_PIPES = {}                # batch geometry -> (pipe, twin | None, [scales_buf, scales_buf]); least recently used first
+PIPE_CACHE_MAX = 4
+
+
+def _pipelines(dev, Ns, num_pairs, k, cfg, num_rots, angle_tol, backproj_ratio, imp_wt_margin, cap, two):
+    """The VotingPipeline (+ its twin for the two-stream mode, + the [T, 3] scale buffers of the two passes) of one batch geometry,
+    kept from call to call: a streaming evaluation calls run_ensemble once per batch and category, and building a pipeline means
+    ~25 device allocations, the workspace, and host-to-device copies of the offsets, sphere bins, bin lookup table and rotation
+    table -- per call, before.  Keyed by everything the buffers' sizes and tables depend on; at most PIPE_CACHE_MAX geometries are
+    kept (real batches are ragged: a batch with new point counts builds its own and evicts the oldest).  The buffers of a cached
+    pipeline are overwritten by the next call with the same geometry: a caller that keeps run_ensemble's `pipe` reads it before."""
+    key = (str(torch.device(dev)), tuple(Ns), int(num_pairs), int(k), float(cfg.res), int(num_rots), float(angle_tol),
+           float(backproj_ratio), float(imp_wt_margin), tuple(cfg.up), tuple(cfg.right), tuple(cfg.front), int(cap), bool(two))
+    hit = _PIPES.pop(key, None)
+    if hit is None:
+        pipe = VotingPipeline(Ns, [num_pairs] * len(Ns), k=k, res=cfg.res, num_rots=num_rots, angle_tol=angle_tol,
+                              backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, cfg_up=cfg.up,
+                              cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
+        bufs = [torch.zeros((pipe.Ttot, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        hit = (pipe, pipe.twin() if two else None, bufs)
+    _PIPES[key] = hit
+    while len(_PIPES) > PIPE_CACHE_MAX:
+        del _PIPES[next(iter(_PIPES))]
+    return hit
+
+
 @torch.no_grad()
 def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_pairs, num_rots, angle_tol=1.,
                  imp_wt_margin=0.01, backproj_ratio=.1, opt=False, geo_branch=True, visual_branch=True, up_sym=False,
@@ -133,9 +159,8 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     if cap * B > (1 << 33):
         raise ValueError("vote grids of %d cells x %d instances do not fit one batch; evaluate fewer instances per call" % (cap, B))
     pts = torch.from_numpy(np.concatenate(pcs)).to(dev)
-    pipe = VotingPipeline(Ns, [num_pairs] * B, k=k, res=cfg.res, num_rots=num_rots, angle_tol=angle_tol,
-                          backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, cfg_up=cfg.up,
-                          cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
+    two = bool(two_streams) and not keep
+    pipe, twin, scale_bufs = _pipelines(dev, Ns, num_pairs, k, cfg, num_rots, angle_tol, backproj_ratio, imp_wt_margin, cap, two)
     # eval.py:207 -- one tuple table per instance, shared by both models
     idx = torch.cat([ops.sample_tuples(n, num_pairs, k, seed, (s,), dev) for s, n in zip(scene_ids, Ns)])
     # descriptors: device tensors stay where they are (main_nocs samples them on the GPU), host arrays are uploaded one by one --
@@ -147,10 +172,9 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     scale_prior = None
     if scale_priors is not None:
         scale_prior = torch.from_numpy(np.asarray(scale_priors, dtype=np.float32)).to(dev).repeat_interleave(num_pairs, 0)
-    two = bool(two_streams) and not keep
     main = torch.cuda.current_stream(dev)
     streams = _side_streams(dev) if two else [main, main]
-    pipes = [pipe, pipe.twin() if two else pipe]
+    pipes = [pipe, twin if two else pipe]
     for st_ in streams:
         st_.wait_stream(main)
     kept = []
@@ -161,7 +185,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
         model = (dino_model, shot_model)[model_idx]
         pp = pipes[model_idx]
         pp.use_slot(model_idx)                       # each pass writes its own records; nothing is read back before the end
-        scales_buf = torch.zeros((pp.Ttot, 3), dtype=torch.float32, device=dev)
+        scales_buf = scale_bufs[model_idx]           # (rows of pairs that are not kept are never read: assemble() walks the kept list)
         u = torch.cat([ops.philox_uniform(num_pairs, 6, seed, 1 + model_idx, (s,), dev) for s in scene_ids])
         # eval.py:225-229 (the bin draw) runs as the epilogue of the logit head's output layer when the kernels allow it (split
         # arithmetic, no intermediates requested): the heads then return None in place of the logits.  The scale head is
@@ -364,9 +388,12 @@ def main_nocs(setups, log_dir, data_root="NOCS/real_test", out_dir=None, desc_np
         cfg, dino_model, shot_model = setups[cat]
         descs = []
         for (_, _, g_, pc, desc) in chunk:
-            if desc is None:                      # no token maps: seeded unit vectors, drawn on the device (per-instance stream)
-                gen = torch.Generator(device=dev).manual_seed(seed * 7919 + g_ + 1)
-                desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen, device=dev), dim=-1)
+            if desc is None:
+                # no token maps: seeded unit vectors from a CPU generator, one stream per instance -- the same numbers on every
+                # device and in every round (round 4 drew them with a device generator, whose stream is not the CPU's: seeded
+                # `--data=nocs` stand-in runs were not comparable with earlier ones)
+                gen = torch.Generator(device="cpu").manual_seed(seed * 7919 + g_ + 1)
+                desc = torch.nn.functional.normalize(torch.randn((pc.shape[0], 1024), generator=gen), dim=-1).to(dev)
             descs.append(desc)
         r = run_ensemble(cfg, dino_model, shot_model, [c_[3] for c_ in chunk], descs, seed, [c_[2] for c_ in chunk],
                          num_pairs, num_rots, angle_tol, imp_wt_margin, backproj_ratio, bool(opt), geo_branch,

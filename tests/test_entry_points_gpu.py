@@ -111,6 +111,41 @@ def test_eval_main_synthetic(tmp_path, monkeypatch):
     assert rep2["results"][0]["model"] == "shot"
 
 
+def test_run_ensemble_reuses_its_pipelines(monkeypatch):
+    """run_ensemble built a VotingPipeline + twin (buffers, workspace, table uploads) on every call.  Now one per batch
+    geometry, kept across calls (bounded), with the same records from the reused buffers as from fresh ones."""
+    monkeypatch.chdir(ROOT)
+    sys.path.insert(0, ROOT)
+    import eval as ev
+    from cppf2_amd import synth
+    cfg, dino, shot_model = ev.load_category("bottle")
+    N, T, R = 512, 3000, 36
+    dev = torch.device("cuda")
+
+    def batch(ids, n=N):
+        scenes = [synth.make_scene(3, s, n) for s in ids]
+        g = torch.Generator(device="cpu").manual_seed(7)
+        descs = [torch.nn.functional.normalize(torch.randn((n, 1024), generator=g), dim=-1).numpy() for _ in scenes]
+        priors = ev._teacher_prior(np.concatenate([s["pc_canon"] for s in scenes]), dev)
+        return ev.run_ensemble(cfg, dino, shot_model, [s["pc"] for s in scenes], descs, 3, ids, T, R, up_sym=True, priors=priors)
+    ev._PIPES.clear()
+    a = batch([0, 1])
+    rec_a = [r.copy() for r in a["records"]]
+    pipe_a = a["pipe"]
+    b = batch([2, 3])                                   # same geometry, other scenes: the same pipeline object, other records
+    assert b["pipe"] is pipe_a and len(ev._PIPES) == 1
+    assert not np.array_equal(b["records"][0]["t"], rec_a[0]["t"])
+    c = batch([0, 1])                                   # and back: the reused buffers give the first call's records, byte for byte
+    assert c["pipe"] is pipe_a
+    for m in (0, 1):
+        assert c["records"][m].tobytes() == rec_a[m].tobytes()
+    d = batch([0, 1], n=640)                            # another geometry: its own pipeline
+    assert d["pipe"] is not pipe_a and len(ev._PIPES) == 2
+    for n in (650, 660, 670, 680):
+        batch([0], n=n)
+    assert len(ev._PIPES) == ev.PIPE_CACHE_MAX          # bounded: the oldest geometries were dropped
+
+
 def test_train_entry_points_write_the_run_dir_eval_loads(tmp_path, monkeypatch):
     """train_shot / train_dino -> the reference's run directory (config/config.yaml:16-22 + train_shot.py:136-142:
     <run dir>/.hydra/config.yaml and lightning_logs/version_0/checkpoints/{epoch=N,last}.ckpt) -> eval.main(ckpt_dir=...)
