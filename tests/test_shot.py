@@ -263,6 +263,41 @@ def test_hip_shot_pcl_arithmetic_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["pcl", "f64"])
+def test_hip_shot_at_voxel_grid_density_vs_oracle(arith):
+    """The density real inputs have (eval.py:185-201 keeps one point per 2 mm voxel: ~250 neighbours inside the 10 x res support,
+    bench.py --cloud voxel2mm / cppf2_amd.synth.make_scene_voxel2mm) -- the long-list paths of the kernels: shot_pcl_long's second
+    pass for every query (PCL arithmetic), shot_cov's multi-pass float64 sums, shot_hist's four rounds and selection tie-break --
+    against the oracle in both arithmetics, same criteria as at bench density."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from scipy.spatial import cKDTree
+    from cppf2_amd import ops, shot
+    scs = [synth.make_scene_voxel2mm(0, s, 4096) for s in (0, 5)]
+    nn = np.array([len(x) for x in cKDTree(scs[0]["pc"]).query_ball_point(scs[0]["pc"], 0.02)])
+    assert 200 < nn.mean() < 300 and nn.max() > 256                      # four to five 64-entry rounds per query
+    pts = torch.as_tensor(np.concatenate([s["pc"] for s in scs])).cuda()
+    pt_off = ops._offsets([4096, 4096], pts.device)
+    hs, hn, hrf = shot.compute_device(pts, pt_off, 0.02, 0.02, want_rf=True, arithmetic=arith)
+    hs, hn, hrf = hs.cpu().numpy(), hn.cpu().numpy(), hrf.cpu().numpy()
+    ntol, dtol, margin = (2e-5, 5e-5, 2e-5) if arith == "pcl" else (2e-6, 2e-5, 1e-6)
+    for b, sc in enumerate(scs):
+        sl = slice(4096 * b, 4096 * (b + 1))
+        os_, on, orf, d = S.compute_ex(sc["pc"], 0.02, 0.02, pcl_arithmetic=(arith == "pcl"))
+        assert np.array_equal(np.isnan(os_), np.isnan(hs[sl])) and np.array_equal(np.isnan(on), np.isnan(hn[sl]))
+        assert np.nanmax(np.abs(hn[sl] - on)) < ntol, float(np.nanmax(np.abs(hn[sl] - on)))
+        assert np.allclose(hrf[sl], orf, atol=2e-5, equal_nan=True)
+        ok = ~np.isnan(os_).any(1)
+        assert ok.mean() > 0.99
+        err = np.abs(hs[sl][ok] - os_[ok]).max(1)
+        exempt = (d[ok, 5] < margin) | (d[ok, 8] < 4e-7)
+        assert np.all(err[~exempt] < dtol), float(err[~exempt].max())
+        assert (err >= dtol).mean() < 2e-2
+        assert np.allclose(np.linalg.norm(hs[sl][ok], axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_hip_shot1344_vs_oracle():
     """shot.compute_color on the GPU (cppf_shot1344) against the oracle: rows agree to 2e-5 except where the oracle
     itself has a neighbour within 1e-6 of a decision boundary of PCL's interpolation (shape or colour step)."""
