@@ -1,7 +1,7 @@
 """Writes profiles/<round>_summary.md from the committed rocprofv3 kernel stats and the bench lines of the round (round 4 on: the
 bench line carries its own counters, so no separate PMC file is read).  usage: python scratch/profile_summary.py [r4]"""
 import csv, json, os, sys
-RND = sys.argv[1] if len(sys.argv) > 1 else "r4"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r5"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
 
@@ -36,7 +36,7 @@ steps, rows, foreign = kernel_rows(RND + "_kernel_stats.csv", "vote_worklist_ker
 out = []
 out.append("# Round profile summary %s (one MI355X)\n" % RND)
 out.append("Sources: `%s_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-scenes 0 "
-           "--single-stream --no-reference-order --no-native-arith --no-evidence --no-f16x2 --no-counters` (%d passes incl. priming); "
+           "--single-stream --no-reference-order --no-native-arith --no-evidence --no-f16x2 --no-counters --no-voxel-density` (%d passes incl. priming); "
            "`%s_step_trace.txt` = launch order of one step of that run; `%s_two_stream_trace.txt` = two consecutive steps of the "
            "default (two-stream) loop; `%s_bench_n1.json` = the default `python bench.py` line, whose counters (HBM bytes, unit "
            "activity) come from rocprofv3 passes the bench ran itself.\n" % (RND, steps, RND, RND, RND))
@@ -49,9 +49,16 @@ for k in ("value_reference_order", "value_f32_input_mfma", "value_f16x2_mfma"):
     if b.get(k):
         out.append("| %s | %.0f scenes/s |" % (k, b[k]))
 r = b["roofline"]
-out.append("| roofline (tuple MLP, %s) | %.0f TFLOP/s executed of %.0f = %.3f; launch_ms %.3f; HBM traffic %.2f GB per step |"
-           % (r["frac_kind"], r["achieved"], r["peak"], r["frac"], r["launch_ms"], (r["traffic"] or 0) / 1e9))
-out.append("| algorithmic float32 rate | %.0f TFLOP/s (f32-input MFMA peak %.0f) |" % (r["algorithmic_f32_tflops"], r["f32_input_mfma_peak_tflops"]))
+out.append("| value_voxel_density (clouds at 2 mm voxel spacing, one stream) | %.0f scenes/s, %.3f ms per step; descriptor stage %.3f ms |"
+           % (b["value_voxel_density"], b["voxel_density"]["ms_per_step"], b["voxel_density"]["shot_stage_ms"]))
+out.append("| roofline.frac (tuple MLP: algorithmic float32 flops / time / bf16 MFMA peak) | %.0f TFLOP/s of %.0f = **%.4f**; launch_ms %.3f "
+           "(rocprofv3: the three launches' durations in `%s_step_trace.txt`); HBM traffic %.2f GB per step |"
+           % (r["achieved"], r["peak"], r["frac"], r["launch_ms"], RND, (r["traffic"] or 0) / 1e9))
+out.append("| roofline.frac_executed (bf16 MFMA work issued, 6 products per float32 product) | %.0f TFLOP/s = %.3f |" % (r["achieved_executed"], r["frac_executed"]))
+out.append("| roofline.frac_vs_f32_mfma_peak (same algorithmic rate / %.0f TFLOP/s of the f32-input matrix instruction) | %.3f |"
+           % (r["f32_input_mfma_peak_tflops"], r["frac_vs_f32_mfma_peak"]))
+out.append("| roofline.hbm (longest streaming kernel: %s) | %.0f GB/s algorithmic on the kernel's rocprofv3 duration = %.3f of 8 TB/s |"
+           % (r["hbm"]["kernel"], r["hbm"]["achieved"], r["hbm"]["frac"]))
 cb = b.get("cpu_baseline")
 if cb:
     out.append("| cpu_baseline | %.3f scenes/s on %d cores (%s) |" % (cb["value"], cb["cores"], cb["kind"]))
@@ -64,14 +71,16 @@ for key, per, us in rows:
 out.append("| **sum** | %.0f | | **%.1f** |" % (sum(x[1] for x in rows), tot))
 out.append("\nPyTorch / BLAS kernels launched once (or k times) per step: **%d** %s\n" % (len(foreign), foreign if foreign else ""))
 out.append("## Stages: bound and fraction of that bound (from the bench line, counters of the same run)\n")
-out.append("| stage | kernel | ms | bound | frac | alg MB | counters' MB | VALU / LDS / conflicts busy | work |\n|---|---|---|---|---|---|---|---|---|")
+out.append("(`frac`: streaming kernels = algorithmic bytes / rocprofv3 kernel duration / 8 TB/s; descriptor and voting kernels = the busier of "
+           "VALU instruction issue (instructions x 2 cycles / SIMD-32 capacity) and LDS-array cycles, from the SQ pass: never above 1.)\n")
+out.append("| stage | kernel | event ms | kernel ms | bound | frac | alg MB | counters' MB | VALU issue / VALU busy / LDS / conflicts | work |\n|---|---|---|---|---|---|---|---|---|---|")
 for s_, e in r["per_kernel"].items():
     a = e.get("activity") or {}
     w = e.get("work") or {}
     wtxt = ", ".join("%s %.3g" % (k_, v_) for k_, v_ in w.items() if isinstance(v_, (int, float)) and k_.endswith("_per_s"))
-    out.append("| %s | `%s` | %.4f | %s | %s | %s | %s | %s / %s / %s | %s |" % (
-        s_, e.get("kernel"), e["ms"], e.get("bound"), e.get("frac"), e.get("alg_MB"), e.get("pmc_MB"),
-        a.get("valu_busy"), a.get("lds_busy"), a.get("lds_bank_conflict"), wtxt))
+    out.append("| %s | `%s` | %.4f | %s | %s | %s | %s | %s | %s / %s / %s / %s | %s |" % (
+        s_, e.get("kernel"), e["ms"], e.get("kernel_ms", ""), e.get("bound"), e.get("frac"), e.get("alg_MB"), e.get("pmc_MB"),
+        a.get("valu_issue"), a.get("valu_busy"), a.get("lds_busy"), a.get("lds_bank_conflict"), wtxt))
 out.append("\nMatrix-pipe activity of the three tuple-MLP launches: " + "; ".join(
     "`%s` MFMA-busy %s at %s GHz" % (k_, v_.get("mfma_busy"), v_.get("shader_clock_ghz")) for k_, v_ in r["mfma_busy_per_launch"].items()) + "\n")
 for tag, title in (("ensemble", "Ensemble workload (configs[2])"), ("dense64k", "Dense-pair workload (configs[4])")):
@@ -81,9 +90,10 @@ for tag, title in (("ensemble", "Ensemble workload (configs[2])"), ("dense64k", 
         continue
     out.append("## %s\n" % title)
     out.append("`%s`\n" % e["config"]["workload"])
-    out.append("value %.0f scenes/s (%.3f ms per step)%s; roofline frac %.3f; pose_5deg5cm_vs_gt %.3f\n" % (
-        e["value"], e["ms_per_step"],
-        (", single stream %.0f" % e["value_single_stream"]) if e.get("value_single_stream") else "", e["roofline"]["frac"], e["pose_5deg5cm_vs_gt"]))
+    out.append("value %.0f %s (%.3f ms per step)%s; roofline frac %.4f (executed %.3f); pose_5deg5cm_vs_gt %.3f\n" % (
+        e["value"], e["unit"], e["ms_per_step"],
+        (", single stream %.0f" % e["value_single_stream"]) if e.get("value_single_stream") else "", e["roofline"]["frac"],
+        e["roofline"]["frac_executed"], e["pose_5deg5cm_vs_gt"]))
     if "per_model_ms" in e:
         out.append("per model: %s\n" % json.dumps(e["per_model_ms"]))
     out.append("per stage (ms): %s\n" % json.dumps(e["roofline"]["per_stage_ms"]))
@@ -91,5 +101,21 @@ for tag, title in (("ensemble", "Ensemble workload (configs[2])"), ("dense64k", 
         st, rws, fr = kernel_rows(RND + "_ensemble_kernel_stats.csv", "ensemble_select_kernel")
         out.append("kernels per step: %.0f launches, %.1f us; PyTorch / BLAS kernels per step: %d (`%s_ensemble_step_trace.txt`)\n"
                    % (sum(x[1] for x in rws), sum(x[1] * x[2] for x in rws), len(fr), RND))
+# the same step on clouds at voxel-grid density
+vs = os.path.join(P, RND + "_voxel2mm_kernel_stats.csv")
+if os.path.exists(vs):
+    st, rws, fr = kernel_rows(RND + "_voxel2mm_kernel_stats.csv", "vote_worklist_kernel")
+    out.append("## The step on clouds at voxel-grid density (`bench.py --cloud voxel2mm`, ~250 neighbours inside the 2 cm support)\n")
+    out.append("`%s_voxel2mm_kernel_stats.csv` / `%s_voxel2mm_step_trace.txt`: %.0f launches, %.1f us of kernel time per step; the kernels that move:\n"
+               % (RND, RND, sum(x[1] for x in rws), sum(x[1] * x[2] for x in rws)))
+    base = {k_: us for k_, per, us in rows}
+    out.append("| kernel | avg us (voxel2mm) | avg us (synthetic) |\n|---|---|---|")
+    for k_, per, us in rws:
+        if k_ in base and abs(us - base[k_]) > 0.15 * base[k_] and us > 20:
+            out.append("| `%s` | %.1f | %.1f |" % (k_, us, base[k_]))
+    out.append("")
+extra = os.path.join(P, RND + "_extra.md")
+if os.path.exists(extra):
+    out.append(open(extra).read())
 open(os.path.join(P, RND + "_summary.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:12]))
