@@ -27,7 +27,7 @@ def main(d):
         with open(os.path.join(d, job["tag"] + ".out"), "w") as out, open(os.path.join(d, job["tag"] + ".err"), "w") as err:
             try:
                 rc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + job["argv"], env=env, stdout=out, stderr=err,
-                                    cwd=root, timeout=job.get("timeout", 600)).returncode
+                                    cwd=root, timeout=job.get("timeout", 240)).returncode
             except subprocess.TimeoutExpired:
                 rc = -9
         with open(os.path.join(d, job["tag"] + ".rc"), "w") as f:

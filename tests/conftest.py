@@ -84,7 +84,7 @@ def bench_jobs_finished():
     """The bench jobs run to completion BEFORE the first test: they never share the GPU with a test (waiting is not fork + exec)."""
     proc = BENCH2.get("proc")
     if proc is not None:
-        BENCH2["runner_rc"] = proc.wait(timeout=1800)
+        BENCH2["runner_rc"] = proc.wait(timeout=1500)            # (six jobs of ~15-40 s each; 240 s limit per job in the runner)
     yield
 
 
