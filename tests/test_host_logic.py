@@ -275,3 +275,34 @@ def test_pin_rank_to_cores_reports_what_it_set(monkeypatch):
     assert launch.pin_rank_to_cores(0, 1) is None                                           # one rank: affinity left alone
     monkeypatch.setenv("CPPF_BENCH_NO_AFFINITY", "1")
     assert launch.pin_rank_to_cores(1, 2) is None
+
+
+def test_voxel_density_scene_generator():
+    """cppf2_amd.synth.make_scene_voxel2mm (bench.py --cloud voxel2mm / value_voxel_density): seeded, the same keys as make_scene,
+    and the neighbour density eval.py:185-201's 2 mm voxel grid gives real inputs (docs/measurements.md 3: ~250 inside the 2 cm
+    SHOT support, against ~90 for the bench's uniform surface samples)."""
+    from scipy.spatial import cKDTree
+    from cppf2_amd import synth
+    a, b = synth.make_scene_voxel2mm(0, 3, 4096), synth.make_scene_voxel2mm(0, 3, 4096)
+    assert set(a) == set(synth.make_scene(0, 3, 64)) and a["pc"].dtype == np.float32 and a["pc"].shape == (4096, 3)
+    assert np.array_equal(a["pc"], b["pc"]) and not np.array_equal(a["pc"], synth.make_scene_voxel2mm(0, 4, 4096)["pc"])
+    nn = np.array([len(x) for x in cKDTree(a["pc"]).query_ball_point(a["pc"], 0.02)])
+    assert 230 < nn.mean() < 280 and nn.max() <= 400                          # lists of the long-list kernels' capacity class
+    ns = np.array([len(x) for x in cKDTree(synth.make_scene(0, 3, 4096)["pc"]).query_ball_point(synth.make_scene(0, 3, 4096)["pc"], 0.02)])
+    assert 70 < ns.mean() < 110
+    # points sit on the 2 mm lattice of the camera frame up to the +-0.2 mm jitter; canonical coordinates map back through (R, t, diag)
+    off = np.abs(a["pc"] / 2e-3 - np.round(a["pc"] / 2e-3))
+    assert off.max() <= 0.1001 + 1e-3
+    back = (a["pc"].astype(np.float64) - a["t"]) @ a["R"] / a["diag"]
+    assert np.allclose(back, a["pc_canon"], atol=1e-6) and np.abs(a["pc_canon"]).max() <= 0.5
+
+
+def test_bench_command_line_defaults():
+    """The driver's contract: `python bench.py` with no flags = N = 1, a K / W that finish in minutes, the headline workload on the
+    synthetic clouds with the voxel-density figure beside it; every round-5 switch exists."""
+    from cppf2_amd.benchlib import launch
+    a = launch.parse([])
+    assert (a.gpus, a.steps, a.warmup, a.scenes_per_gpu, a.points, a.tuples, a.rots) == (1, 100, 3, 64, 4096, 20000, 180)
+    assert a.workload == "shot" and a.cloud == "synthetic" and not a.no_voxel_density and not a.separate_encode and not a.single_stream
+    b = launch.parse(["--gpus", "8", "--cloud", "voxel2mm", "--separate-encode", "--no-voxel-density", "--workload", "ensemble"])
+    assert b.gpus == 8 and b.cloud == "voxel2mm" and b.separate_encode and b.no_voxel_density and b.workload == "ensemble"
