@@ -109,6 +109,7 @@ SIGNATURES = {
     "cppf_decode_from_bins": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_encode_tuples_shot_heads": (_i, [_i, _p, _p, _p, _i, _p, _p, _i64, _p, _i, _p, _p]),
     "cppf_reslayer_split_gather": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
+    "cppf_reslayer_split_sumencode": (_i, [_i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
     "cppf_reslayer_split_encode": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
     "cppf_linear_split_stream_bytes": (_i64, [_i32, _i32]),
     "cppf_linear_split": (_i, [_p, _i64, _i32, _p, _i64, _i32, _i64, _p, _i64, _p, _p]),

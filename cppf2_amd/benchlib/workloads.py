@@ -229,7 +229,7 @@ class EnsembleStep(Step):
             fold = self.dino.first_layer_fold(5)
             tables = fold.tables(self.dino.transform_points(self.desc))
             u = ops.philox_uniform(T, 6, a.seed, 1, ids, self.dev)
-            heads, gidx = ops.encode_tuples_coord_heads(self.pts, idx, pipe.pt_off, pipe.tup_off)
+            heads, gidx = ops.TupleSource(self.pts, idx, None, pipe.pt_off, pipe.tup_off), None
             _, tf = fused_stack((self.dino.tuple_encoder, self.dino.logit_encoder), None, gather=(heads, gidx, tables, fold),
                                 decode=(u, self.prior, pipe.bins))
             self._vote_pass("dino_", self.dino, tf, idx, self.scales_buf, pipe=pipe, before_loss=self.dino_done.record)
@@ -279,7 +279,7 @@ class EnsembleStep(Step):
         tables = fold.tables(self.dino.transform_points(self.desc))      # desc_transform, then the folded slot products: per POINT
         self._mark("dino_point_transforms")
         u = ops.philox_uniform(T, 6, a.seed, 1, ids, self.dev)
-        heads, gidx = ops.encode_tuples_coord_heads(self.pts, idx, pipe.pt_off, pipe.tup_off)
+        heads, gidx = ops.TupleSource(self.pts, idx, None, pipe.pt_off, pipe.tup_off), None
         self._mark("dino_encode")
         _, tf = fused_stack((self.dino.tuple_encoder, self.dino.logit_encoder), None, gather=(heads, gidx, tables, fold),
                             decode=(u, self.prior, pipe.bins))

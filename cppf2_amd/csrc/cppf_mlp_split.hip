@@ -66,6 +66,9 @@ __host__ __device__ constexpr int rs_waves(int nt) { return nt >= 6 ? 4 : 8; }
 #define RS_LINEAR 1
 #define RS_SUMGATHER 2
 #define RS_ENCODE 3
+//   RS_SUMENCODE  RS_SUMGATHER with the head columns built in the kernel like RS_ENCODE: the DINO model's 30 coordinate differences
+//                 (train_dino.py:92; zero-padded to 32 columns = K steps 0 and 1) from pts and the sampler's scene-local indices.
+#define RS_SUMENCODE 5
 // (RS_SUMGATHER keeps the 8-wavefront workgroup of the other 128-wide launches.  Its table loads -- 160 sixteen-byte loads per lane
 // and row block, 32 distinct rows per wavefront instruction -- occupy the CU's texture-address unit for ~25 us per 256 rows while
 // no wavefront of the CU multiplies: 2.5 ms per launch against 1.85 ms with the loads removed and 2.4 ms with every load an L2 hit,
@@ -861,6 +864,35 @@ __device__ __forceinline__ void rs_encode_tiles(char* slots, int lane, int g, co
   }
 }
 
+// RS_SUMENCODE: the x tiles of K steps 0 and 1 -- input columns 0 .. 31 = [30 coordinate differences p_i - p_j in combinations order |
+// 0 0] (cppf_encode_tuples_coord_heads' columns, bit for bit: plain float32 subtractions).
+__device__ __forceinline__ void rs_encode_coord_tiles(char* slots, int lane, int g, const float* __restrict__ pts, int g0, int g1, int g2,
+                                                      int g3, int g4) {
+  constexpr int PI_[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, PJ_[10] = {1, 2, 3, 4, 2, 3, 4, 3, 4, 4};
+  const int gi[5] = {g0, g1, g2, g3, g4};
+  float p[5][3], v[32];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const RsRow3 r = *reinterpret_cast<const RsRow3*>(pts + 3 * (int64_t)gi[q]);
+    p[q][0] = r.x; p[q][1] = r.y; p[q][2] = r.z;
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[3 * q + c] = p[PI_[q]][c] - p[PJ_[q]][c];
+  v[30] = 0.0f; v[31] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    f32x4 lo, hi;
+    lo.x = g ? v[16 * s + 8] : v[16 * s + 0]; lo.y = g ? v[16 * s + 9] : v[16 * s + 1];
+    lo.z = g ? v[16 * s + 10] : v[16 * s + 2]; lo.w = g ? v[16 * s + 11] : v[16 * s + 3];
+    hi.x = g ? v[16 * s + 12] : v[16 * s + 4]; hi.y = g ? v[16 * s + 13] : v[16 * s + 5];
+    hi.z = g ? v[16 * s + 14] : v[16 * s + 6]; hi.w = g ? v[16 * s + 15] : v[16 * s + 7];
+    *reinterpret_cast<f32x4*>(slots + s * 2048 + lane * 16) = lo;
+    *reinterpret_cast<f32x4*>(slots + s * 2048 + 1024 + lane * 16) = hi;
+  }
+}
+
 // f16x2 (PC == 2, CPPF_MLP_ARITH=split16): every float32 operand as an fp16 pair hi + lo (22-23 significant bits), three
 // products per K step, float32 accumulate.  fp16 has five exponent bits, so the weights are multiplied by a power of two
 // `wscale` before they are split (the host picks it so that the largest weight of the launch sits near 2^13: the lo pieces stay
@@ -880,7 +912,9 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   constexpr int T0 = PROJ ? 2 * NT : NT;        // tiles of the first product: W1 [and W0 behind it]
   constexpr bool LIN = MODE == RS_LINEAR;
   static_assert(!LIN || (!PROJ && !GATHER && !DECODE), "a plain Linear has one product");
-  static_assert(MODE != RS_SUMGATHER || (PROJ && !GATHER), "the table sums stand for columns of a projection layer's input");
+  constexpr bool SUMG = MODE == RS_SUMGATHER || MODE == RS_SUMENCODE;      // the per-point parts come from slot tables
+  constexpr bool LOCAL_IDX = MODE == RS_ENCODE || MODE == RS_SUMENCODE;    // gidx holds the sampler's scene-local indices
+  static_assert(!SUMG || (PROJ && !GATHER), "the table sums stand for columns of a projection layer's input");
   static_assert(MODE != RS_ENCODE || (GATHER && !DECODE), "RS_ENCODE is a form of the gathering launch");
   constexpr bool PF = RS_DEEP_PREFETCH && WAVES == 4;   // LDS read-ahead: two tiles or (measured no slower) one
   extern __shared__ __attribute__((aligned(16))) char s_ring[];
@@ -950,12 +984,12 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const int64_t rc = row < rows ? row : rows - 1;
     RsRow rw;
-    rw.xrow = (MODE == RS_ENCODE) ? ga.table : x + rc * ldx;      // (RS_ENCODE has no head array: any valid address for masked loads)
+    rw.xrow = LOCAL_IDX ? ga.table : x + rc * ldx;      // (no head array in the encoding modes: any valid address for masked loads)
     rw.g0 = rw.g1 = rw.g2 = rw.g3 = rw.g4 = rw.g5 = rw.g6 = rw.g7 = 0;
-    if (GATHER || MODE == RS_SUMGATHER) {
+    if (GATHER || SUMG) {
       const int32_t* p = ga.gidx + rc * ga.slots;
       int p0 = 0;
-      if (MODE == RS_ENCODE) {                      // scene-local indices: + the point offset of the row's scene
+      if (LOCAL_IDX) {                      // scene-local indices: + the point offset of the row's scene
         int lo = 0, hi = ga.B;
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -967,7 +1001,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
       rw.g1 = ga.slots > 1 ? p[1] : 0; rw.g2 = ga.slots > 2 ? p[2] : 0; rw.g3 = ga.slots > 3 ? p[3] : 0;
       rw.g4 = ga.slots > 4 ? p[4] : 0; rw.g5 = ga.slots > 5 ? p[5] : 0; rw.g6 = ga.slots > 6 ? p[6] : 0;
       rw.g7 = ga.slots > 7 ? p[7] : 0;
-      if (MODE == RS_ENCODE) {
+      if (LOCAL_IDX) {
         rw.g0 += p0; rw.g1 += ga.slots > 1 ? p0 : 0; rw.g2 += ga.slots > 2 ? p0 : 0; rw.g3 += ga.slots > 3 ? p0 : 0;
         rw.g4 += ga.slots > 4 ? p0 : 0; rw.g5 += ga.slots > 5 ? p0 : 0; rw.g6 += ga.slots > 6 ? p0 : 0; rw.g7 += ga.slots > 7 ? p0 : 0;
       }
@@ -978,6 +1012,8 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   auto first_tiles = [&](const RsRow rw) {        // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
     if constexpr (MODE == RS_ENCODE) {
       rs_encode_tiles(xs.slots, lane, g, ga.pts, ga.nrm, ga.table, ga.fshift, rw.g0, rw.g1, rw.g2, rw.g3, rw.g4);
+    } else if constexpr (MODE == RS_SUMENCODE) {
+      rs_encode_coord_tiles(xs.slots, lane, g, ga.pts, rw.g0, rw.g1, rw.g2, rw.g3, rw.g4);
     } else {
       xs.issue(0, 0, rw);
       xs.issue(1, 1, rw);
@@ -1041,7 +1077,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     f32x16 (&o)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[NT]);
 #pragma unroll
     for (int u = 0; u < T0; ++u) rs_load_tile(acc[u], s_b1 + 32 * u, g);
-    if constexpr (MODE == RS_SUMGATHER) {
+    if constexpr (SUMG) {
       // + sum_i table[gidx[row, i]][i][:]: the per-point parts of x W1^T (tiles 0 .. NT-1) and x W0^T (tiles NT .. 2 NT-1) of this
       // lane's row, in slot order (a fixed order: the sums do not depend on the launch geometry).  Lane (r, g) owns features
       // 32 u + 8 q + 4 g + (0..3) of tile u: one 16-byte load each, 16 of them (4 tiles) requested before the first is added.
@@ -1487,6 +1523,37 @@ extern "C" int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_head
                                                            chain, rs_cus(), (hipStream_t)stream, ga);
 }
 
+
+// cppf_reslayer_split_sumgather with the coordinate columns built inside the kernel (RS_SUMENCODE): the DINO model's
+// prepare_tuple_inputs (train_dino.py:91-97) + its tuple encoder's first launch with no per-tuple array in between.  pts float32
+// [points, 3], idx int32 [rows, 5] scene-local (the sampler's), pt_off / tup_off int32 [B + 1]; tables / wq / b1 / b0 / chain as
+// cppf_reslayer_split_sumgather with head_cols = 32.
+extern "C" int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, int32_t k, const int32_t* pt_off,
+                                             const int32_t* tup_off, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
+                                             int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
+                                             const float* b0, int32_t chain, void* stream) {
+  CPPF_CHECK_ARG(B > 0 && pts && idx && pt_off && tup_off && tables && out && wq && b1 && b0 && rows >= 0);
+  CPPF_CHECK_ARG(ld_tables >= (int64_t)k * 256 && (ld_tables & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
+  CPPF_CHECK_ARG((((uintptr_t)tables | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
+  if (k != 5 || n_out != 128) {
+    snprintf(g_cppf_err, sizeof(g_cppf_err), "cppf_reslayer_split_sumencode: k = %d, n_out = %d (5-point tuples, the 128-wide projection "
+             "layer of the tuple encoder)", k, n_out);
+    return CPPF_EUNSUPPORTED;
+  }
+  CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(32, n_out, 1, chain));
+  if (rows == 0) return CPPF_OK;
+  RsGather ga;
+  ga.gidx = idx;
+  ga.table = tables;
+  ga.slots = k;
+  ga.tld = ld_tables;
+  ga.pts = pts;
+  ga.pt_off = pt_off;
+  ga.tup_off = tup_off;
+  ga.B = B;
+  return rs_launch<4, true, false, false, 3, RS_SUMENCODE>(nullptr, 0, 32, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
+                                                           rs_cus(), (hipStream_t)stream, ga);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // f16x2 arithmetic (CPPF_MLP_ARITH=split16): one entry point for every launch form

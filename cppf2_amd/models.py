@@ -285,9 +285,11 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         heads, gidx, table = gather[:3]
         source = None
         if isinstance(heads, ops.TupleSource):
-            # the pair features are built inside the first launch (cppf_reslayer_split_encode) where that kernel exists; the
-            # other launch forms read them from the array the separate kernel writes
-            if fold is None and MLP_ARITH == "split" and ops.reslayer_split_encode_supported(heads.k, 128):
+            # the head columns are built inside the first launch (cppf_reslayer_split_encode: the SHOT model's 40 pair features;
+            # cppf_reslayer_split_sumencode: the DINO model's coordinate block in front of its slot tables) where that kernel
+            # exists; the other launch forms read them from the array the separate kernel writes
+            if (MLP_ARITH == "split" and ops.reslayer_split_encode_supported(heads.k, 128)
+                    and (fold is None) == (heads.nrm is not None)):
                 source = heads
             else:
                 heads, gidx = heads.heads()
@@ -313,7 +315,9 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
         stamp = (cross if crossing else None, None if fold is None else fold.stamp)
         wq, bb1, bb0, sc = _packed(cache, (k_in, chain, crossing, fold is not None), w1t, w0t, w2t, k_in, plan[1:1 + chain], b1, b0,
                                    stamp=stamp, add=None if fold is None else (fold.b1_add, fold.b0_add))
-        if fold is not None:
+        if fold is not None and source is not None:
+            x = ops.reslayer_split_sumencode(source, table, wq, bb1, bb0, 128, chain=chain)
+        elif fold is not None:
             x = ops.reslayer_split_sumgather(heads, gidx, table, wq, bb1, bb0, 128, chain=chain,
                                              scale=sc if MLP_ARITH == "split16" else None)
         elif MLP_ARITH == "split16":
@@ -729,9 +733,10 @@ class BeyondCPPFDino(nn.Module):
         fold = self.first_layer_fold(k)
         if tables is None:
             tables = fold.tables(self.transform_points(point_descs.contiguous()))
-        heads, gidx = ops.encode_tuples_coord_heads(points, idx, pt_off, tup_off)
-        draw = decode if (decode is not None and decode_supported(self.logit_encoder, heads)) else None
-        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=(heads, gidx, tables, fold), decode=draw)
+        # (round 5: the coordinate columns are built by the first launch itself -- no per-tuple array between sampler and encoder)
+        tuples = ops.TupleSource(points, idx, None, pt_off, tup_off)
+        draw = decode if (decode is not None and decode_supported(self.logit_encoder, tables)) else None
+        preds_cls, feat = fused_stack((self.tuple_encoder, self.logit_encoder), None, gather=(tuples, None, tables, fold), decode=draw)
         second = feat if lazy_scale else fused_stack(self.scale_encoder, feat)
         if draw is not None:
             return None, second

@@ -452,24 +452,29 @@ def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
 
 
 class TupleSource:
-    """What prepare_tuple_inputs (train_shot.py:75-83) reads besides the descriptors: points, normals, the sampler's tuple indices
-    (scene-local with pt_off / tup_off: a batch; global without).  Handed to fused_stack(gather=(TupleSource, None, table)) the
-    first tuple-encoder launch builds the 40 pair features itself (reslayer_split_encode); heads() materialises them through
-    the separate kernel for the launch forms that read an array (f16x2 arithmetic, the table-fed first layer)."""
+    """What prepare_tuple_inputs reads besides the descriptors: points, the sampler's tuple indices (scene-local with pt_off /
+    tup_off: a batch; global without) and -- the SHOT model, train_shot.py:75-83 -- normals (normal=None: the DINO model's
+    coordinate block, train_dino.py:92).  Handed to fused_stack(gather=(TupleSource, None, table[, fold])) the first
+    tuple-encoder launch builds the head columns itself (reslayer_split_encode: 40 pair features; reslayer_split_sumencode: 30
+    coordinate differences); heads() materialises them through the separate kernel for the launch forms that read an array
+    (f16x2 arithmetic, the SHOT model's table-fed variant)."""
 
-    def __init__(self, points, point_idxs_all, normal, pt_off=None, tup_off=None):
+    def __init__(self, points, point_idxs_all, normal=None, pt_off=None, tup_off=None):
         dev = _dev()
         self.pts = _t(points, torch.float32, dev)
-        self.nrm = _t(normal, torch.float32, dev)
+        self.nrm = None if normal is None else _t(normal, torch.float32, dev)
         self.idx = _t(point_idxs_all, torch.int32, dev)
         T, self.k = self.idx.shape
         if pt_off is None:
             pt_off, tup_off = _offsets([self.pts.shape[0]], dev), _offsets([T], dev)
         self.pt_off, self.tup_off = pt_off, tup_off
         self.B = pt_off.numel() - 1
-        self.shape = (T, self.k * (self.k - 1) // 2 * 4)           # of the pair-feature block it stands for
+        npair = self.k * (self.k - 1) // 2
+        self.shape = (T, npair * 4 if normal is not None else (npair * 3 + 7) // 8 * 8)      # of the head block it stands for
 
     def heads(self):
+        if self.nrm is None:
+            return encode_tuples_coord_heads(self.pts, self.idx, self.pt_off, self.tup_off)
         return encode_tuples_shot_heads(self.pts, self.idx, self.nrm, self.pt_off, self.tup_off)
 
 
@@ -490,6 +495,23 @@ def reslayer_split_encode(src, table, wq, b1, b0, n_out, chain=0):
                                              _p(table), table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
                                              wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
                "cppf_reslayer_split_encode")
+    return out
+
+
+def reslayer_split_sumencode(src, tables, wq, b1, b0, n_out, chain=0):
+    """reslayer_split_sumgather with the coordinate columns built inside the kernel (cppf_reslayer_split_sumencode): bit-identical to
+    the two-kernel form.  src: TupleSource without normals; tables float32 [points, slots * 256].  Returns float32 [T, n_out]."""
+    assert isinstance(src, TupleSource) and src.nrm is None and tables.dtype == torch.float32 and tables.stride(1) == 1 and tables.is_cuda
+    rows = src.idx.shape[0]
+    assert tables.shape[1] == src.k * 256
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=tables.device)
+    b1 = b1.contiguous()
+    b0 = b0.contiguous()
+    assert b1.numel() == (1 + chain) * n_out
+    _lib.check(_L.cppf_reslayer_split_sumencode(src.B, _p(src.pts), _p(src.idx), src.k, _p(src.pt_off), _p(src.tup_off), _p(tables),
+                                                tables.stride(0), _p(out), out.stride(0), n_out, rows, _p(wq),
+                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+               "cppf_reslayer_split_sumencode")
     return out
 
 

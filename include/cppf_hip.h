@@ -438,6 +438,14 @@ int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t 
                                   const float* tables, int64_t ld_tables, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                                   const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
                                   void* stream);
+/* cppf_reslayer_split_sumgather with the coordinate columns built inside the kernel (ABI 9; RS_SUMENCODE): the DINO model's
+ * prepare_tuple_inputs (train_dino.py:91-97) + its tuple encoder's first launch with no per-tuple array in between -- pts float32
+ * [points, 3], idx int32 [rows, 5] scene-local tuple indices (the sampler's), pt_off / tup_off int32 [B + 1]; tables / wq / b1 / b0 /
+ * chain as cppf_reslayer_split_sumgather with head_cols = 32.  k = 5, n_out = 128.  Bit-identical to the two-kernel form. */
+int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, int32_t k, const int32_t* pt_off,
+                                  const int32_t* tup_off, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
+                                  int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
+                                  int32_t chain, void* stream);
 
 /* ---- the bin draw fused into the MLP's output layer (eval.py:225-229 behind train_shot.py:62-66): the 192-wide projection
  * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]

@@ -320,6 +320,36 @@ def test_pair_features_built_inside_the_first_launch(small):
 
 
 @pytest.mark.gpu
+def test_coordinate_columns_built_inside_the_table_fed_launch():
+    """cppf_reslayer_split_sumencode (the DINO model's first launch building its 30 coordinate differences itself, train_dino.py:92)
+    against cppf_encode_tuples_coord_heads + cppf_reslayer_split_sumgather: the same outputs bit for bit, ragged batch and a batch
+    with many row blocks per workgroup; through the model: heads_from_tuples == the row form's logits as before."""
+    from cppf2_amd import models, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(4)
+    w1 = (torch.randn(128, 32, generator=g) / 32 ** 0.5).to(dev)
+    w0 = (torch.randn(128, 32, generator=g) / 32 ** 0.5).to(dev)
+    w2 = (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev)
+    chain = [((torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev), (torch.randn(128, 128, generator=g) / 128 ** 0.5).to(dev))]
+    b1 = torch.randn(2 * 128, generator=g).to(dev)
+    b0 = torch.randn(128, generator=g).to(dev)
+    wq = models.pack_split(w1, w0, w2, 32, chain=chain)
+    for Ns, Ts in (([300, 1, 77, 512], [255, 1, 256, 257]), ([1024] * 24, [20000] * 24)):
+        pt_off, tup_off = ops._offsets(Ns, dev), ops._offsets(Ts, dev)
+        pts = torch.randn(sum(Ns), 3, device=dev)
+        tables = torch.randn(sum(Ns), 5 * 256, device=dev)
+        idx = torch.cat([torch.randint(0, n, (t, 5), device=dev, dtype=torch.int32) for n, t in zip(Ns, Ts)])
+        heads, gidx = ops.encode_tuples_coord_heads(pts, idx, pt_off, tup_off)
+        want = ops.reslayer_split_sumgather(heads, gidx, tables, wq, b1, b0, 128, chain=1)
+        src = ops.TupleSource(pts, idx, None, pt_off, tup_off)
+        assert src.shape == (sum(Ts), 32) and src.nrm is None
+        h2, g2 = src.heads()
+        assert torch.equal(h2, heads) and torch.equal(g2, gidx)
+        got = ops.reslayer_split_sumencode(src, tables, wq, b1, b0, 128, chain=1)
+        assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
 def test_bin_draw_fused_into_the_output_layer_equals_decode_bins():
     """cppf_reslayer_split_decode + cppf_decode_from_bins against cppf_reslayer_split + cppf_decode_bins (eval.py:225-240):
     the same bins and vote parameters bit for bit, with and without a logit prior, on a ragged batch."""
