@@ -40,6 +40,9 @@
 #endif
 #define VC_TAB_LEN (2 * VC_MAX_LDS_ROTS + 4)
 #define VC_LDS_WORDS (VC_SLAB_CELLS + 2 * VC_TAB_LEN + (VC_THREADS / 64) * 64)
+#ifndef VC_MIN_SLAB_CELLS
+#define VC_MIN_SLAB_CELLS 8192         // finest cut of a small grid (vote_worklist_kernel)
+#endif
 #ifndef VC_MIN_WAVES
 #define VC_MIN_WAVES 4
 #endif
@@ -373,7 +376,7 @@ __device__ __forceinline__ OwnerRegs find_owner(int qb, int WQ, int incl, int ex
 // marks per wavefront.
 template <bool ARCS, bool WEIGHTED>
 __device__ __forceinline__ void vote_slab_item(
-    uint32_t* slab, int& tag, int b, int s, int pc, int Pl,
+    uint32_t* slab, int& tag, int b, int s, int slab_cells, int pc, int Pl,
     const CppfSceneGrid& g, int G, const float* __restrict__ fr, int64_t total, const int32_t* __restrict__ tup_off,
     float res, int num_rots, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
     uint32_t* __restrict__ grid, const int64_t* __restrict__ grid_off, int64_t cells_cap,
@@ -384,8 +387,8 @@ __device__ __forceinline__ void vote_slab_item(
   const float* s_cos = reinterpret_cast<const float*>(slab + VC_SLAB_CELLS);
   const float* s_sin = s_cos + VC_TAB_LEN;
   uint32_t* s_mark = slab + VC_SLAB_CELLS + 2 * VC_TAB_LEN + (threadIdx.x >> 6) * 64;     // this wavefront's strip
-  const int lo = s * VC_SLAB_CELLS;
-  const int n = min(VC_SLAB_CELLS, G - lo);
+  const int lo = s * slab_cells;                               // slab_cells <= VC_SLAB_CELLS: the counters of this item
+  const int n = min(slab_cells, G - lo);
   for (int i = threadIdx.x; i < n; i += VC_THREADS) slab[i] = 0u;
   __syncthreads();
 #ifdef VC_DIAG
@@ -477,10 +480,10 @@ __device__ __forceinline__ void vote_slab_item(
     }
   }
   __syncthreads();
-  if (ARCS && narrow && s == 0) {
+  if (ARCS && narrow && lo < gyz) {
     // x-layer 0 is never a valid cell (train_dino.py:199 keeps indices > 0); the fast path clamps x instead of testing
-    // it, so whatever landed there is wiped here
-    for (int i = threadIdx.x; i < min(n, gyz); i += VC_THREADS) slab[i] = 0u;
+    // it, so whatever landed there is wiped here (the layer may span several small slabs)
+    for (int i = threadIdx.x; i < min(n, gyz - lo); i += VC_THREADS) slab[i] = 0u;
     __syncthreads();
   }
 #ifdef VC_DIAG
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_slab_ker
   const int mid = nslab >> 1, dd = (rank + 1) >> 1;
   const int s = (rank & 1) ? mid - dd : mid + dd;
   if (ARCS) vote_stage_tables(slab, num_rots, cos_tab, sin_tab);
-  vote_slab_item<ARCS, WEIGHTED>(slab, tag, b, s, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
+  vote_slab_item<ARCS, WEIGHTED>(slab, tag, b, s, VC_SLAB_CELLS, pc, P, g, G, fr, total, tup_off, res, num_rots, cos_tab, sin_tab,
                                  grid, grid_off, cells_cap, slab_best, s_max, P, nullptr, nullptr);
 }
 
@@ -592,17 +595,36 @@ __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid
                                                              int64_t cells_cap, int s_max, int max_parts, int target,
                                                              uint32_t* __restrict__ list, int* __restrict__ ctl) {
   __shared__ int s_wave[16];
-  __shared__ int s_base, s_maxn;
-  if (threadIdx.x == 0) { s_base = 0; s_maxn = 0; }
+  __shared__ int s_base, s_maxg, s_cells;
+  __shared__ unsigned long long s_sumg;
+  if (threadIdx.x == 0) { s_base = 0; s_maxg = 0; s_sumg = 0ull; }
   __syncthreads();
-  // slabs of the largest scene bound the ranks that exist at all
+  // Cells per slab.  A throughput-sized batch of SMALL grids (64 objects of 8e4 cells: 2.2 LDS-sized slabs each = 170 items for
+  // 256 CUs, the heavy central ones a third of a scene's votes) is cut finer than the LDS allows, so that the batch still
+  // makes about `target` work items (two per CU): a slab is any run of consecutive flat cells, the arcs adapt to its
+  // x-layers.  Never below VC_MIN_SLAB_CELLS (short arcs waste rotation quanta; every item streams its scene's frame list)
+  // and never into more slabs than the per-scene partial-maximum table holds (s_max).  Batches small enough for the pair-list
+  // split (max_parts > 1) keep LDS-sized slabs: equal parts of a slab balance better than unequal thin slabs (measured,
+  // docs/measurements.md 11.6).
   int mx = 0;
+  unsigned long long sm = 0ull;
   for (int b = threadIdx.x; b < B; b += 1024) {
     const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
-    mx = max(mx, (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS);
+    mx = max(mx, G);
+    sm += (unsigned long long)G;
   }
-  if (mx > 0) atomicMax(&s_maxn, mx);
+  if (mx > 0) { atomicMax(&s_maxg, mx); atomicAdd(&s_sumg, sm); }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t sc = max_parts > 1 ? (int64_t)VC_SLAB_CELLS : ((int64_t)s_sumg + target - 1) / max(target, 1);
+    sc = max(sc, (int64_t)VC_MIN_SLAB_CELLS);
+    sc = max(sc, ((int64_t)s_maxg + s_max - 1) / max(s_max, 1));
+    sc = (sc + 255) / 256 * 256;
+    s_cells = (int)min(sc, (int64_t)VC_SLAB_CELLS);
+  }
+  __syncthreads();
+  const int slab_cells = s_cells;
+  const int s_maxn = (s_maxg + slab_cells - 1) / slab_cells;       // slabs of the largest scene bound the ranks that exist
   const int64_t cand = (int64_t)B * min(s_maxn, s_max);             // (rank, scene slot) candidates, rank-major
   for (int64_t base = 0; base < cand; base += 1024) {
     const int64_t c = base + threadIdx.x;
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid
       const int rank = (int)(c / B), x = (int)(c % B);
       b = (x + rank) % B;
       const int G = ((int64_t)grids[b].ncell <= cells_cap) ? grids[b].ncell : 0;
-      const int nslab = (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+      const int nslab = (G + slab_cells - 1) / slab_cells;
       if (rank < nslab) {
         cnt = 1;
         const int mid = nslab >> 1, dd = (rank + 1) >> 1;
@@ -635,6 +657,7 @@ __global__ __launch_bounds__(1024) void vote_worklist_kernel(const CppfSceneGrid
     int P = 1;
     if (max_parts > 1 && items > 0 && items < target) P = min(max_parts, (target + items - 1) / items);
     ctl[0] = 0; ctl[1] = items * P; ctl[2] = P;               // next work item, work item count, parts per slab
+    ctl[3] = slab_cells;
   }
 }
 
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
   __shared__ int s_item;
   int tag = 0;
   vote_stage_tables(slab, num_rots, cos_tab, sin_tab);
-  const int count = ctl[1], parts = ctl[2];
+  const int count = ctl[1], parts = ctl[2], slab_cells = ctl[3];
   for (;;) {
     __syncthreads();                                   // previous item's epilogue is done with the slab and s_item
     if (threadIdx.x == 0) s_item = atomicAdd(&ctl[0], 1);
@@ -662,7 +685,7 @@ __global__ __launch_bounds__(VC_THREADS, VC_MIN_WAVES) void vote_center_persist_
     const uint32_t e = list[item / parts];                // the parts of a slab are consecutive work items
     const int b = (int)(e & 0xffffu), s = (int)(e >> 16);
     const CppfSceneGrid g = grids[b];
-    vote_slab_item<true, WEIGHTED>(slab, tag, b, s, item % parts, parts, g, g.ncell, fr, total, tup_off, res, num_rots,
+    vote_slab_item<true, WEIGHTED>(slab, tag, b, s, slab_cells, item % parts, parts, g, g.ncell, fr, total, tup_off, res, num_rots,
                                    cos_tab, sin_tab, grid, grid_off, cells_cap, slab_best, s_max, 1, part, tickets);
   }
 }
@@ -720,7 +743,7 @@ __global__ __launch_bounds__(256) void grid_argmax_partial_kernel(const uint32_t
 
 // stage 2: combine partials, unravel, world coordinates (train_dino.py:212-213)
 __global__ __launch_bounds__(64) void grid_argmax_final_kernel(const SlabBest* __restrict__ partial, int s_max,
-                                                               int fixed_parts,
+                                                               int fixed_parts, const int* __restrict__ ctl,
                                                                const CppfSceneGrid* __restrict__ grids,
                                                                int64_t cells_cap, double res,
                                                                int64_t* __restrict__ out_argmax,
@@ -729,7 +752,8 @@ __global__ __launch_bounds__(64) void grid_argmax_final_kernel(const SlabBest* _
   const int b = blockIdx.x;
   const CppfSceneGrid g = grids[b];
   const int G = ((int64_t)g.ncell <= cells_cap) ? g.ncell : 0;
-  const int parts = fixed_parts > 0 ? fixed_parts : (G + VC_SLAB_CELLS - 1) / VC_SLAB_CELLS;
+  const int slab_cells = ctl ? ctl[3] : VC_SLAB_CELLS;        // the persistent kernel's work list chose the slab size
+  const int parts = fixed_parts > 0 ? fixed_parts : (G + slab_cells - 1) / slab_cells;
   uint32_t bv = 0;
   int64_t bi = INT64_MAX;
   for (int i = threadIdx.x; i < parts; i += 64) {
@@ -868,7 +892,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
         hipLaunchKernelGGL(vote_frames_kernel, dim3((max_t + 255) / 256, B), dim3(256), 0, st, pts, pt_off, idx, k,
                            tup_off, tr, vote_wt, res32, num_rots, total_tuples, frames);
         // the work list belongs to the preparation half of the two-call form
-        hipLaunchKernelGGL(vote_worklist_kernel, dim3(1), dim3(1024), 0, st, grids, B, cells_cap, s_max, max_parts,
+        hipLaunchKernelGGL(vote_worklist_kernel, dim3(1), dim3(1024), 0, st, grids, B, cells_cap, s_max_parts, max_parts,
                            2 * num_cus, ws_list, ws_ctl);
         if (max_parts > 1) {
           hipLaunchKernelGGL(grid_zero_kernel, dim3(64, B), dim3(256), 0, st, ws_grid, (const int64_t*)nullptr, cells_cap,
@@ -887,7 +911,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
                            total_tuples, tup_off, res32, num_rots, cos_tab, sin_tab, grids, grid, grid_off, cells_cap, best,
                            s_max_parts, ws_list, ws_ctl, max_parts > 1 ? ws_grid : (uint32_t*)nullptr, ws_tickets);
       CPPF_LAUNCH_CHECK();
-      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap, res,
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, (const int*)ws_ctl, grids, cells_cap, res,
                          out_argmax, out_peak, out_world);
       CPPF_LAUNCH_CHECK();
       return CPPF_OK;
@@ -909,12 +933,12 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
     }
     CPPF_LAUNCH_CHECK();
     if (P == 1) {
-      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, grids, cells_cap,
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, 0, (const int*)nullptr, grids, cells_cap,
                          res, out_argmax, out_peak, out_world);
     } else {
       hipLaunchKernelGGL(grid_argmax_partial_kernel, dim3(VC_ARG_BLOCKS, B), dim3(256), 0, st, g_use, goff_use,
                          cells_cap, grids, best, s_max_parts);
-      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, grids,
+      hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, (const int*)nullptr, grids,
                          cells_cap, res, out_argmax, out_peak, out_world);
     }
     CPPF_LAUNCH_CHECK();
@@ -932,7 +956,7 @@ extern "C" int cppf_vote_center(int B, const float* pts, const int32_t* pt_off, 
     }
     hipLaunchKernelGGL(grid_argmax_partial_kernel, dim3(VC_ARG_BLOCKS, B), dim3(256), 0, st, g_use, goff_use,
                        cells_cap, grids, best, s_max_parts);
-    hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, grids,
+    hipLaunchKernelGGL(grid_argmax_final_kernel, dim3(B), dim3(64), 0, st, best, s_max_parts, VC_ARG_BLOCKS, (const int*)nullptr, grids,
                        cells_cap, res, out_argmax, out_peak, out_world);
     CPPF_LAUNCH_CHECK();
     return CPPF_OK;

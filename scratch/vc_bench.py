@@ -10,7 +10,8 @@ stage = sys.argv[1] if len(sys.argv) > 1 else "vote_center"
 reps = int(os.environ.get("REPS", 10))
 mode = int(os.environ.get("MODE", 0))
 dev = torch.device("cuda")
-scenes = [synth.make_scene(0, b, N) for b in range(B)]
+mk = synth.make_scene_voxel2mm if os.environ.get("CLOUD") == "voxel2mm" else synth.make_scene
+scenes = [mk(0, b, N) for b in range(B)]
 SCALE = float(os.environ.get("SCALE", 1.0))          # object extent x SCALE at the same 2 mm cells (laptop-sized grids: SCALE=2.5)
 pts = torch.from_numpy(np.concatenate([(s["pc"] - s["pc"].mean(0)) * np.float32(SCALE) + s["pc"].mean(0) for s in scenes]).astype(np.float32)).to(dev)
 pipe = VotingPipeline([N] * B, [T] * B, num_rots=R, vote_mode=mode)

@@ -494,3 +494,44 @@ def test_decode_bins_with_masked_logits():
     b = pipe.bins.cpu().numpy()
     assert b.min() >= 10 and b.max() <= 24
     assert bool(torch.isfinite(pipe.tr).all()) and bool(torch.isfinite(pipe.scale).all())
+
+
+@pytest.mark.parametrize("shape", ["voxel_cylinders", "thin_plates"])
+def test_big_batch_of_small_grids_is_cut_into_fine_slabs(shape):
+    """More than 48 scenes whose grids are far smaller than the LDS slab (objects of ~8e4 cells): vote_worklist_kernel cuts them
+    into slabs finer than the LDS allows so that the batch still fills the chip.  The grids must stay what the one-atomic-per-vote
+    kernel (mode 2: exact divisions, every rotation tested) counts, cell for cell, and the first maxima with them.  `thin_plates`:
+    gy * gz exceeds the slab, so x-layer 0 -- never a valid cell, train_dino.py:199 -- spans several slabs."""
+    B, N, T, R = 56, 1024, 2000, 36
+    rng = np.random.default_rng(11)
+    if shape == "voxel_cylinders":
+        pcs = [synth.make_scene_voxel2mm(7, b, N)["pc"] for b in range(B)]
+    else:
+        pcs = [(rng.random((N, 3)) * np.array([0.008, 0.4, 0.4]) + np.array([0.1 * b, 0.0, 0.8])).astype(np.float32) for b in range(B)]
+    pts = torch.as_tensor(np.concatenate(pcs)).to(DEV)
+    idx = torch.as_tensor(np.concatenate([synth.host_sample_tuples(7, b, T, 5, N) for b in range(B)])).to(DEV, torch.int32)
+    ext = 0.05 if shape == "voxel_cylinders" else 0.2
+    tr = np.stack([(rng.random(B * T) - 0.5) * ext, rng.random(B * T) * ext], -1).astype(np.float32)
+    out = {}
+    for mode in (1, 2):
+        pipe = VotingPipeline([N] * B, [T] * B, num_rots=R, vote_mode=mode)
+        pipe.tr.copy_(torch.as_tensor(tr))
+        pipe.vote_center(pts, idx, phase=1) if mode == 1 else None           # scene bounds -> grid sizes
+        if mode == 2:
+            from cppf2_amd import _lib
+            import ctypes as C
+            _lib.check(_lib.load().cppf_scene_bounds(B, ops._p(pts), ops._p(pipe.pt_off), C.c_float(pipe.res), ops._p(pipe.grids),
+                                                     ops._stream()), "bounds")
+        cells = np.array([g.ncell for g in ops.grids_to_host(pipe.grids)], np.int64)
+        off = torch.as_tensor(np.concatenate([[0], np.cumsum(cells)])).to(DEV)
+        grid = torch.full((int(cells.sum()),), -1, dtype=torch.int32, device=DEV)
+        pipe.vote_center(pts, idx, grid=grid, grid_off=off)
+        out[mode] = (grid.cpu().numpy(), pipe.argmax.cpu().numpy().copy(), pipe.peak.cpu().numpy().copy(), cells)
+    cells = out[1][3]
+    assert cells.max() * B < 36864 * 512                       # the batch is in the fine-slab regime (two items per CU wanted)
+    if shape == "thin_plates":
+        g = ops.grids_to_host(pipe.grids)[0]
+        assert g.g[1] * g.g[2] > cells.sum() / 512             # one x-layer is wider than a slab
+    assert out[1][0].min() >= 0 and out[1][0].sum() > (0.2 * B * T * R if shape == "voxel_cylinders" else 1e5)
+    assert np.array_equal(out[1][0], out[2][0])
+    assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
