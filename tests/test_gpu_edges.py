@@ -496,42 +496,74 @@ def test_decode_bins_with_masked_logits():
     assert bool(torch.isfinite(pipe.tr).all()) and bool(torch.isfinite(pipe.scale).all())
 
 
+def _vote_grids_both_kernels(pcs, Ts, R, res, tr, seed):
+    """The batch's vote grids, first maxima and peaks from the LDS-slab kernel (mode 1) and from the one-atomic-per-vote kernel
+    (mode 2: exact divisions, every rotation tested) on the same pairs and vote parameters."""
+    from cppf2_amd import _lib
+    import ctypes as C
+    B, Ns = len(pcs), [len(p) for p in pcs]
+    pts = torch.as_tensor(np.concatenate(pcs)).to(DEV)
+    idx = torch.as_tensor(np.concatenate([synth.host_sample_tuples(seed, b, Ts[b], 5, Ns[b]) for b in range(B)])).to(DEV, torch.int32)
+    out = {}
+    for mode in (1, 2):
+        pipe = VotingPipeline(Ns, Ts, num_rots=R, res=res, vote_mode=mode)
+        pipe.tr.copy_(torch.as_tensor(tr))
+        _lib.check(_lib.load().cppf_scene_bounds(B, ops._p(pts), ops._p(pipe.pt_off), C.c_float(pipe.res), ops._p(pipe.grids),
+                                                 ops._stream()), "bounds")
+        hg = ops.grids_to_host(pipe.grids)
+        cells = np.array([g.ncell for g in hg], np.int64)
+        off = torch.as_tensor(np.concatenate([[0], np.cumsum(cells)])).to(DEV)
+        grid = torch.full((int(cells.sum()),), -1, dtype=torch.int32, device=DEV)
+        pipe.vote_center(pts, idx, grid=grid, grid_off=off)
+        out[mode] = (grid.cpu().numpy(), pipe.argmax.cpu().numpy().copy(), pipe.peak.cpu().numpy().copy(), cells,
+                     [tuple(g.g) for g in hg])
+    return out
+
+
 @pytest.mark.parametrize("shape", ["voxel_cylinders", "thin_plates"])
 def test_big_batch_of_small_grids_is_cut_into_fine_slabs(shape):
     """More than 48 scenes whose grids are far smaller than the LDS slab (objects of ~8e4 cells): vote_worklist_kernel cuts them
     into slabs finer than the LDS allows so that the batch still fills the chip.  The grids must stay what the one-atomic-per-vote
-    kernel (mode 2: exact divisions, every rotation tested) counts, cell for cell, and the first maxima with them.  `thin_plates`:
-    gy * gz exceeds the slab, so x-layer 0 -- never a valid cell, train_dino.py:199 -- spans several slabs."""
+    kernel counts, cell for cell, and the first maxima with them.  `thin_plates`: gy * gz exceeds the slab, so x-layer 0 -- never
+    a valid cell, train_dino.py:199 -- spans several slabs."""
     B, N, T, R = 56, 1024, 2000, 36
     rng = np.random.default_rng(11)
     if shape == "voxel_cylinders":
         pcs = [synth.make_scene_voxel2mm(7, b, N)["pc"] for b in range(B)]
     else:
         pcs = [(rng.random((N, 3)) * np.array([0.008, 0.4, 0.4]) + np.array([0.1 * b, 0.0, 0.8])).astype(np.float32) for b in range(B)]
-    pts = torch.as_tensor(np.concatenate(pcs)).to(DEV)
-    idx = torch.as_tensor(np.concatenate([synth.host_sample_tuples(7, b, T, 5, N) for b in range(B)])).to(DEV, torch.int32)
     ext = 0.05 if shape == "voxel_cylinders" else 0.2
     tr = np.stack([(rng.random(B * T) - 0.5) * ext, rng.random(B * T) * ext], -1).astype(np.float32)
-    out = {}
-    for mode in (1, 2):
-        pipe = VotingPipeline([N] * B, [T] * B, num_rots=R, vote_mode=mode)
-        pipe.tr.copy_(torch.as_tensor(tr))
-        pipe.vote_center(pts, idx, phase=1) if mode == 1 else None           # scene bounds -> grid sizes
-        if mode == 2:
-            from cppf2_amd import _lib
-            import ctypes as C
-            _lib.check(_lib.load().cppf_scene_bounds(B, ops._p(pts), ops._p(pipe.pt_off), C.c_float(pipe.res), ops._p(pipe.grids),
-                                                     ops._stream()), "bounds")
-        cells = np.array([g.ncell for g in ops.grids_to_host(pipe.grids)], np.int64)
-        off = torch.as_tensor(np.concatenate([[0], np.cumsum(cells)])).to(DEV)
-        grid = torch.full((int(cells.sum()),), -1, dtype=torch.int32, device=DEV)
-        pipe.vote_center(pts, idx, grid=grid, grid_off=off)
-        out[mode] = (grid.cpu().numpy(), pipe.argmax.cpu().numpy().copy(), pipe.peak.cpu().numpy().copy(), cells)
+    out = _vote_grids_both_kernels(pcs, [T] * B, R, 2e-3, tr, 7)
     cells = out[1][3]
     assert cells.max() * B < 36864 * 512                       # the batch is in the fine-slab regime (two items per CU wanted)
     if shape == "thin_plates":
-        g = ops.grids_to_host(pipe.grids)[0]
-        assert g.g[1] * g.g[2] > cells.sum() / 512             # one x-layer is wider than a slab
+        g = out[1][4][0]
+        assert g[1] * g[2] > cells.sum() / 512                 # one x-layer is wider than a slab
     assert out[1][0].min() >= 0 and out[1][0].sum() > (0.2 * B * T * R if shape == "voxel_cylinders" else 1e5)
     assert np.array_equal(out[1][0], out[2][0])
     assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
+
+
+@pytest.mark.parametrize("cfg_seed", list(range(6)))
+def test_vote_center_slab_cut_random_batches(cfg_seed):
+    """Batches drawn from a seed on both sides of the pair-split limit (40 .. 96 scenes): ragged point / pair counts, boxes from
+    needles to plates and cubes (grids of 1e2 .. 2e6 cells, so the device-chosen slab ranges from its floor to the LDS capacity), cell sizes,
+    rotation counts that are not multiples of the vote quantum.  Slab kernel == one-atomic-per-vote kernel, cell for cell."""
+    rng = np.random.default_rng(500 + cfg_seed)
+    B = int(rng.integers(40, 97))
+    res = float(rng.choice([1.5e-3, 2e-3, 3e-3, 5e-3]))
+    R = int(rng.choice([8, 13, 36, 59, 120]))
+    big = res * float(rng.choice([25, 50, 80]))         # (the longest box edge is 1.5 x this: grids stay below the 2^21-cell cap)
+    pcs, Ts = [], []
+    for b in range(B):
+        n = int(rng.integers(60, 900))
+        box = rng.choice([0.004, 0.02, big], size=3) * (0.5 + rng.random(3))
+        pcs.append((rng.random((n, 3)) * box + np.array([0.0, 0.0, 0.6])).astype(np.float32))
+        Ts.append(int(rng.integers(100, 1500)))
+    tot = sum(Ts)
+    tr = np.stack([(rng.random(tot) - 0.5) * big, rng.random(tot) * big], -1).astype(np.float32)
+    out = _vote_grids_both_kernels(pcs, Ts, R, res, tr, 900 + cfg_seed)
+    assert out[1][3].max() <= 1 << 21 and out[1][0].min() >= 0 and out[1][0].sum() > 0
+    assert np.array_equal(out[1][0], out[2][0]), cfg_seed
+    assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2]), cfg_seed
