@@ -203,11 +203,13 @@ def run_other_workload(args, rank, world, dev, backend, timer):
         ref_sel = step.pipe.selected.clone()
         ref_slots = step.pipe.result_slots.clone()
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # (no cppf_mlp_reserve_cus here: both passes are dominated by their own wide MLP launches, which cannot share the chip --
+        # measured 2 830 -> 2 730 instances/s with 32 CUs reserved, docs/measurements.md 11.7)
         for _ in range(max(2, args.warmup)):
             step.run_two_streams(streams)
         dt, mine, _ = timer.loop(args.steps, lambda i: step.run_two_streams(streams))
         same = bool(torch.equal(step.pipe.selected, ref_sel) and torch.equal(step.pipe.result_slots, ref_slots))
-        step.two = {"streams": 2, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
+        step.two = {"streams": 2, "mlp_reserved_cus": 0, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
                     "ms_per_step_single_stream": 1e3 * dt1 / args.steps,
                     "note": "the DINO pass and the SHOT pass (descriptors included) on two HIP streams, twin pipelines, one event "
                             "for the DINO scale; per-stage times come from the single-stream loop of the same run"}
@@ -364,6 +366,12 @@ def main():
             s_.run()
             torch.cuda.synchronize()
             refs.append(s_.pipe.results.clone())
+        # batch mode: the persistent MLP launches leave one CU per shader engine to the other stream's kernels
+        # (cppf_mlp_reserve_cus; a queue's workgroups are placed round-robin over the shader engines, so ONE full engine stalls
+        # the other stream's whole launch: 31 reserved CUs change nothing, 32 give + 3.5 %, docs/measurements.md 11.7)
+        if args.mlp_reserve_cus is None:
+            args.mlp_reserve_cus = step.ops.batch_mode_reserved_cus(dev)
+        step.ops.mlp_reserve_cus(args.mlp_reserve_cus)
         for s_, st_ in zip(*pair):
             st_.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st_):
@@ -371,12 +379,13 @@ def main():
                     s_.run()
         torch.cuda.synchronize()
         dt, mine, evs, ends = timed_loop(args.steps, pair=pair)
+        step.ops.mlp_reserve_cus(0)
         intervals = completion_intervals(ends, group=len(streams))
         same = bool(all(torch.equal(s_.pipe.results, r_) for s_, r_ in zip(pair[0], refs)))
         distinct = bool(all(not torch.equal(refs[0], r_) for r_ in refs[1:]))
         dt_single, _, evs_single, ends_single = timed_loop(args.steps)
         intervals_single = completion_intervals(ends_single)
-        two = {"streams": ns, "records_identical_to_single_stream": same, "pipelines_hold_different_scenes": distinct,
+        two = {"streams": ns, "mlp_reserved_cus": args.mlp_reserve_cus, "records_identical_to_single_stream": same, "pipelines_hold_different_scenes": distinct,
                "note": "steps alternate between two HIP streams with double-buffered state; the pipelines hold different scene batches, and "
                        "each one's records are compared byte for byte with what the same pipeline produced alone on one stream in this "
                        "run; per-stage times of the headline are measured on the stage's own stream while the other stream's kernels "

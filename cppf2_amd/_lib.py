@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libcppf_hip.so")
 if os.environ.get("CPPF_LIB"):           # a differently built library (probe builds under scratch/); same ABI version required
     LIB_PATH = os.path.abspath(os.environ["CPPF_LIB"])
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class CppfError(RuntimeError):
@@ -87,6 +87,7 @@ SIGNATURES = {
                             _p, _p, _p, _p, _i64, _p]),
     "cppf_kept_rows": (_i, [_i, _p, _p, _p, _i, _p, _p]),
     "cppf_reslayer_split_debug_grid": (_i, [_i32]),
+    "cppf_mlp_reserve_cus": (_i, [_i32]),
     "cppf_reslayer_split16_stream_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cppf_reslayer_split16": (_i, [_p]),
     "cppf_kept_rows32": (_i, [_i, _p, _p, _p, _i, _p, _p]),

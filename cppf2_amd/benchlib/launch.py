@@ -47,6 +47,9 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--vote-mode", type=int, default=0)
+    ap.add_argument("--mlp-reserve-cus", type=int, default=None,
+                    help="CUs the persistent tuple-MLP launches leave to the other stream in the two-stream loop "
+                         "(default: one per shader engine = CUs / 8; 0 = none)")
     ap.add_argument("--eager-scale-head", action="store_true",
                     help="run the scale head on every tuple like the reference's forward (default: only on the pairs "
                          "that survive the back-vote filter, the only rows eval.py:272 ever reads)")

@@ -1249,6 +1249,14 @@ extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
   return CPPF_OK;
 }
 
+// Batch-mode knob (include/cppf_hip.h): CUs every persistent launch leaves to the kernels of other streams
+static std::atomic<int> g_rs_reserved_cus{0};
+extern "C" int cppf_mlp_reserve_cus(int32_t cus) {
+  CPPF_CHECK_ARG(cus >= 0 && cus <= 1024);
+  g_rs_reserved_cus.store(cus);
+  return CPPF_OK;
+}
+
 template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false, int PC = 3, int MODE = RS_RESLAYER>
 static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t ldo, int64_t rows, const char* wq,
                      const float* b1, const float* b0, int chain, int cus, hipStream_t stream, RsGather ga = RsGather(),
@@ -1257,6 +1265,7 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
   const int64_t nblocks = (rows + BLOCK_ROWS - 1) / BLOCK_ROWS;
   const int forced = g_rs_debug_cus.load();
   if (forced > 0) cus = forced;
+  else cus = cus - g_rs_reserved_cus.load() > cus / 2 ? cus - g_rs_reserved_cus.load() : (cus + 1) / 2;   // never below half the chip
   cus *= rs_wgs_per_cu(MODE);
   const unsigned grid = (unsigned)(nblocks < cus ? nblocks : cus);
   // RS_LINEAR: `chain` = column groups of 32 NT outputs; with fewer row blocks than CUs the groups are spread over blockIdx.y

@@ -478,6 +478,38 @@ class TupleSource:
         return encode_tuples_shot_heads(self.pts, self.idx, self.nrm, self.pt_off, self.tup_off)
 
 
+CUS_PER_SHADER_ENGINE = 8         # gfx950: 8 XCDs x 4 shader engines x 8 CUs
+
+
+def batch_mode_reserved_cus(dev=None):
+    """What the two-stream batch mode leaves to the other stream: one CU per shader engine (32 on an MI355X).  A queue's
+    workgroups go round-robin over the shader engines, so a single engine without a free CU stalls the other stream's launch
+    until the persistent MLP launch ends (docs/measurements.md 11.7)."""
+    return torch.cuda.get_device_properties(dev if dev is not None else _dev()).multi_processor_count // CUS_PER_SHADER_ENGINE
+
+
+def mlp_reserve_cus(cus):
+    """cppf_mlp_reserve_cus: every later cppf_reslayer_split* launch of this process leaves `cus` CUs to the kernels of other
+    streams (0 = one persistent workgroup per CU).  Results do not depend on it."""
+    _lib.check(_L.cppf_mlp_reserve_cus(int(cus)), "cppf_mlp_reserve_cus")
+
+
+class mlp_cus_reserved:
+    """`with ops.mlp_cus_reserved():` -- the batch mode's setting for the launches enqueued inside the block (two streams working
+    on different batches: one batch's voting / descriptor kernels run on the reserved CUs beside the other's matrix-core kernels)."""
+
+    def __init__(self, cus=None):
+        self.cus = batch_mode_reserved_cus() if cus is None else int(cus)
+
+    def __enter__(self):
+        mlp_reserve_cus(self.cus)
+        return self
+
+    def __exit__(self, *exc):
+        mlp_reserve_cus(0)
+        return False
+
+
 def reslayer_split_encode_supported(k, n_out):
     return int(k) == 5 and int(n_out) == 128
 

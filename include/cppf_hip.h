@@ -38,7 +38,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 9
+#define CPPF_ABI_VERSION 10
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -486,6 +486,16 @@ typedef struct CppfReslayerSplit16Args {
 } CppfReslayerSplit16Args;
 int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);
+
+/* Batch mode (two HIP streams working on different batches): the cppf_reslayer_split* launches are
+ * persistent -- one workgroup per CU holding the CU's whole register file -- so while one runs, no kernel of another stream
+ * can start anywhere on the chip.  cppf_mlp_reserve_cus(n) makes every later launch of this process use n fewer CUs (never
+ * fewer than half of them); the kernels are power-limited, so 32 fewer CUs cost them ~4 % while the other stream's voting /
+ * descriptor kernels run beside them.  Use one CU per shader engine (CUs / 8 = 32 on an MI355X): workgroups are placed
+ * round-robin over the engines, and one engine without a free CU stalls the other stream's launch (docs/measurements.md 11.7).  0 (default) = one workgroup per CU.  Results never
+ * depend on it.  With the per-device cache of line 18 this is the library's only process-wide state; it is an atomic
+ * integer, safe to set from any thread, and applies to launches enqueued afterwards. */
+int cppf_mlp_reserve_cus(int32_t cus);
 
 /* Test hook: workgroups > 0 forces the number of persistent workgroups of every later cppf_reslayer_split* launch of this
  * process (the kernels' results do not depend on it; tests/test_mlp_split.py runs the counted-wait protocol at 1, 7 and all

@@ -304,5 +304,6 @@ def test_bench_command_line_defaults():
     a = launch.parse([])
     assert (a.gpus, a.steps, a.warmup, a.scenes_per_gpu, a.points, a.tuples, a.rots) == (1, 100, 3, 64, 4096, 20000, 180)
     assert a.workload == "shot" and a.cloud == "synthetic" and not a.no_voxel_density and not a.separate_encode and not a.single_stream
+    assert a.mlp_reserve_cus is None and launch.parse(["--mlp-reserve-cus", "0"]).mlp_reserve_cus == 0   # None: one per shader engine
     b = launch.parse(["--gpus", "8", "--cloud", "voxel2mm", "--separate-encode", "--no-voxel-density", "--workload", "ensemble"])
     assert b.gpus == 8 and b.cloud == "voxel2mm" and b.separate_encode and b.no_voxel_density and b.workload == "ensemble"

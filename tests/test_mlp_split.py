@@ -460,6 +460,36 @@ def test_counted_wait_protocol_race_screen():
 
 
 @pytest.mark.gpu
+def test_reserved_cus_change_the_grid_not_the_results():
+    """cppf_mlp_reserve_cus (the batch mode's knob): launches that leave CUs to other streams -- 1, one per shader engine, half
+    the chip, more than the library accepts to give away -- return the bits of the default launch; the context manager restores
+    one workgroup per CU; a negative count is refused."""
+    from cppf2_amd import _lib, models, ops
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    n, k, rows = 128, 360, 70001
+    rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(2)]
+    wq = models.pack_split(mk(n, k) / k ** 0.5, mk(n, k) / k ** 0.5, mk(n, n) / n ** 0.5, k, chain=rest)
+    b1, b0 = mk(3 * n) * 0.1, mk(n) * 0.1
+    x = mk(rows, k)
+    ref = ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=2)
+    assert ops.batch_mode_reserved_cus(dev) == torch.cuda.get_device_properties(dev).multi_processor_count // 8
+    try:
+        for cus in (1, ops.batch_mode_reserved_cus(dev), 128, 1000):
+            ops.mlp_reserve_cus(cus)
+            assert torch.equal(ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=2), ref), cus
+        with ops.mlp_cus_reserved():
+            assert torch.equal(ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=2), ref)
+        assert L.cppf_mlp_reserve_cus(-1) != 0
+        with pytest.raises(_lib.CppfError):
+            ops.mlp_reserve_cus(-3)
+    finally:
+        ops.mlp_reserve_cus(0)
+
+
+@pytest.mark.gpu
 def test_tapped_first_layer_equals_the_separate_launches():
     """cppf_reslayer_split_tap: the first layer's output (the tuple features) is bit-identical to what that layer's own launch
     writes; the chain's output equals the separate launches' (128 -> 256 projection, then two 256-wide identity layers) up to

@@ -77,11 +77,18 @@ def test_two_streams_give_the_single_stream_records():
         want.append(s.pipe.results.clone())
     assert not torch.equal(want[0], want[1]) and steps[1].scene0 == 16
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    for trial in range(3):
-        for i in range(6):
-            with torch.cuda.stream(streams[i & 1]):
-                steps[i & 1].run()
-        torch.cuda.synchronize()
+    from cppf2_amd import ops
+    for trial in range(4):
+        # (trials 2, 3: the bench's batch-mode setting -- the persistent MLP launches leave one CU per shader engine to the
+        # other stream, cppf_mlp_reserve_cus -- so the two pipelines' kernels really run side by side)
+        ops.mlp_reserve_cus(ops.batch_mode_reserved_cus(dev) if trial >= 2 else 0)
+        try:
+            for i in range(6):
+                with torch.cuda.stream(streams[i & 1]):
+                    steps[i & 1].run()
+            torch.cuda.synchronize()
+        finally:
+            ops.mlp_reserve_cus(0)
         for s, w in zip(steps, want):
             assert torch.equal(s.pipe.results, w), trial
 
@@ -217,6 +224,10 @@ def test_bench_gathers_through_rccl_in_a_one_rank_group():
     assert c["backend"] == "nccl" and c["op"] == "all_gather_into_tensor" and c["world"] == 1
     assert c["records_gathered"] == 4 and c["gather_us"] > 0
     assert j["n_gpus"] == 1 and j["records_gathered"] == 4 and j["pose_5deg5cm_vs_gt"] == 1.0
+    # the headline loop of that run was the two-stream batch mode with one CU per shader engine left to the other stream
+    two = j["two_streams"]
+    assert two["streams"] == 2 and two["records_identical_to_single_stream"] and two["pipelines_hold_different_scenes"]
+    assert two["mlp_reserved_cus"] == torch.cuda.get_device_properties(0).multi_processor_count // 8
 
 
 def test_bench_refuses_more_ranks_than_gpus():
