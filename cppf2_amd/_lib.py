@@ -39,7 +39,7 @@ class ReslayerSplit16Args(C.Structure):
                 ("first_out", C.c_void_p), ("ld_first", C.c_int64),
                 ("gidx", C.c_void_p), ("slots", C.c_int32), ("table", C.c_void_p), ("fdim", C.c_int32),
                 ("logit_prior", C.c_void_p), ("uniforms", C.c_void_p), ("bins", C.c_void_p),
-                ("stream", C.c_void_p), ("mode", C.c_int32), ("ld_table", C.c_int64)]
+                ("stream", C.c_void_p), ("mode", C.c_int32), ("ld_table", C.c_int64), ("sched", C.c_void_p)]
 
 
 assert C.sizeof(SceneGrid) == 32
@@ -104,18 +104,18 @@ SIGNATURES = {
     "cppf_voxel_downsample": (_i, [_p, _i, _f, _u64, _p, _p, _p, _i64, _p]),
     "cppf_reslayer128": (_i, [_p, _i64, _p, _p, _p, _p]),
     "cppf_reslayer_split_stream_bytes": (_i64, [_i, _i, _i, _i]),
-    "cppf_reslayer_split": (_i, [_p, _i64, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
-    "cppf_reslayer_split_tap": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
-    "cppf_reslayer_split_decode": (_i, [_p, _i64, _i, _i64, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "cppf_reslayer_split": (_i, [_p, _i64, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
+    "cppf_reslayer_split_tap": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
+    "cppf_reslayer_split_decode": (_i, [_p, _i64, _i, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "cppf_decode_from_bins": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_encode_tuples_shot_heads": (_i, [_i, _p, _p, _p, _i, _p, _p, _i64, _p, _i, _p, _p]),
-    "cppf_reslayer_split_gather": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
-    "cppf_reslayer_split_sumencode": (_i, [_i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
-    "cppf_reslayer_split_encode": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p]),
+    "cppf_reslayer_split_gather": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
+    "cppf_reslayer_split_sumencode": (_i, [_i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
+    "cppf_reslayer_split_encode": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
     "cppf_linear_split_stream_bytes": (_i64, [_i32, _i32]),
     "cppf_linear_split": (_i, [_p, _i64, _i32, _p, _i64, _i32, _i64, _p, _i64, _p, _p]),
     "cppf_encode_tuples_coord_heads": (_i, [_i, _p, _p, _i, _p, _p, _i64, _p, _i32, _p, _p]),
-    "cppf_reslayer_split_sumgather": (_i, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i32, _i64, _p, _i64, _p, _p, _i32, _p]),
+    "cppf_reslayer_split_sumgather": (_i, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i32, _i64, _p, _i64, _p, _p, _i32, _p, _p]),
     "cppf_alignment_loss": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "cppf_ensemble_select": (_i, [_i, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "cppf_assemble_pose": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -804,6 +804,8 @@ struct RsGather {               // GATHER launches: see RsX; RS_SUMGATHER: the p
   const int32_t* pt_off = nullptr;
   const int32_t* tup_off = nullptr;
   int B = 0;
+  // dynamic row-block scheduling (nullptr: static partition): int32[2] = {claims, finished workgroups}, zero on entry and on exit
+  int* sched = nullptr;
 };
 
 struct RsRow3 {                  // a 12-byte row of a [points, 3] array (4-byte aligned): one load instruction
@@ -934,7 +936,16 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     bend = nblocks * (xcd + 1) / 8;
     bstride = gridDim.x >> 3;
   }
-  const int64_t mine = bend > bfirst ? (bend - bfirst + bstride - 1) / bstride : 0;
+  // Dynamic scheduling (ga.sched): workgroup w starts with row block w and claims every further one from a counter, one block
+  // ahead (the claim issued at the top of block i is published through LDS in the middle of it and names the block after next), so
+  // that workgroups that start late -- or share the chip with another stream's launch -- take fewer blocks instead of finishing last.
+  int* const sched = ga.sched;
+  const bool dyn = sched != nullptr && !LIN;
+  // (the claim slots: 16 bytes of the dynamic LDS behind the biases -- a static array would not fit beside 160 KiB of dynamic LDS)
+  int* const s_claim = reinterpret_cast<int*>(s_ring + 2 * rs_stage_bytes(rs_stage_tiles(MODE)) + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4);
+  if (dyn) { bfirst = blockIdx.x; bstride = 0; bend = nblocks; }
+  const int64_t mine = dyn ? (bfirst < bend ? 1 : 0) : (bend > bfirst ? (bend - bfirst + bstride - 1) / bstride : 0);
+  if (dyn && threadIdx.x == 0) s_claim[0] = (int)gridDim.x + atomicAdd(&sched[0], 1);
 
   constexpr int STG = rs_stage_tiles(MODE), RING_BYTES = 2 * rs_stage_bytes(STG);
   RsStream<NT, T0, WAVES, PC, LIN, STG> ws;
@@ -1008,6 +1019,8 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     }
     return rw;
   };
+  int64_t next_blk = dyn ? (int64_t)s_claim[0] : bfirst + bstride;      // (after the barrier above)
+  int par = 1;
   RsRow cur = row_of(bfirst < bend ? bfirst : 0);
   auto first_tiles = [&](const RsRow rw) {        // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
     if constexpr (MODE == RS_ENCODE) {
@@ -1065,12 +1078,16 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   RsDraw draw;
   pend.row = -1;
   pend.in = false;
-  for (int64_t blk = bfirst; blk < bend; blk += bstride) {
+  for (int64_t blk = bfirst; blk < bend;) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
     const float* xrow = cur.xrow;
-    const bool more = blk + bstride < bend;
-    const RsRow nxt = row_of(more ? blk + bstride : blk);         // (GATHER: its index loads are used after the first product)
+    const int64_t nb = dyn ? next_blk : blk + bstride;
+    const bool more = nb < bend;
+    if (dyn && more) ws.left += ws.chunks;                          // the stream runs on into the next block's weights
+    const RsRow nxt = row_of(more ? nb : blk);                    // (GATHER: its index loads are used after the first product)
+    int claim = 0;
+    if (dyn && threadIdx.x == 0) claim = atomicAdd(&sched[0], 1);   // the block after next; published after the first product
     // ---- h^T = relu(W1 x^T + b1)  [and skip^T = W0 x^T + b0 of a projection layer] ----------------------------
     f32x16 acc[2 * NT];                         // h tiles, then the output tiles
     f32x16 (&h)[NT] = *reinterpret_cast<f32x16 (*)[NT]>(&acc[0]);
@@ -1160,6 +1177,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
         for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
       }
     }
+    if (dyn && threadIdx.x == 0) s_claim[par] = (int)gridDim.x + claim;   // (read at the loop's end: barriers of the products between)
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
     if (more) first_tiles(nxt);
     cur = nxt;
@@ -1214,6 +1232,11 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
         }
       }
     }
+    blk = nb;
+    if (dyn) {
+      next_blk = s_claim[par];
+      par ^= 1;
+    }
   }
   if constexpr (DECODE && NT == 6 && RS_DEFER_DRAW) {
     if (pend.row >= 0) {                          // the last row block's draw: nothing left to hide it behind
@@ -1230,6 +1253,12 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   // workgroup starting on the CU while the last wavefronts of a 512-register MLP workgroup were leaving had the first KiB of
   // its LDS -- sphere bins 0..62 -- overwritten by weight bytes, scratch/rot_race_probe3.py).
   RS_WAIT(0, 15);
+  if (dyn && threadIdx.x == 0) {                  // the last workgroup out leaves the counters zeroed for the next launch
+    if (atomicAdd(&sched[1], 1) == (int)gridDim.x - 1) {
+      __hip_atomic_store(&sched[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sched[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 static int64_t rs_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain, int pc) {
@@ -1275,7 +1304,7 @@ static int rs_launch(const float* x, int64_t ldx, int k_in, float* out, int64_t 
       if (chain % d == 0 && (int64_t)grid * d <= cus) { gy = (unsigned)d; break; }
     chain /= (int)gy;
   }
-  const int lds_bytes = 2 * rs_stage_bytes(rs_stage_tiles(MODE)) + WAVES * 3 * 2048 + (MODE == RS_LINEAR ? chain : 2 + chain) * 32 * NT * 4;
+  const int lds_bytes = 2 * rs_stage_bytes(rs_stage_tiles(MODE)) + WAVES * 3 * 2048 + (MODE == RS_LINEAR ? chain : 2 + chain) * 32 * NT * 4 + 16;
   if (lds_bytes > 160 * 1024 / rs_wgs_per_cu(MODE)) {
     snprintf(g_cppf_err, sizeof(g_cppf_err), "reslayer_split: %d bytes of LDS for the biases of this launch (too many column groups)", lds_bytes);
     return CPPF_EINVAL;
@@ -1314,7 +1343,7 @@ static int rs_cus() {
 // L_1, ...  The second-layer biases are the caller's (carried as a pending offset by cppf2_amd.models.fused_stack).
 static int rs_dispatch(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                        const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, RsTap tap,
-                       void* stream, const char* fn) {
+                       int32_t* sched, void* stream, const char* fn) {
   if (!(x && out && wq && b1 && rows >= 0) || !(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out) ||
       !(n_out == 64 || n_out == 128 || n_out == 192 || n_out == 256) || !(b0 != nullptr || k_in == n_out) ||
       !(chain >= 0 && chain <= 15) || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)wq | (uintptr_t)tap.out) & 15) != 0 ||
@@ -1341,7 +1370,8 @@ static int rs_dispatch(const float* x, int64_t ldx, int32_t k_in, float* out, in
   const char* w = static_cast<const char*>(wq);
   hipStream_t st = (hipStream_t)stream;
   const bool proj = b0 != nullptr;
-  const RsGather ga = RsGather();
+  RsGather ga;
+  ga.sched = sched;
   const RsDecode dc = RsDecode();
   switch (n_out / 32) {
     case 2: return proj ? rs_launch<2, true>(x, ldx, k_in, out, ldo, rows, w, b1, b0, chain, n_cu, st, ga, dc, tap)
@@ -1357,8 +1387,8 @@ static int rs_dispatch(const float* x, int64_t ldx, int32_t k_in, float* out, in
 
 extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out,
                                    int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
-                                   int32_t chain, void* stream) {
-  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, RsTap(), stream, __func__);
+                                   int32_t chain, int32_t* sched, void* stream) {
+  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, RsTap(), sched, stream, __func__);
 }
 
 // cppf_reslayer_split with a second output: first_out [rows, >= n_out] (row stride ld_first) receives the activation after the
@@ -1367,7 +1397,7 @@ extern "C" int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, fl
 // registers: the chain's input is never re-read.  first_out may not alias x or out.
 extern "C" int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in, float* first_out, int64_t ld_first, float* out,
                                        int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes,
-                                       const float* b1, const float* b0, int32_t chain, void* stream) {
+                                       const float* b1, const float* b0, int32_t chain, int32_t* sched, void* stream) {
   if (!first_out || first_out == out || first_out == x) {
     snprintf(g_cppf_err, sizeof(g_cppf_err), "%s: first_out must be a buffer of its own", __func__);
     return CPPF_EINVAL;
@@ -1375,7 +1405,7 @@ extern "C" int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in
   RsTap tap;
   tap.out = first_out;
   tap.ld = ld_first;
-  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, tap, stream, __func__);
+  return rs_dispatch(x, ldx, k_in, out, ldo, n_out, rows, wq, wq_bytes, b1, b0, chain, tap, sched, stream, __func__);
 }
 
 // The first ResLayer of the SHOT model's tuple encoder fed by the tuple encode itself (train_shot.py:75-83 never materialised):
@@ -1388,7 +1418,7 @@ extern "C" int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in
 extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx,
                                           int32_t slots, const float* table, int32_t fdim, float* out, int64_t ldo,
                                           int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
-                                          const float* b0, int32_t chain, void* stream) {
+                                          const float* b0, int32_t chain, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(heads && gidx && table && out && wq && b1 && b0 && rows >= 0);
   CPPF_CHECK_ARG(head_cols >= 0 && (head_cols & 7) == 0 && ld_heads >= head_cols && (ld_heads & 3) == 0);
   CPPF_CHECK_ARG(slots >= 1 && slots <= 8 && fdim >= 8 && (fdim & (fdim - 1)) == 0);
@@ -1411,6 +1441,7 @@ extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, 
   ga.slots = slots;
   ga.head = head_cols;
   ga.fshift = __builtin_ctz((unsigned)fdim);
+  ga.sched = sched;
   return rs_launch<4, true, true>(heads, ld_heads, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
                                   n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga);
 }
@@ -1422,7 +1453,7 @@ extern "C" int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, 
 extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, const int32_t* idx, int32_t k,
                                           const int32_t* pt_off, const int32_t* tup_off, const float* table, int32_t fdim,
                                           float* out, int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes,
-                                          const float* b1, const float* b0, int32_t chain, void* stream) {
+                                          const float* b1, const float* b0, int32_t chain, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && normals && idx && pt_off && tup_off && table && out && wq && b1 && b0 && rows >= 0);
   CPPF_CHECK_ARG(fdim >= 8 && (fdim & (fdim - 1)) == 0 && (ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
   CPPF_CHECK_ARG((((uintptr_t)table | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
@@ -1445,6 +1476,7 @@ extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* 
   ga.pt_off = pt_off;
   ga.tup_off = tup_off;
   ga.B = B;
+  ga.sched = sched;
   return rs_launch<4, true, true, false, 3, RS_ENCODE>(nullptr, 0, k_in, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
                                                        rs_cus(), (hipStream_t)stream, ga);
 }
@@ -1456,7 +1488,7 @@ extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* 
 // logit_prior float32 [rows, 192] or NULL, uniforms float32 [rows, 6], bins int32 [rows, 6].
 extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
                                           const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
-                                          int32_t* bins, void* stream) {
+                                          int32_t* bins, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(x && wq && b1 && b0 && uniforms && bins && rows >= 0);
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0);
   CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)wq | (uintptr_t)logit_prior) & 15) == 0);
@@ -1469,8 +1501,10 @@ extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k
   dc.prior = logit_prior;
   dc.uniforms = uniforms;
   dc.bins = bins;
+  RsGather ga;
+  ga.sched = sched;
   return rs_launch<6, true, false, true>(x, ldx, k_in, nullptr, 192, rows, static_cast<const char*>(wq), b1, b0, 0,
-                                         n_cu > 0 ? n_cu : 256, (hipStream_t)stream, RsGather(), dc);
+                                         n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga, dc);
 }
 
 
@@ -1510,7 +1544,7 @@ extern "C" int cppf_linear_split(const float* x, int64_t ldx, int32_t k_in, floa
 extern "C" int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx,
                                              int32_t slots, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
                                              int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
-                                             const float* b0, int32_t chain, void* stream) {
+                                             const float* b0, int32_t chain, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(heads && gidx && tables && out && wq && b1 && b0 && rows >= 0);
   CPPF_CHECK_ARG(head_cols > 0 && (head_cols & 7) == 0 && ld_heads >= head_cols && (ld_heads & 3) == 0);
   CPPF_CHECK_ARG(slots >= 1 && slots <= 8 && ld_tables >= (int64_t)slots * 256 && (ld_tables & 3) == 0);
@@ -1528,6 +1562,7 @@ extern "C" int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_head
   ga.table = tables;
   ga.slots = slots;
   ga.tld = ld_tables;
+  ga.sched = sched;
   return rs_launch<4, true, false, false, 3, RS_SUMGATHER>(heads, ld_heads, head_cols, out, ldo, rows, static_cast<const char*>(wq), b1, b0,
                                                            chain, rs_cus(), (hipStream_t)stream, ga);
 }
@@ -1540,7 +1575,7 @@ extern "C" int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_head
 extern "C" int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, int32_t k, const int32_t* pt_off,
                                              const int32_t* tup_off, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
                                              int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
-                                             const float* b0, int32_t chain, void* stream) {
+                                             const float* b0, int32_t chain, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(B > 0 && pts && idx && pt_off && tup_off && tables && out && wq && b1 && b0 && rows >= 0);
   CPPF_CHECK_ARG(ld_tables >= (int64_t)k * 256 && (ld_tables & 3) == 0 && (ldo & 3) == 0 && ldo >= n_out && chain >= 0 && chain <= 15);
   CPPF_CHECK_ARG((((uintptr_t)tables | (uintptr_t)out | (uintptr_t)wq) & 15) == 0);
@@ -1560,6 +1595,7 @@ extern "C" int cppf_reslayer_split_sumencode(int B, const float* pts, const int3
   ga.pt_off = pt_off;
   ga.tup_off = tup_off;
   ga.B = B;
+  ga.sched = sched;
   return rs_launch<4, true, false, false, 3, RS_SUMENCODE>(nullptr, 0, 32, out, ldo, rows, static_cast<const char*>(wq), b1, b0, chain,
                                                            rs_cus(), (hipStream_t)stream, ga);
 }
@@ -1571,10 +1607,16 @@ extern "C" int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_ou
   return rs_stream_bytes(k_in, n_out, proj, chain, 2);
 }
 
+static RsGather rs16_gather(const CppfReslayerSplit16Args& a) {      // no gather: only the scheduling counters
+  RsGather ga;
+  ga.sched = a.sched;
+  return ga;
+}
+
 template <int NT, bool PROJ>
 static int rs16_plain(const CppfReslayerSplit16Args& a, int n_cu, RsTap tap) {
   return rs_launch<NT, PROJ, false, false, 2>(a.x, a.ldx, a.k_in, a.out, a.ldo, a.rows, static_cast<const char*>(a.wq), a.b1, a.b0,
-                                              a.chain, n_cu, (hipStream_t)a.stream, RsGather(), RsDecode(), tap, a.weight_scale);
+                                              a.chain, n_cu, (hipStream_t)a.stream, rs16_gather(a), RsDecode(), tap, a.weight_scale);
 }
 
 // The ResLayer launch of cppf_reslayer_split / _tap / _gather / _decode in f16x2 arithmetic (see the kernel's comment): wq =
@@ -1618,6 +1660,7 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
     ga.table = a.table;
     ga.slots = a.slots;
     ga.tld = a.ld_table;
+    ga.sched = a.sched;
     return rs_launch<4, true, false, false, 2, RS_SUMGATHER>(a.x, a.ldx, a.k_in, a.out, a.ldo, a.rows, w, a.b1, a.b0, a.chain, n_cu, st, ga,
                                                              RsDecode(), RsTap(), a.weight_scale);
   }
@@ -1633,6 +1676,7 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
     ga.slots = a.slots;
     ga.head = a.k_in;
     ga.fshift = __builtin_ctz((unsigned)a.fdim);
+    ga.sched = a.sched;
     return rs_launch<4, true, true, false, 2>(a.x, a.ldx, k_tot, a.out, a.ldo, a.rows, w, a.b1, a.b0, a.chain, n_cu, st, ga,
                                               RsDecode(), RsTap(), a.weight_scale);
   }
@@ -1643,7 +1687,7 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
     dc.prior = a.logit_prior;
     dc.uniforms = a.uniforms;
     dc.bins = a.bins;
-    return rs_launch<6, true, false, true, 2>(a.x, a.ldx, a.k_in, nullptr, 192, a.rows, w, a.b1, a.b0, 0, n_cu, st, RsGather(), dc,
+    return rs_launch<6, true, false, true, 2>(a.x, a.ldx, a.k_in, nullptr, 192, a.rows, w, a.b1, a.b0, 0, n_cu, st, rs16_gather(a), dc,
                                               RsTap(), a.weight_scale);
   }
   CPPF_CHECK_ARG(a.out && (a.n_out == 64 || a.n_out == 128 || a.n_out == 192 || a.n_out == 256) && a.ldo >= a.n_out);

@@ -44,6 +44,27 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+DYNAMIC_BLOCKS = True        # the cppf_reslayer_split* launches claim their row blocks from a counter (False: fixed shares)
+_SCHED = {}                  # (device, stream handle) -> int32[2] scheduling counters of that stream's launches
+SCHED_CACHE_MAX = 64
+
+
+def _sched():
+    """The `sched` argument of the cppf_reslayer_split* entry points for a launch on the current stream: two zeroed int32 words
+    per (device, stream) -- launches of one stream cannot overlap and every launch leaves them zero, launches of different
+    streams must not share them (include/cppf_hip.h).  NULL when DYNAMIC_BLOCKS is off."""
+    if not DYNAMIC_BLOCKS:
+        return C.c_void_p(0)
+    st = torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    buf = _SCHED.get(key)
+    if buf is None:
+        if len(_SCHED) >= SCHED_CACHE_MAX:             # a process that keeps creating streams does not pin a buffer per stream
+            _SCHED.pop(next(iter(_SCHED)))
+        buf = _SCHED[key] = torch.zeros((2,), dtype=torch.int32, device=st.device)
+    return C.c_void_p(buf.data_ptr())
+
+
 def _t(x, dtype, device=None):
     """torch tensor on the device with the given dtype, contiguous (accepts numpy / torch / lists)."""
     device = device or _dev()
@@ -331,11 +352,11 @@ def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0, tap=None):
     if tap is not None:
         assert tap.dtype == torch.float32 and tap.shape == (rows, n_out) and tap.stride(1) == 1
         _lib.check(_L.cppf_reslayer_split_tap(_p(x), x.stride(0), k_in, _p(tap), tap.stride(0), _p(out), out.stride(0), n_out,
-                                              rows, _p(wq), wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                              rows, _p(wq), wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                    "cppf_reslayer_split_tap")
         return out
     _lib.check(_L.cppf_reslayer_split(_p(x), x.stride(0), k_in, _p(out), out.stride(0), n_out, rows, _p(wq),
-                                      wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                      wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                "cppf_reslayer_split")
     return out
 
@@ -388,6 +409,7 @@ def reslayer_split16(x, wq, b1, b0, n_out, scale, out=None, chain=0, tap=None, g
     a.b0 = None if b0 is None else b0.data_ptr()
     a.weight_scale = float(scale)
     a.stream = torch.cuda.current_stream().cuda_stream
+    a.sched = _sched().value
     _lib.check(_L.cppf_reslayer_split16(C.byref(a)), "cppf_reslayer_split16")
     return bins if decode is not None else out
 
@@ -407,7 +429,7 @@ def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
         bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
     assert bins.dtype == torch.int32 and bins.is_contiguous() and bins.numel() == rows * 6
     _lib.check(_L.cppf_reslayer_split_decode(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
-                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(u), _p(bins), _stream()),
+                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(u), _p(bins), _sched(), _stream()),
                "cppf_reslayer_split_decode")
     return bins
 
@@ -446,7 +468,7 @@ def reslayer_split_gather(heads, gidx, table, wq, b1, b0, n_out, chain=0):
     ld_heads = heads.stride(0) if heads.shape[1] else 0
     _lib.check(_L.cppf_reslayer_split_gather(_p(heads if heads.shape[1] else table), ld_heads, heads.shape[1], _p(gidx), gidx.shape[1], _p(table),
                                              table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
-                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                "cppf_reslayer_split_gather")
     return out
 
@@ -525,7 +547,7 @@ def reslayer_split_encode(src, table, wq, b1, b0, n_out, chain=0):
     assert b1.numel() == (1 + chain) * n_out
     _lib.check(_L.cppf_reslayer_split_encode(src.B, _p(src.pts), _p(src.nrm), _p(src.idx), src.k, _p(src.pt_off), _p(src.tup_off),
                                              _p(table), table.shape[1], _p(out), out.stride(0), n_out, rows, _p(wq),
-                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                             wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                "cppf_reslayer_split_encode")
     return out
 
@@ -542,7 +564,7 @@ def reslayer_split_sumencode(src, tables, wq, b1, b0, n_out, chain=0):
     assert b1.numel() == (1 + chain) * n_out
     _lib.check(_L.cppf_reslayer_split_sumencode(src.B, _p(src.pts), _p(src.idx), src.k, _p(src.pt_off), _p(src.tup_off), _p(tables),
                                                 tables.stride(0), _p(out), out.stride(0), n_out, rows, _p(wq),
-                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                "cppf_reslayer_split_sumencode")
     return out
 
@@ -621,11 +643,12 @@ def reslayer_split_sumgather(heads, gidx, tables, wq, b1, b0, n_out, chain=0, sc
         a.gidx, a.slots, a.table, a.ld_table = gidx.data_ptr(), int(slots), tables.data_ptr(), tables.stride(0)
         a.weight_scale, a.mode = float(scale), 2
         a.stream = torch.cuda.current_stream().cuda_stream
+        a.sched = _sched().value
         _lib.check(_L.cppf_reslayer_split16(C.byref(a)), "cppf_reslayer_split16(sumgather)")
         return out
     _lib.check(_L.cppf_reslayer_split_sumgather(_p(heads), heads.stride(0), heads.shape[1], _p(gidx), slots, _p(tables),
                                                 tables.stride(0), _p(out), out.stride(0), n_out, rows, _p(wq),
-                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _stream()),
+                                                wq.numel() * wq.element_size(), _p(b1), _p(b0), int(chain), _sched(), _stream()),
                "cppf_reslayer_split_sumgather")
     return out
 

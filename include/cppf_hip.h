@@ -373,17 +373,24 @@ int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out,
  * their weights are zero in the stream); n_out in {64, 128, 192, 256}; b1 float32[(1 + chain) * n_out].  wq = the weights
  * pre-split into bf16 triples in the per-lane operand order the kernel streams (cppf2_amd.models.pack_split writes it;
  * cppf_reslayer_split_stream_bytes gives its size, -1 for unsupported shapes).  Each layer's fc2 bias is the caller's, as
- * for cppf_reslayer128. */
+ * for cppf_reslayer128.
+ * sched (ABI 10; every cppf_reslayer_split* entry point takes it in front of `stream`): NULL, or int32[2] device memory of the
+ * caller's, ZERO before the first launch that uses it.  With it the launch's persistent workgroups claim their 128- / 256-row
+ * blocks from a counter instead of taking a fixed share each: workgroups that start late or run slower -- another stream's
+ * kernels on the chip, the last partial round of a static split -- take fewer blocks (tuple MLP 9.17 -> 8.94 ms).  A launch
+ * leaves the two words zero again, so launches that cannot overlap (one stream) may share one buffer; launches on DIFFERENT
+ * streams need different buffers.  Results never depend on it (a row block's arithmetic does not depend on who runs it). */
 int64_t cppf_reslayer_split_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
-                        const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, void* stream);
+                        const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain, int32_t* sched,
+                        void* stream);
 /* The same with a second output: first_out float32 [rows, >= n_out] (row stride ld_first, a multiple of 4; 16-byte aligned; a
  * buffer of its own) receives the activation after the FIRST layer, out the one after the whole chain -- for a stack whose
  * intermediate result is read elsewhere (the SHOT / DINO models' 256-wide tuple features feed the scale head,
  * train_shot.py:112-114) while the identity layers behind it continue in registers. */
 int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in, float* first_out, int64_t ld_first, float* out,
                             int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
-                            const float* b0, int32_t chain, void* stream);
+                            const float* b0, int32_t chain, int32_t* sched, void* stream);
 
 /* ---- the tuple encode feeding the tuple MLP without materialising its rows (train_shot.py:75-83 -> :100-111): the pair
  * features alone and the tuples' global point indices ...
@@ -400,7 +407,7 @@ int cppf_encode_tuples_shot_heads(int B, const float* pts, const float* normals,
 int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
                                const float* table, int32_t fdim, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                                const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
-                               void* stream);
+                               int32_t* sched, void* stream);
 /* prepare_tuple_inputs (train_shot.py:75-83) and the tuple encoder's first launch in ONE kernel (ABI 9): the 40 pair features of a
  * 5-point tuple -- what cppf_encode_tuples_shot_heads writes, bit for bit -- are computed by the ResLayer kernel's own lanes from
  * pts / normals float32 [points, 3] and the sampler's scene-local idx int32 [rows, 5] (pt_off / tup_off int32 [B + 1]) and go
@@ -409,7 +416,7 @@ int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t hea
 int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, const int32_t* idx, int32_t k,
                                const int32_t* pt_off, const int32_t* tup_off, const float* table, int32_t fdim, float* out,
                                int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
-                               const float* b0, int32_t chain, void* stream);
+                               const float* b0, int32_t chain, int32_t* sched, void* stream);
 
 /* ---- the DINO model's tuple encode without its rows, and every Linear of both models on the matrix cores (train_dino.py:86-97,
  * 128-133; reference call site eval.py:221).
@@ -437,7 +444,7 @@ int cppf_encode_tuples_coord_heads(int B, const float* pts, const int32_t* idx, 
 int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
                                   const float* tables, int64_t ld_tables, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                                   const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
-                                  void* stream);
+                                  int32_t* sched, void* stream);
 /* cppf_reslayer_split_sumgather with the coordinate columns built inside the kernel (ABI 9; RS_SUMENCODE): the DINO model's
  * prepare_tuple_inputs (train_dino.py:91-97) + its tuple encoder's first launch with no per-tuple array in between -- pts float32
  * [points, 3], idx int32 [rows, 5] scene-local tuple indices (the sampler's), pt_off / tup_off int32 [B + 1]; tables / wq / b1 / b0 /
@@ -445,7 +452,7 @@ int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t 
 int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, int32_t k, const int32_t* pt_off,
                                   const int32_t* tup_off, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
                                   int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
-                                  int32_t chain, void* stream);
+                                  int32_t chain, int32_t* sched, void* stream);
 
 /* ---- the bin draw fused into the MLP's output layer (eval.py:225-229 behind train_shot.py:62-66): the 192-wide projection
  * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]
@@ -455,7 +462,7 @@ int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, i
  * logit_prior float32 [rows, 192] or NULL; uniforms float32 [rows, 6]; bins int32 [rows, 6]. */
 int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
                                const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
-                               int32_t* bins, void* stream);
+                               int32_t* bins, int32_t* sched, void* stream);
 int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
                           const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
                           float* scaled, float* scale, float* tr, float* rot, void* stream);
@@ -483,6 +490,7 @@ typedef struct CppfReslayerSplit16Args {
                               2: gather with per-point slot tables summed into the accumulators (cppf_reslayer_split_sumgather:
                               table = [points, slots, 256], ld_table its point pitch, fdim unused) */
   int64_t ld_table;
+  int32_t* sched;          /* NULL or the block-scheduling counters (see cppf_reslayer_split; not used by mode 1) */
 } CppfReslayerSplit16Args;
 int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);

@@ -460,6 +460,59 @@ def test_counted_wait_protocol_race_screen():
 
 
 @pytest.mark.gpu
+def test_dynamic_row_blocks_equal_the_static_split():
+    """The `sched` argument (ABI 10): persistent workgroups claiming their row blocks from a counter compute the bits of the
+    fixed-share launch -- plain, chained, gathered, encoded, with the bin draw; at 1, 7 and all CUs; beside a saturating copy stream --
+    and every launch leaves its two counter words zero, so consecutive launches of a stream share them."""
+    from cppf2_amd import _lib, models, ops
+    L = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+    def layer(k, n, proj, chain):
+        w1, w2 = mk(n, k) / k ** 0.5, mk(n, n) / n ** 0.5
+        w0 = mk(n, k) / k ** 0.5 if proj else None
+        rest = [(mk(n, n) / n ** 0.5, mk(n, n) / n ** 0.5) for _ in range(chain)]
+        return models.pack_split(w1, w0, w2, k, chain=rest), mk((1 + chain) * n) * 0.1, (mk(n) * 0.1 if proj else None)
+
+    rows = 90001
+    table = mk(5000, 64)
+    gidx = torch.randint(0, 5000, (rows, 5), generator=g).to(torch.int32).to(dev)
+    uni = torch.rand(rows, 6, generator=g).to(dev)
+    cases = []
+    for n, k, proj, chain in ((64, 64, False, 1), (128, 360, True, 4), (192, 256, True, 0), (256, 128, True, 2), (256, 256, False, 1)):
+        wq, b1, b0 = layer(k, n, proj, chain)
+        cases.append(("n%d k%d chain%d" % (n, k, chain), lambda x, wq=wq, b1=b1, b0=b0, n=n, chain=chain: ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=chain), k))
+    wq_g, b1_g, b0_g = layer(360, 128, True, 4)
+    cases.append(("gather", lambda x: ops.reslayer_split_gather(x, gidx, table, wq_g, b1_g, b0_g, 128, chain=4), 40))
+    wq_d, b1_d, b0_d = layer(256, 192, True, 0)
+    cases.append(("decode", lambda x: ops.reslayer_split_decode(x, wq_d, b1_d, b0_d, uni), 256))
+    side = torch.cuda.Stream()
+    hog_a, hog_b = torch.empty(1 << 27, device=dev, dtype=torch.uint8), torch.empty(1 << 27, device=dev, dtype=torch.uint8)
+    assert ops.DYNAMIC_BLOCKS
+    try:
+        for name, fn, k in cases:
+            x = mk(rows, k)
+            ops.DYNAMIC_BLOCKS = False
+            ref = fn(x)
+            ops.DYNAMIC_BLOCKS = True
+            for grid in (0, 1, 7):
+                _lib.check(L.cppf_reslayer_split_debug_grid(grid), "grid")
+                for rep in range(4):
+                    with torch.cuda.stream(side):
+                        hog_b.copy_(hog_a)
+                    got = fn(x)
+                    assert torch.equal(got, ref), (name, grid, rep)
+                torch.cuda.synchronize()
+                for buf in ops._SCHED.values():
+                    assert int(buf.abs().sum()) == 0, (name, grid)
+    finally:
+        ops.DYNAMIC_BLOCKS = True
+        L.cppf_reslayer_split_debug_grid(0)
+
+
+@pytest.mark.gpu
 def test_reserved_cus_change_the_grid_not_the_results():
     """cppf_mlp_reserve_cus (the batch mode's knob): launches that leave CUs to other streams -- 1, one per shader engine, half
     the chip, more than the library accepts to give away -- return the bits of the default launch; the context manager restores
