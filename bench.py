@@ -313,7 +313,7 @@ def main():
 
     def timed_loop(k, sample=True, pair=None, one=None):
         """THE timed region: exactly k steps between two barrier + synchronize pairs; max over ranks of the wall-clock seconds.
-        pair = ([step_a, step_b, ...], [stream_a, stream_b, ...]): step i runs on stream i % n with that stream's own state;
+        pair = an entered cppf2_amd.pipeline.BatchMode: step i runs on the mode's next stream with that stream's own Step;
         one = the Step to run on the current stream (default: `step`).  Returns (seconds, own seconds, stage events, end events)."""
         sampled = sampled_steps(k, Step.EVENT_SLOTS) if sample else {}
         ends = []
@@ -325,8 +325,8 @@ def main():
                 if sample:
                     end_pool[i].record()
             else:
-                with torch.cuda.stream(pair[1][i % len(pair[1])]):
-                    ev = pair[0][i % len(pair[1])].run(timed=sampled.get(i))
+                with pair.next() as s_:            # cppf2_amd.pipeline.BatchMode: the next stream and its Step
+                    ev = s_.run(timed=sampled.get(i))
                     if sample:
                         end_pool[i].record()
             if sample:
@@ -359,27 +359,27 @@ def main():
         others = [Step(args, rank, world, dev, scene_shift=j * args.scenes_per_gpu * world) for j in range(1, ns)]
         for o_ in others:
             o_.prepare_events()
-        streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-        pair = ([step] + others, streams)
+        from cppf2_amd.pipeline import BatchMode
+        all_steps = [step] + others
         refs = []
-        for s_ in pair[0]:               # every pipeline alone on the current stream: the records of ITS scenes
+        for s_ in all_steps:             # every pipeline alone on the current stream: the records of ITS scenes
             s_.run()
             torch.cuda.synchronize()
             refs.append(s_.pipe.results.clone())
-        # batch mode: the persistent MLP launches leave one CU per shader engine to the other stream's kernels
-        # (cppf_mlp_reserve_cus; a queue's workgroups are placed round-robin over the shader engines, so ONE full engine stalls
-        # the other stream's whole launch: 31 reserved CUs change nothing, 32 give + 3.5 %, docs/measurements.md 11.7)
-        if args.mlp_reserve_cus is None:
-            args.mlp_reserve_cus = step.ops.batch_mode_reserved_cus(dev)
-        step.ops.mlp_reserve_cus(args.mlp_reserve_cus)
-        for s_, st_ in zip(*pair):
-            st_.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st_):
-                for _ in range(max(2, args.warmup)):
+        # The library's batch mode (cppf2_amd.pipeline.BatchMode): one stream per Step, and while it is active the persistent MLP
+        # launches leave one CU per shader engine to the other stream's kernels (cppf_mlp_reserve_cus; a queue's workgroups are
+        # placed round-robin over the engines, so ONE full engine stalls the other stream's whole launch: 31 reserved CUs change
+        # nothing, 32 give + 3.5 %, docs/measurements.md 11.7).  --mlp-reserve-cus overrides the count.
+        mode = BatchMode(all_steps, device=dev, reserve_cus=args.mlp_reserve_cus)
+        args.mlp_reserve_cus = mode.reserve_cus
+        streams = mode.streams
+        with mode:
+            for _ in range(max(2, args.warmup) * ns):
+                with mode.next() as s_:
                     s_.run()
-        torch.cuda.synchronize()
-        dt, mine, evs, ends = timed_loop(args.steps, pair=pair)
-        step.ops.mlp_reserve_cus(0)
+            torch.cuda.synchronize()
+            dt, mine, evs, ends = timed_loop(args.steps, pair=mode)
+        pair = (all_steps, streams)
         intervals = completion_intervals(ends, group=len(streams))
         same = bool(all(torch.equal(s_.pipe.results, r_) for s_, r_ in zip(pair[0], refs)))
         distinct = bool(all(not torch.equal(refs[0], r_) for r_ in refs[1:]))

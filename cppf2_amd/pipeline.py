@@ -295,3 +295,66 @@ class VotingPipeline:
     def results_to_numpy(self, results=None):
         r = self.results if results is None else results
         return np.frombuffer(r.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).copy()
+
+
+class BatchMode:
+    """The batch mode of the path: consecutive, independent batches alternate between HIP streams, each stream with state of its
+    own (one VotingPipeline / model pass object per stream: `states`), so that one batch's descriptor, voting and small MLP
+    kernels run beside the other batch's wide matrix-core launches.  While the mode is active those persistent launches leave one
+    CU per shader engine to the other streams (cppf_mlp_reserve_cus: workgroups are placed round-robin over the engines, and an
+    engine without a free CU stalls the other stream's whole launch).  Results are those of the same batches run one after the
+    other on one stream (every entry point takes its stream; no state is shared).
+
+        with BatchMode([state_a, state_b]) as mode:
+            for batch in batches:
+                with mode.next() as state:        # the stream of this batch is current inside the block
+                    state.run(batch)
+        # leaving the block: the calling stream waits for both streams, the reservation is lifted
+    """
+
+    def __init__(self, states, device=None, reserve_cus=None, streams=None):
+        self.states = list(states)
+        assert len(self.states) >= 1
+        self.dev = torch.device(device) if device is not None else ops._dev()
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(device=self.dev) for _ in self.states]
+        assert len(self.streams) == len(self.states)
+        self.reserve_cus = ops.batch_mode_reserved_cus(self.dev) if reserve_cus is None else int(reserve_cus)
+        self.count = 0
+        self.active = False
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+        ops.mlp_reserve_cus(self.reserve_cus if len(self.states) > 1 else 0)
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        ops.mlp_reserve_cus(0)
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+        self.active = False
+        return False
+
+    def next(self):
+        """Context manager: the next stream's state, with that stream current."""
+        assert self.active, "use inside `with BatchMode(...)`"
+        j = self.count % len(self.states)
+        self.count += 1
+        return _OnStream(self.streams[j], self.states[j])
+
+
+class _OnStream:
+    def __init__(self, stream, state):
+        self.stream, self.state = stream, state
+        self.ctx = None
+
+    def __enter__(self):
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self.state
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)

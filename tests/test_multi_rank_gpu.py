@@ -238,3 +238,33 @@ def test_bench_refuses_more_ranks_than_gpus():
         assert rc == 0 and json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])["n_gpus"] == 2
         return
     assert rc == 2 and "GPU(s) are visible" in err and not [ln for ln in out.splitlines() if ln.startswith("{")]
+
+
+def test_batch_mode_object_alternates_streams_and_restores_the_grid():
+    """cppf2_amd.pipeline.BatchMode (what bench.py's headline loop runs on): batches alternate between the states' own streams
+    with the CU reservation in force inside the block and lifted after it; records equal the sequential run's."""
+    from cppf2_amd.benchlib import workloads as bench
+    from cppf2_amd.pipeline import BatchMode
+    from cppf2_amd import ops, _lib
+    dev = torch.device("cuda")
+    a = _args(8, points=2048, tuples=6000, rots=90)
+    steps = [bench.Step(a, 0, 1, dev), bench.Step(a, 0, 1, dev, scene_shift=8)]
+    want = []
+    for s in steps:
+        s.run()
+        torch.cuda.synchronize()
+        want.append(s.pipe.results.clone())
+    seen = []
+    with BatchMode(steps, device=dev) as mode:
+        assert mode.reserve_cus == ops.batch_mode_reserved_cus(dev) and len(mode.streams) == 2
+        for i in range(6):
+            with mode.next() as s:
+                assert s is steps[i % 2] and torch.cuda.current_stream() == mode.streams[i % 2]
+                seen.append(torch.cuda.current_stream().cuda_stream)
+                s.run()
+    torch.cuda.synchronize()              # (leaving the block made the calling stream wait for both)
+    assert len(set(seen)) == 2
+    for s, w in zip(steps, want):
+        assert torch.equal(s.pipe.results, w)
+    with pytest.raises(AssertionError):
+        mode.next()                       # not active any more
