@@ -203,13 +203,17 @@ def run_other_workload(args, rank, world, dev, backend, timer):
         ref_sel = step.pipe.selected.clone()
         ref_slots = step.pipe.result_slots.clone()
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        # (no cppf_mlp_reserve_cus here: both passes are dominated by their own wide MLP launches, which cannot share the chip --
-        # measured 2 830 -> 2 730 instances/s with 32 CUs reserved, docs/measurements.md 11.7)
+        # like eval.run_ensemble: one CU per shader engine left to the other pass' kernels (with the row blocks claimed from a
+        # counter the two passes' wide launches share the chip gracefully: + 1.3 %; with fixed shares it lost 3.5 %, measurements 11.7)
+        if args.mlp_reserve_cus is None:
+            args.mlp_reserve_cus = step.ops.batch_mode_reserved_cus(dev)
+        step.ops.mlp_reserve_cus(args.mlp_reserve_cus)
         for _ in range(max(2, args.warmup)):
             step.run_two_streams(streams)
         dt, mine, _ = timer.loop(args.steps, lambda i: step.run_two_streams(streams))
+        step.ops.mlp_reserve_cus(0)
         same = bool(torch.equal(step.pipe.selected, ref_sel) and torch.equal(step.pipe.result_slots, ref_slots))
-        step.two = {"streams": 2, "mlp_reserved_cus": 0, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
+        step.two = {"streams": 2, "mlp_reserved_cus": args.mlp_reserve_cus, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
                     "ms_per_step_single_stream": 1e3 * dt1 / args.steps,
                     "note": "the DINO pass and the SHOT pass (descriptors included) on two HIP streams, twin pipelines, one event "
                             "for the DINO scale; per-stage times come from the single-stream loop of the same run"}

@@ -226,9 +226,14 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                              pred_cls=pred_cls.cpu().numpy(), raw_cls=raw_cls.cpu().numpy(), pred_scales=pred_scales.cpu().numpy(), u=u.cpu().numpy(),
                              counts=pp.counts.cpu().numpy()))
 
-    for model_idx in (0, 1):                                                               # eval.py:219
-        with torch.cuda.stream(streams[model_idx]):
-            one_pass(model_idx)
+    # (two streams: the persistent MLP launches leave one CU per shader engine to the other pass' kernels, cppf_mlp_reserve_cus)
+    ops.mlp_reserve_cus(ops.batch_mode_reserved_cus(dev) if two else 0)
+    try:
+        for model_idx in (0, 1):                                                           # eval.py:219
+            with torch.cuda.stream(streams[model_idx]):
+                one_pass(model_idx)
+    finally:
+        ops.mlp_reserve_cus(0)
     for st_ in streams:
         main.wait_stream(st_)
     # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first -- on the device ---------
