@@ -29,14 +29,24 @@ __global__ __launch_bounds__(256) void sample_tuples_kernel(int B, const int32_t
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
   const uint32_t n = (uint32_t)(pt_off[b + 1] - pt_off[b]);
   const uint32_t sid = (uint32_t)(sid_base + b * sid_stride);
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
-    int32_t* row = out + (int64_t)(t0 + t) * k;
-    for (int blk = 0; blk * 4 < k; ++blk) {
-      const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, 0u, key0, key1);
+  // a workgroup's 256 rows are contiguous in the table: staged in LDS and written out as consecutive words (a row is 8 .. 32
+  // bytes: row-wise stores touch every cache line of the tile k times)
+  __shared__ int32_t s_rows[256 * 8];
+  for (int tb = blockIdx.x * blockDim.x; tb < nt; tb += gridDim.x * blockDim.x) {
+    const int t = tb + threadIdx.x;
+    if (t < nt) {
+      for (int blk = 0; blk * 4 < k; ++blk) {
+        const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, 0u, key0, key1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (blk * 4 + j < k) row[blk * 4 + j] = (int32_t)(((uint64_t)w.v[j] * n) >> 32);
+        for (int j = 0; j < 4; ++j)
+          if (blk * 4 + j < k) s_rows[threadIdx.x * k + blk * 4 + j] = (int32_t)(((uint64_t)w.v[j] * n) >> 32);
+      }
     }
+    __syncthreads();
+    const int words = min(256, nt - tb) * k;
+    int32_t* dst = out + (int64_t)(t0 + tb) * k;
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = s_rows[i];
+    __syncthreads();
   }
 }
 
@@ -60,14 +70,22 @@ __global__ __launch_bounds__(256) void philox_uniform_kernel(int B, const int32_
   const int b = blockIdx.y;
   const int t0 = tup_off[b], nt = tup_off[b + 1] - t0;
   const uint32_t sid = (uint32_t)(sid_base + b * sid_stride);
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
-    float* row = out + (int64_t)(t0 + t) * m;
-    for (int blk = 0; blk * 4 < m; ++blk) {
-      const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, stream_id, key0, key1);
+  __shared__ float s_rows[256 * 8];               // (staged like sample_tuples_kernel's rows: consecutive words out)
+  for (int tb = blockIdx.x * blockDim.x; tb < nt; tb += gridDim.x * blockDim.x) {
+    const int t = tb + threadIdx.x;
+    if (t < nt) {
+      for (int blk = 0; blk * 4 < m; ++blk) {
+        const Philox4 w = philox4x32_10((uint32_t)t, (uint32_t)blk, sid, stream_id, key0, key1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (blk * 4 + j < m) row[blk * 4 + j] = (float)(w.v[j] >> 8) * 5.9604644775390625e-8f;  // 2^-24
+        for (int j = 0; j < 4; ++j)
+          if (blk * 4 + j < m) s_rows[threadIdx.x * m + blk * 4 + j] = (float)(w.v[j] >> 8) * 5.9604644775390625e-8f;  // 2^-24
+      }
     }
+    __syncthreads();
+    const int words = min(256, nt - tb) * m;
+    float* dst = out + (int64_t)(t0 + tb) * m;
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = s_rows[i];
+    __syncthreads();
   }
 }
 
