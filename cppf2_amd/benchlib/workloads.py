@@ -175,12 +175,12 @@ class EnsembleStep(Step):
     STAGES = (["sample_tuples", "shot_frames", "shot352", "shot_encoder", "dino_point_transforms"]
               + ["dino_" + n for n in PASS] + ["shot_" + n for n in PASS] + ["select", "gather"])
 
-    def __init__(self, args, rank, world, dev):
-        super().__init__(args, rank, world, dev)
+    def __init__(self, args, rank, world, dev, scene_shift=0):
+        super().__init__(args, rank, world, dev, scene_shift=scene_shift)
         from cppf2_amd.models import BeyondCPPFDino
         torch.manual_seed(args.seed + 1)
         self.dino = BeyondCPPFDino(Cfg()).to(dev).eval()
-        g = torch.Generator(device="cpu").manual_seed(args.seed + 17 + rank)
+        g = torch.Generator(device="cpu").manual_seed(args.seed + 17 + rank + 1000003 * scene_shift)
         self.desc = torch.nn.functional.normalize(torch.randn((self.B * self.N, 1024), generator=g), dim=-1).to(dev)
         self.scales_buf2 = torch.zeros((self.B * self.T, 3), dtype=torch.float32, device=dev)
 
