@@ -39,7 +39,8 @@ class ReslayerSplit16Args(C.Structure):
                 ("first_out", C.c_void_p), ("ld_first", C.c_int64),
                 ("gidx", C.c_void_p), ("slots", C.c_int32), ("table", C.c_void_p), ("fdim", C.c_int32),
                 ("logit_prior", C.c_void_p), ("uniforms", C.c_void_p), ("bins", C.c_void_p),
-                ("stream", C.c_void_p), ("mode", C.c_int32), ("ld_table", C.c_int64), ("sched", C.c_void_p)]
+                ("stream", C.c_void_p), ("mode", C.c_int32), ("ld_table", C.c_int64), ("sched", C.c_void_p),
+                ("prior_pos", C.c_void_p), ("prior_inv_sigma", C.c_float)]
 
 
 assert C.sizeof(SceneGrid) == 32
@@ -106,7 +107,7 @@ SIGNATURES = {
     "cppf_reslayer_split_stream_bytes": (_i64, [_i, _i, _i, _i]),
     "cppf_reslayer_split": (_i, [_p, _i64, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
     "cppf_reslayer_split_tap": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),
-    "cppf_reslayer_split_decode": (_i, [_p, _i64, _i, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "cppf_reslayer_split_decode": (_i, [_p, _i64, _i, _i64, _p, _i64, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p]),
     "cppf_decode_from_bins": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "cppf_encode_tuples_shot_heads": (_i, [_i, _p, _p, _p, _i, _p, _p, _i64, _p, _i, _p, _p]),
     "cppf_reslayer_split_gather": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p, _i64, _i, _i64, _p, _i64, _p, _p, _i, _p, _p]),

@@ -43,7 +43,7 @@ def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
                                    "note": "relative to max |logit|; the timed step runs " + ("split_bf16x3" if arith0 == "split" else "split_f16x2")}
     logits = step.model.heads(x, lazy_scale=True)[0].contiguous()                  # [sc*T, 6, 32]
     u = ops.philox_uniform(T, 6, a.seed, 1, ids, dev)
-    prior = step.prior[:sc * T]
+    prior = step.prior_dense[:sc * T]
     got = ops.decode_bins(logits, u, step.pts[:sc * N], idx, Cfg.up, Cfg.front, Cfg.right, pt_off, tup_off, prior=prior)["bins"]
     e = logits + prior
     p = torch.exp(e - e.max(-1, keepdim=True).values)

@@ -47,6 +47,8 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--vote-mode", type=int, default=0)
+    ap.add_argument("--array-prior", action="store_true",
+                    help="pass the teacher prior as a [T, 6, 32] array instead of its generator (ops.BinPrior): same records, + 0.34 ms")
     ap.add_argument("--mlp-reserve-cus", type=int, default=None,
                     help="CUs the persistent tuple-MLP launches leave to the other stream in the two-stream loop "
                          "(default: one per shader engine = CUs / 8; 0 = none)")

@@ -49,8 +49,11 @@ class Step:
         base = (torch.arange(B, device=dev, dtype=torch.int64) * N).repeat_interleave(T)
         coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(B * T, 6)
         pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
-        kbin = torch.arange(32, device=dev, dtype=torch.float32)
-        self.prior = (-0.5 * ((kbin[None, None, :] - pos[..., None]) / 0.6) ** 2).contiguous()
+        # as its generator (ops.BinPrior: the fused bin draw evaluates -0.5 ((k - pos) / sigma)^2 in its epilogue, 24 bytes per tuple
+        # instead of a 983 MB array per launch; --array-prior passes the array -- the same values bit for bit, same records)
+        self.teacher = ops.BinPrior(pos.contiguous(), 1.0 / 0.6)
+        self._prior_dense = None
+        self.prior = self.prior_dense if getattr(args, "array_prior", False) else self.teacher
         self.shot = torch.empty((B * N, 352), dtype=torch.float32, device=dev)
         self.normal = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         self.all_records = None
@@ -60,6 +63,13 @@ class Step:
         self.materialize = bool(getattr(args, "materialize_tuples", False))
         self.host_times = None          # debugging aid: host-side time stamps of the stage boundaries (CPPF_BENCH_HOSTTIMES=1)
         self.ev = None
+
+    @property
+    def prior_dense(self):
+        """The teacher prior as a [T, 6, 32] array (the unfused decode kernel and --array-prior read it), built on first use."""
+        if self._prior_dense is None:
+            self._prior_dense = self.teacher.dense(32)
+        return self._prior_dense
 
     @property
     def gather(self):
@@ -136,7 +146,7 @@ class Step:
         if drawn:
             pipe.decode_from_bins(self.pts, idx)
         else:
-            pipe.decode(self.pts, idx, logits, u, prior=self.prior)      # teacher prior added inside the decode kernel
+            pipe.decode(self.pts, idx, logits, u, prior=self.prior_dense)      # teacher prior added inside the decode kernel
         self._mark("decode_bins")
         pipe.vote_center(self.pts, idx, phase=1)      # scene bounds + per-pair circle frames
         self._mark("vote_frames")

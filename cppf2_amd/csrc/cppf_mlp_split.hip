@@ -580,6 +580,11 @@ __device__ __forceinline__ void rs_load_tile_scaled(f32x16& acc, const float* v,
 // target = uniform * total, bin = #{cdf <= target} capped at 31.  The six coordinates' chains are independent and interleave.
 struct RsDecode {
   const float* prior = nullptr;     // [rows, 192] additive logit prior or NULL
+  // ... or the prior GENERATED here: -0.5 ((k - prior_pos[row, c]) * prior_inv_sigma)^2 for bin k of coordinate c (a Gaussian
+  // bump in logit space around a per-coordinate bin position: 24 bytes per row read instead of 768; float32 operations in this
+  // order, no contraction -- the values of the array a caller would build with the same three operations, bit for bit)
+  const float* prior_pos = nullptr; // [rows, 6] or NULL
+  float prior_inv_sigma = 0.0f;
   const float* uniforms = nullptr;  // [rows, 6]
   int32_t* bins = nullptr;          // [rows, 6] out
 };
@@ -599,6 +604,18 @@ __device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDeco
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(pr + 32 * u + 8 * q);
         o[u][4 * q + 0] += v.x; o[u][4 * q + 1] += v.y; o[u][4 * q + 2] += v.z; o[u][4 * q + 3] += v.w;
+      }
+    }
+  } else if (dc.prior_pos) {
+    const float* pp = dc.prior_pos + row * 6;
+    const float is = dc.prior_inv_sigma;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const float pos = pp[u];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {               // register e <-> bin (e & 3) + 8 (e >> 2) + 4 g
+        const float z = ((float)((e & 3) + 8 * (e >> 2) + 4 * g) - pos) * is;
+        o[u][e] += (z * z) * -0.5f;
       }
     }
   }
@@ -667,6 +684,7 @@ struct RsDraw {
   float mx, ex, back, fwd, tot, tb3, ta[4], uni;
   int cnt, cx;
   const float* pr;              // prior of this coordinate's 32 bins (this lane's 4 g offset applied) or NULL
+  float ppos, pis;              // generated prior: position of this coordinate, 1 / sigma (pis == 0: none)
   int32_t* bin;                 // where the bin goes (NULL: row out of range)
 };
 
@@ -681,6 +699,12 @@ __device__ __forceinline__ void rs_draw_piece(RsDraw& d, int g, float bs) {
     if (d.pr) {
       const f32x4 p4 = *reinterpret_cast<const f32x4*>(d.pr + 8 * q);
       d.v[4 * q + 0] += p4.x; d.v[4 * q + 1] += p4.y; d.v[4 * q + 2] += p4.z; d.v[4 * q + 3] += p4.w;
+    } else if (d.pis != 0.0f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z = ((float)(i + 8 * q + 4 * g) - d.ppos) * d.pis;
+        d.v[4 * q + i] += (z * z) * -0.5f;
+      }
     }
   } else if constexpr (M == 4) {
     float m = d.v[0];
@@ -762,6 +786,8 @@ __device__ __forceinline__ void rs_draw_begin(RsDraw& d, const RsPending& pd, co
     d.v[e] = x;
   }
   d.pr = dc.prior ? dc.prior + pd.row * 192 + 32 * p + 4 * g : nullptr;
+  d.pis = (!dc.prior && dc.prior_pos) ? dc.prior_inv_sigma : 0.0f;
+  d.ppos = d.pis != 0.0f ? dc.prior_pos[pd.row * 6 + p] : 0.0f;
   d.uni = dc.uniforms[pd.row * 6 + p];
   d.bin = pd.in ? dc.bins + pd.row * 6 + p : nullptr;
 }
@@ -1487,9 +1513,10 @@ extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* 
 // cppf_decode_from_bins for the vote parameters.  x / wq / b1 / b0 as cppf_reslayer_split with n_out = 192, chain = 0;
 // logit_prior float32 [rows, 192] or NULL, uniforms float32 [rows, 6], bins int32 [rows, 6].
 extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
-                                          const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
-                                          int32_t* bins, int32_t* sched, void* stream) {
+                                          const float* b1, const float* b0, const float* logit_prior, const float* prior_pos,
+                                          float prior_inv_sigma, const float* uniforms, int32_t* bins, int32_t* sched, void* stream) {
   CPPF_CHECK_ARG(x && wq && b1 && b0 && uniforms && bins && rows >= 0);
+  CPPF_CHECK_ARG(!(logit_prior && prior_pos) && (!prior_pos || (prior_inv_sigma > 0.0f && prior_inv_sigma < INFINITY)));
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0);
   CPPF_CHECK_ARG((((uintptr_t)x | (uintptr_t)wq | (uintptr_t)logit_prior) & 15) == 0);
   CPPF_CHECK_ARG(wq_bytes == cppf_reslayer_split_stream_bytes(k_in, 192, 1, 0));
@@ -1499,6 +1526,8 @@ extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k
   CPPF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   RsDecode dc;
   dc.prior = logit_prior;
+  dc.prior_pos = prior_pos;
+  dc.prior_inv_sigma = prior_pos ? prior_inv_sigma : 0.0f;
   dc.uniforms = uniforms;
   dc.bins = bins;
   RsGather ga;
@@ -1684,7 +1713,10 @@ extern "C" int cppf_reslayer_split16(const CppfReslayerSplit16Args* args) {
   if (decode) {
     CPPF_CHECK_ARG(proj && a.bins && a.chain == 0 && a.wq_bytes == rs_stream_bytes(a.k_in, 192, 1, 0, 2));
     RsDecode dc;
+    CPPF_CHECK_ARG(!(a.logit_prior && a.prior_pos) && (!a.prior_pos || (a.prior_inv_sigma > 0.0f && a.prior_inv_sigma < INFINITY)));
     dc.prior = a.logit_prior;
+    dc.prior_pos = a.prior_pos;
+    dc.prior_inv_sigma = a.prior_pos ? a.prior_inv_sigma : 0.0f;
     dc.uniforms = a.uniforms;
     dc.bins = a.bins;
     return rs_launch<6, true, false, true, 2>(a.x, a.ldx, a.k_in, nullptr, 192, a.rows, w, a.b1, a.b0, 0, n_cu, st, rs16_gather(a), dc,

@@ -390,6 +390,10 @@ def reslayer_split16(x, wq, b1, b0, n_out, scale, out=None, chain=0, tap=None, g
     if decode is not None:
         uniforms, prior, bins = decode
         uniforms = uniforms.contiguous()
+        if isinstance(prior, BinPrior):
+            a.prior_pos, a.prior_inv_sigma = prior.pos.data_ptr(), prior.inv_sigma
+            keep.append(prior.pos)
+            prior = None
         prior = None if prior is None else prior.contiguous()
         if bins is None:
             bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
@@ -414,14 +418,38 @@ def reslayer_split16(x, wq, b1, b0, n_out, scale, out=None, chain=0, tap=None, g
     return bins if decode is not None else out
 
 
+class BinPrior:
+    """A logit prior given by its generator instead of its [T, 6, 32] array: prior[t, c, k] = -0.5 ((k - pos[t, c]) * inv_sigma)^2,
+    a Gaussian bump in logit space around a per-coordinate bin position (the synthetic teacher of the benchmarks and of
+    eval.main's synthetic mode; a coarse pose hypothesis would supply the same).  The fused bin draw evaluates it in its epilogue
+    (cppf_reslayer_split_decode: prior_pos / prior_inv_sigma) -- 24 bytes per tuple read instead of 768; dense() is the array, built
+    with the same three float32 operations in the same order, so both forms draw the same bins bit for bit."""
+
+    def __init__(self, pos, inv_sigma):
+        assert pos.dtype == torch.float32 and pos.dim() == 2 and pos.shape[1] == 6
+        self.pos = pos.contiguous()
+        self.inv_sigma = float(np.float32(inv_sigma))
+        assert self.inv_sigma > 0.0
+
+    def dense(self, nb=32):
+        k = torch.arange(nb, device=self.pos.device, dtype=torch.float32)
+        z = (k[None, None, :] - self.pos[..., None]) * torch.tensor(self.inv_sigma, dtype=torch.float32, device=self.pos.device)
+        return ((z * z) * -0.5).contiguous()
+
+
 def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
     """The logit head's output layer (192-wide projection ResLayer) with the bin draw of eval.py:225-229 as its epilogue
     (cppf_reslayer_split_decode): bins int32 [rows, 6] = what decode_bins draws from these logits (+ prior) at `uniforms`
-    [rows, 6], bit for bit; the logits are never written."""
+    [rows, 6], bit for bit; the logits are never written.  prior: None, a float32 [rows, 6, 32] array, or a BinPrior (generated
+    in the epilogue)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     rows = x.shape[0]
     u = uniforms.contiguous()
     assert u.dtype == torch.float32 and u.numel() == rows * 6
+    ppos, pis = None, 0.0
+    if isinstance(prior, BinPrior):
+        assert prior.pos.shape[0] == rows
+        ppos, pis, prior = prior.pos, prior.inv_sigma, None
     if prior is not None:
         prior = prior.contiguous()
         assert prior.dtype == torch.float32 and prior.numel() == rows * 192
@@ -429,7 +457,8 @@ def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
         bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
     assert bins.dtype == torch.int32 and bins.is_contiguous() and bins.numel() == rows * 6
     _lib.check(_L.cppf_reslayer_split_decode(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
-                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(u), _p(bins), _sched(), _stream()),
+                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(ppos), C.c_float(pis), _p(u), _p(bins),
+                                             _sched(), _stream()),
                "cppf_reslayer_split_decode")
     return bins
 

@@ -168,7 +168,8 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
     desc = torch.cat([d.to(dev) if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32)).to(dev)
                       for d in descs])
     base = torch.cat([torch.full((num_pairs,), o, dtype=torch.int64) for o in np.cumsum([0] + Ns[:-1])]).to(dev)
-    prior = priors(idx, base) if priors is not None else None
+    prior = priors(idx, base) if priors is not None else None      # a [T, 6, nb] array or an ops.BinPrior
+    prior_arr = (lambda: prior.dense() if isinstance(prior, ops.BinPrior) else prior)
     scale_prior = None
     if scale_priors is not None:
         scale_prior = torch.from_numpy(np.asarray(scale_priors, dtype=np.float32)).to(dev).repeat_interleave(num_pairs, 0)
@@ -190,7 +191,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
         # eval.py:225-229 (the bin draw) runs as the epilogue of the logit head's output layer when the kernels allow it (split
         # arithmetic, no intermediates requested): the heads then return None in place of the logits.  The scale head is
         # evaluated after the back-vote filter, on the kept pairs' rows only (eval.py:272 reads nothing else).
-        draw = None if keep else (u, None if prior is None else prior.contiguous(), pp.bins)
+        draw = None if keep else (u, None if prior is None else (prior if isinstance(prior, ops.BinPrior) else prior.contiguous()), pp.bins)
         if model_idx == 0:
             # train_dino.py:91-97, 128-133 without its rows: per-point slot tables + coordinate columns, summed by the first
             # ResLayer's kernel; every layer is a kernel of the library
@@ -206,7 +207,7 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                                                             lazy_scale=not keep, decode=draw)
         raw_cls = pred_cls
         if prior is not None and pred_cls is not None:
-            pred_cls = pred_cls + prior
+            pred_cls = pred_cls + prior_arr()
 
         def scales():
             s_ = second if keep else model.scale_head_rows(second, pp.kept_rows32(),
@@ -466,7 +467,7 @@ def _teacher_prior(canon, dev):
     def prior(idx, base):
         coords = canon[(idx[:, :2].long() + base[:, None]).reshape(-1)].reshape(-1, 6)
         pos = (coords.clamp(-0.5, 0.5) + 0.5) * 31.0
-        return -0.5 * ((kb[None, None, :] - pos[..., None]) / 0.6) ** 2
+        return ops.BinPrior(pos.contiguous(), 1.0 / 0.6)          # generated inside the fused bin draw; .dense() where an array is needed
     return prior
 
 

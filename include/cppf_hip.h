@@ -459,10 +459,15 @@ int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, i
  * (+ logit_prior[t, c, :])) at uniforms[t, c]  as its epilogue -- cppf_decode_bins' arithmetic bit for bit -- so that the
  * logits are never written; cppf_decode_from_bins then computes what the second half of cppf_decode_bins computes (scaled
  * pair, scale, targets_tr, targets_rot) from the bins.  x / wq / b1 / b0 as cppf_reslayer_split (n_out = 192, chain = 0);
- * logit_prior float32 [rows, 192] or NULL; uniforms float32 [rows, 6]; bins int32 [rows, 6]. */
+ * logit_prior float32 [rows, 192] or NULL; uniforms float32 [rows, 6]; bins int32 [rows, 6].
+ * prior_pos / prior_inv_sigma (ABI 10; instead of logit_prior, never both): the prior GENERATED in the epilogue --
+ * prior[t, c, k] = -0.5 ((k - prior_pos[t, c]) * prior_inv_sigma)^2, float32, these three operations in this order -- a Gaussian bump
+ * in logit space around a per-coordinate bin position (what a synthetic teacher or a coarse pose hypothesis supplies): 24 bytes per
+ * row read instead of 768 (the array form costs the launch 0.34 ms per 1.28 M rows, all of it its 983 MB of reads).  Bit-identical
+ * to passing the array built with the same three operations. */
 int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
-                               const float* b1, const float* b0, const float* logit_prior, const float* uniforms,
-                               int32_t* bins, int32_t* sched, void* stream);
+                               const float* b1, const float* b0, const float* logit_prior, const float* prior_pos,
+                               float prior_inv_sigma, const float* uniforms, int32_t* bins, int32_t* sched, void* stream);
 int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
                           const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
                           float* scaled, float* scale, float* tr, float* rot, void* stream);
@@ -491,6 +496,8 @@ typedef struct CppfReslayerSplit16Args {
                               table = [points, slots, 256], ld_table its point pitch, fdim unused) */
   int64_t ld_table;
   int32_t* sched;          /* NULL or the block-scheduling counters (see cppf_reslayer_split; not used by mode 1) */
+  const float* prior_pos;  /* decode: the generated prior of cppf_reslayer_split_decode (instead of logit_prior) or NULL */
+  float prior_inv_sigma;
 } CppfReslayerSplit16Args;
 int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
 int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);

@@ -460,6 +460,46 @@ def test_counted_wait_protocol_race_screen():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["split", "split16"])
+def test_generated_bin_prior_equals_its_array(arith):
+    """ops.BinPrior (cppf_reslayer_split_decode's prior_pos / prior_inv_sigma): the Gaussian logit prior generated in the bin draw's
+    epilogue draws the bins of the same prior passed as a [T, 6, 32] array, bit for bit -- positions inside, at the edges of and
+    outside the bin range, several widths -- and of decode_bins on the written logits + that array; both at once are refused."""
+    from cppf2_amd import _lib, models, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(13)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    rows, k = 50001, 256
+    w1, w0, w2 = mk(192, k) / k ** 0.5, mk(192, k) / k ** 0.5, mk(192, 192) / 192 ** 0.5
+    b1, b0 = mk(192) * 0.1, mk(192) * 0.1
+    x = mk(rows, k)
+    uni = torch.rand(rows, 6, generator=g).to(dev)
+    pos = (torch.rand(rows, 6, generator=g) * 37.0 - 3.0).to(dev)          # [-3, 34): also beyond bins 0 .. 31
+    pos[:100] = torch.round(pos[:100])                                     # exactly on a bin
+    for inv_sigma in (1.0 / 0.6, 0.25, 3.0):
+        prior = ops.BinPrior(pos, inv_sigma)
+        dense = prior.dense(32)
+        assert dense.shape == (rows, 6, 32) and float(dense.max()) <= 0.0
+        if arith == "split":
+            wq = models.pack_split(w1, w0, w2, k)
+            got = ops.reslayer_split_decode(x, wq, b1, b0, uni, prior=prior)
+            want = ops.reslayer_split_decode(x, wq, b1, b0, uni, prior=dense)
+        else:
+            sc = models.f16_scale(w1, w0, w2)
+            wq = models.pack_split(w1, w0, w2, k, arith="f16x2", scale=sc)
+            got = ops.reslayer_split16(x, wq, b1 * sc, b0 * sc, 192, sc, decode=(uni, prior, None))
+            want = ops.reslayer_split16(x, wq, b1 * sc, b0 * sc, 192, sc, decode=(uni, dense, None))
+        assert torch.equal(got, want), inv_sigma
+        assert not torch.equal(got, (ops.reslayer_split_decode(x, wq, b1, b0, uni) if arith == "split" else got * 0 - 1))   # the prior matters
+    if arith == "split":
+        L = _lib.load()
+        bins = torch.empty((rows, 6), dtype=torch.int32, device=dev)
+        rc = L.cppf_reslayer_split_decode(ops._p(x), x.stride(0), k, rows, ops._p(wq), wq.numel() * wq.element_size(), ops._p(b1), ops._p(b0),
+                                          ops._p(dense), ops._p(pos), 1.0, ops._p(uni), ops._p(bins), None, ops._stream())
+        assert rc != 0                                                     # an array AND a generator: refused
+
+
+@pytest.mark.gpu
 def test_dynamic_row_blocks_equal_the_static_split():
     """The `sched` argument (ABI 10): persistent workgroups claiming their row blocks from a counter compute the bits of the
     fixed-share launch -- plain, chained, gathered, encoded, with the bin draw; at 1, 7 and all CUs; beside a saturating copy stream --
