@@ -503,7 +503,9 @@ __device__ __forceinline__ void pcl_float_sums(int lane, double* s_raw, float rn
 // its registers keep eight wavefronts per SIMD); a longer list keeps the float64 sums and marks sums[9] with + 0.5 for
 // shot_pcl_long_kernel, which redoes the marked queries from the workspace copy of the list (up to NBR_CAP = 512 neighbours: a
 // 2 mm voxel cloud has at most ~314 inside 2 cm; beyond that the float64 sums stay).
+#ifndef PCL_EMAX_SHORT
 #define PCL_EMAX_SHORT 2
+#endif
 #define PCL_EMAX_LONG (NBR_CAP / 64)
 #define PCL_LONG_SCAN 16
 template <bool PCL>
