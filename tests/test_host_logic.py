@@ -307,3 +307,26 @@ def test_bench_command_line_defaults():
     assert a.mlp_reserve_cus is None and launch.parse(["--mlp-reserve-cus", "0"]).mlp_reserve_cus == 0   # None: one per shader engine
     b = launch.parse(["--gpus", "8", "--cloud", "voxel2mm", "--separate-encode", "--no-voxel-density", "--workload", "ensemble"])
     assert b.gpus == 8 and b.cloud == "voxel2mm" and b.separate_encode and b.no_voxel_density and b.workload == "ensemble"
+
+
+def test_bin_prior_dense_is_the_gaussian_logit_bump():
+    """ops.BinPrior.dense(): -0.5 ((k - pos) * inv_sigma)^2 in float32, these operations in this order (what the fused bin draw
+    generates in its epilogue); equal to synth.teacher_logits' array up to the rounding of its division."""
+    import torch
+    from cppf2_amd import ops, synth
+    rng = np.random.default_rng(0)
+    pos = (rng.random((50, 6)) * 36 - 2).astype(np.float32)
+    prior = ops.BinPrior(torch.from_numpy(pos), 1.0 / 0.6)
+    d = prior.dense(32).numpy()
+    inv = np.float32(1.0 / 0.6)
+    k = np.arange(32, dtype=np.float32)
+    z = (k[None, None, :] - pos[..., None]) * inv
+    assert d.dtype == np.float32 and d.shape == (50, 6, 32) and np.array_equal(d, (z * z) * np.float32(-0.5))
+    ref = -0.5 * ((k[None, None, :] - pos[..., None]) / np.float32(0.6)) ** 2
+    assert np.abs(d - ref).max() <= 4e-6 * np.abs(ref).max()
+    try:
+        ops.BinPrior(torch.zeros((4, 5)), 1.0)
+    except AssertionError:
+        pass
+    else:
+        raise AssertionError("a [T, 5] position array must be refused")
