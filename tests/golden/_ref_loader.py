@@ -14,8 +14,11 @@ functions call them:
 Nothing in this file travels to the GPU box as a dependency of tests: the
 fixtures it helps to generate are plain .npz data.
 """
+import contextlib
+import importlib
 import importlib.abc
 import importlib.machinery
+import os
 import sys
 import types
 
@@ -52,8 +55,14 @@ class _Stub(types.ModuleType):
 
 
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    # `src_shot` (the reference's unbuilt pybind11 module; this repository has a real package of that name) is stubbed only
+    # while load_reference() imports the reference
+    loading = False
+
     def find_spec(self, fullname, path, target=None):
         root = fullname.split(".")[0]
+        if root == "src_shot" and not _Finder.loading:
+            return None
         if root in _STUB_ROOTS or fullname == "scipy.misc":
             try:
                 # prefer a real install if there is one (PIL, tqdm, matplotlib)
@@ -76,14 +85,72 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+# Top-level names BOTH trees define.  The reference's `utils/` has no __init__.py (a namespace package), this repository's
+# `utils/` is a regular package and therefore wins whatever the order of sys.path is; `dataset`, `eval`, `train_*` and `src_shot`
+# exist at both roots too.  load_reference() imports the reference's modules with this repository's root taken OFF sys.path and
+# these names purged from sys.modules, and afterwards restores both, so that `cppf2_amd` (and this repository's shims) import as
+# usual while the returned namespace holds the reference's own module objects.
+_SHARED_NAMES = ("utils", "dataset", "eval", "train_dino", "train_shot", "src_shot", "demo")
+_REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_CACHE = None
+
+
+def _is_repo_root(p):
+    try:
+        return os.path.realpath(p or os.getcwd()) == os.path.realpath(_REPO_ROOT)
+    except OSError:
+        return False
+
+
+def _shared(name):
+    return name.split(".")[0] in _SHARED_NAMES
+
+
 def load_reference():
-    """Returns a namespace with the reference's hot-path callables."""
+    """Returns a namespace with the reference's hot-path callables and its modules (`ns.dataset`, `ns.eval`, `ns.train_dino`,
+    `ns.train_shot`, `ns.util`) -- all of them loaded from /root/reference, checked by file path."""
+    global _CACHE
+    if _CACHE is not None:
+        return _CACHE
     import torch
-    if REF_ROOT not in sys.path:
-        sys.path.insert(0, REF_ROOT)
     if not any(isinstance(f, _Finder) for f in sys.meta_path):
         sys.meta_path.insert(0, _Finder())
+    saved_modules = {k: sys.modules.pop(k) for k in list(sys.modules) if _shared(k)}
+    saved_path = list(sys.path)
+    sys.path[:] = [REF_ROOT] + [p for p in sys.path if p != REF_ROOT and not _is_repo_root(p)]
+    importlib.invalidate_caches()
+    _Finder.loading = True
+    ref_modules = {}
+    try:
+        ns = _import_reference(torch)
+    finally:
+        _Finder.loading = False
+        for k in [k for k in sys.modules if _shared(k)]:
+            ref_modules[k] = sys.modules.pop(k)
+        sys.modules.update(saved_modules)
+        sys.path[:] = saved_path
+        importlib.invalidate_caches()
+    ns._modules = ref_modules
+    _CACHE = ns
+    return ns
 
+
+@contextlib.contextmanager
+def reference_modules():
+    """Puts the reference's module objects back under their names in sys.modules for the duration of the block: needed where
+    the reference pickles its own functions by qualified name (multiprocessing in compute_degree_cm_mAP, utils/util.py:2771-2779)."""
+    ns = load_reference()
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if _shared(k)}
+    sys.modules.update(ns._modules)
+    try:
+        yield ns
+    finally:
+        for k in [k for k in sys.modules if _shared(k)]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def _import_reference(torch):
     import pytorch_lightning as pl
     pl.LightningModule = torch.nn.Module
     import hydra
@@ -104,7 +171,13 @@ def load_reference():
     import dataset
     import utils.util as util
 
+    import eval as ref_eval
+    for m in (train_dino, train_shot, dataset, util, ref_eval):
+        assert os.path.realpath(m.__file__).startswith(os.path.realpath(REF_ROOT) + os.sep), \
+            "%s resolved to %s, not to the reference" % (m.__name__, m.__file__)
+
     ns = types.SimpleNamespace()
+    ns.train_dino, ns.train_shot, ns.dataset, ns.eval = train_dino, train_shot, dataset, ref_eval
     ns.vote_center = train_dino.vote_center
     ns.vote_rotation = train_dino.vote_rotation
     ns.generate_target_pairs = dataset.generate_target_pairs
@@ -118,7 +191,6 @@ def load_reference():
 
     # eval.get_topk_dir hard-codes .cuda()/device='cuda' (eval.py:38-39):
     # run it on CPU by making .cuda() the identity and dropping device kwargs.
-    import eval as ref_eval
     _zeros = torch.zeros
 
     def get_topk_dir_cpu(*a, **k):

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
@@ -170,7 +171,7 @@ def main():
     shot_raw = rng.uniform(0, 1, (N, 352)).astype(np.float32)
     shot_raw /= np.linalg.norm(shot_raw, axis=-1, keepdims=True)
     cls_s, sc_s = ms(t(pc), t(idx[:64]), t(shot_raw), t(normal))
-    np.savez_compressed(os.path.join(HERE, "model_shot.npz"),
+    np.savez_compressed(os.path.join(OUT, "model_shot.npz"),
                         shot_raw=shot_raw, normal=normal, pc=pc, idx=idx[:64],
                         pred_cls=cls_s.numpy(), pred_scales=sc_s.numpy(),
                         **{"w::" + k: v.numpy() for k, v in ms.state_dict().items()})
@@ -180,7 +181,7 @@ def main():
     desc /= np.linalg.norm(desc, axis=-1, keepdims=True)
     cls_d, sc_d = md(t(pc), t(desc), t(idx[:64]))
     sd = md.state_dict()
-    np.savez_compressed(os.path.join(HERE, "model_dino.npz"),
+    np.savez_compressed(os.path.join(OUT, "model_dino.npz"),
                         desc=desc.astype(np.float16), pc=pc, idx=idx[:64],
                         pred_cls=md(t(pc), t(desc.astype(np.float16).astype(np.float32)), t(idx[:64]))[0].numpy(),
                         pred_scales=md(t(pc), t(desc.astype(np.float16).astype(np.float32)), t(idx[:64]))[1].numpy(),
@@ -188,7 +189,7 @@ def main():
                         shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
                         seed=np.int64(1))
 
-    np.savez_compressed(os.path.join(HERE, "small.npz"), **g)
+    np.savez_compressed(os.path.join(OUT, "small.npz"), **g)
 
     # ---- 5 deg / 5 cm criterion (utils/util.py:588-663) on seeded similarity transforms -------
     mr = np.random.RandomState(3)
@@ -211,7 +212,7 @@ def main():
         cid = 1 + i % 6
         for hv in (0, 1):
             table.append((i, cid, hv, *ref.util.compute_RT_degree_cm_symmetry(A[i], Bm[i], cid, hv, names)))
-    np.savez(os.path.join(HERE, "metric_5deg5cm.npz"), A=A, B=Bm, table=np.array(table))
+    np.savez(os.path.join(OUT, "metric_5deg5cm.npz"), A=A, B=Bm, table=np.array(table))
 
     # ---- example_data plumbing (config 1): backproject stats, utils/util.py:2586-2607 ------
     summ = {}
@@ -251,9 +252,9 @@ def main():
         up_top5_counts=out["up_top5_counts"].tolist(), right_top5_counts=out["right_top5_counts"].tolist(),
         up_counts_sha=sha(out["up_counts"]), right_counts_sha=sha(out["right_counts"]),
     )
-    np.savez_compressed(os.path.join(HERE, "full_scaled.npz"), scaled=scaled,
+    np.savez_compressed(os.path.join(OUT, "full_scaled.npz"), scaled=scaled,
                         up_counts=out["up_counts"], right_counts=out["right_counts"])
-    with open(os.path.join(HERE, "full_summary.json"), "w") as f:
+    with open(os.path.join(OUT, "full_summary.json"), "w") as f:
         json.dump(summ, f, indent=1)
     print(json.dumps(summ, indent=1)[:1500])
 

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 sys.path.insert(0, HERE)
 
 import make_golden as mg  # noqa: E402  (imports the reference through _ref_loader; main() is not run)
@@ -92,7 +93,7 @@ def main():
     logits[2, 0] = -80.0                    # all equal, large negative
     prob = torch.softmax(logits, -1)
     g.update(softmax_logits=logits.numpy(), softmax_prob=prob.numpy())
-    np.savez_compressed(os.path.join(HERE, "axes.npz"), **g)
+    np.savez_compressed(os.path.join(OUT, "axes.npz"), **g)
     print({k: getattr(v, "shape", None) for k, v in g.items()})
     for name in AXES:
         print(name, "T_est", g[name + "_T_est"], "up", g[name + "_up_top1"], "right", g[name + "_right_top1"])

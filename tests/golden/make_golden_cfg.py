@@ -11,6 +11,7 @@ import os
 import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 REF = "/root/reference/config"
 
 
@@ -21,6 +22,6 @@ def load(p):
 
 out = dict(config=load(os.path.join(REF, "config.yaml")), custom=load(os.path.join(REF, "custom.yaml")),
            category={os.path.basename(p)[:-5]: load(p) for p in sorted(glob.glob(os.path.join(REF, "category", "*.yaml")))})
-with open(os.path.join(HERE, "category_configs.json"), "w") as f:
+with open(os.path.join(OUT, "category_configs.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print(json.dumps(out["category"], indent=1))

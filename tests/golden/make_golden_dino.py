@@ -10,13 +10,13 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 sys.path.insert(0, HERE)
 from _ref_loader import load_reference  # noqa: E402
 
 
 def main():
-    load_reference()
-    import dataset as ref_dataset
+    ref_dataset = load_reference().dataset
     rng = np.random.RandomState(7)
     C, h, w, stride = 48, 9, 13, 4
     desc = rng.randn(1, C, h, w).astype(np.float32)
@@ -30,7 +30,7 @@ def main():
         r = ref_dataset.interpolate_features(torch.from_numpy(desc), torch.from_numpy(pts)[None], strides=stride,
                                              normalize=norm)
         out[name] = r[0].T.contiguous().numpy()          # [n, C], as DINOV2.forward returns it (dataset.py:79-80)
-    np.savez_compressed(os.path.join(HERE, "dino_interp.npz"), desc=desc, pts=pts, stride=np.int32(stride), **out)
+    np.savez_compressed(os.path.join(OUT, "dino_interp.npz"), desc=desc, pts=pts, stride=np.int32(stride), **out)
     print({k: v.shape for k, v in out.items()})
 
 

@@ -12,8 +12,9 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 sys.path.insert(0, HERE)
-from _ref_loader import load_reference  # noqa: E402
+from _ref_loader import load_reference, reference_modules  # noqa: E402
 
 
 def rand_rot(rng):
@@ -75,13 +76,14 @@ def main():
     results = make_results()
     names = ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
     thr = np.linspace(0, 1, 101)
-    with tempfile.TemporaryDirectory() as d:
+    # (the reference's worker function is pickled by name for its process pool: its modules must be importable by name there)
+    with tempfile.TemporaryDirectory() as d, reference_modules():
         iou_aps, pose_aps = ref.util.compute_degree_cm_mAP(copy.deepcopy(results), names, d, degree_thresholds=[5, 10, 15],
                                                            shift_thresholds=[5, 10, 15],
                                                            iou_3d_thresholds=thr,
                                                            iou_pose_thres=0.1, use_matches_for_pose=False, num_proc=2)
     # the call eval.py:400-411 makes: pose AP over the instances matched at 3-D IoU > 0.1
-    with tempfile.TemporaryDirectory() as d:
+    with tempfile.TemporaryDirectory() as d, reference_modules():
         iou_aps_m, pose_aps_m = ref.util.compute_degree_cm_mAP(copy.deepcopy(results), names, d, degree_thresholds=[5, 10, 15],
                                                                shift_thresholds=[5, 10, 15], iou_3d_thresholds=thr,
                                                                iou_pose_thres=0.1, use_matches_for_pose=True, num_proc=2)
@@ -110,7 +112,7 @@ def main():
         iou = ref.util.compute_3d_iou_new(RT1.copy(), RT2.copy(), s1.copy(), s2.copy(), 1, "laptop", "laptop")
         pairs.append(dict(RT1=RT1.copy(), RT2=RT2.copy(), s1=s1, s2=s2, cls="laptop", hv=1, iou=float(iou)))
     print("pair IoUs:", [round(p_["iou"], 4) for p_ in pairs])
-    with open(os.path.join(HERE, "map_results.pkl"), "wb") as f:
+    with open(os.path.join(OUT, "map_results.pkl"), "wb") as f:
         pickle.dump(dict(results=results, synset_names=names, pose_aps=pose_aps, iou_aps=iou_aps, iou_thresholds=thr,
                          pose_aps_matched=pose_aps_m, iou_aps_matched=iou_aps_m, iou_pairs=pairs), f, protocol=4)
     print(pose_aps[-1])

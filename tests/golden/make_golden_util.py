@@ -11,13 +11,12 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CPPF_GOLDEN_OUT", HERE)     # tests/test_golden_regen.py regenerates into a temp dir
 sys.path.insert(0, HERE)
 from _ref_loader import load_reference  # noqa: E402
 
 ref = load_reference()
-import dataset as ref_dataset  # noqa: E402  (the reference's: /root/reference is first on sys.path now)
-
-assert ref_dataset.__file__.startswith("/root/reference"), ref_dataset.__file__
+ref_dataset = ref.dataset       # the reference's module object (load_reference checks its file path)
 util = ref.util
 
 
@@ -55,7 +54,7 @@ def main():
     g["bbox_px"] = util.calculate_2d_projections(g["bbox_cam"], K)
     for n in ("rotx", "roty", "rotz"):
         g[n] = getattr(ref_dataset, n)(0.37)
-    np.savez_compressed(os.path.join(HERE, "util_helpers.npz"), **g)
+    np.savez_compressed(os.path.join(OUT, "util_helpers.npz"), **g)
     print("wrote util_helpers.npz:", {k: v.shape for k, v in g.items()})
 
 
