@@ -43,7 +43,7 @@ launch.use_tuned_gemms()                    # before torch initialises
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
-from cppf2_amd.benchlib import counters, evidence, report                       # noqa: E402
+from cppf2_amd.benchlib import counters, evidence, report, telemetry            # noqa: E402
 from cppf2_amd.benchlib.workloads import Cfg, DenseStep, EnsembleStep, Step     # noqa: E402
 
 
@@ -54,77 +54,358 @@ def host_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(args, step, res):
-    """`cpu_baseline` of the headline: the oracle (NumPy + C SHOT) timed on the host for a bounded sample of the same workload, and
-    how the GPU records of those scenes agree with it.  Returns (cpu_baseline, oracle_agreement)."""
-    from oracle import pipeline_oracle as PO          # the checker, timed as the CPU baseline (never the product path)
+# ======================================================================================================================
+# CPU legs -- the ONLY code that imports oracle/ (the checker; never the product path):
+#   * cpu_baseline: the oracle TIMED on the host for a bounded sequential sample of the workload (descriptors
+#     single-threaded like PCL and on all cores; matmuls and the get_topk_dir stage on all cores);
+#   * oracle_agreement: EVERY scene of rank 0's timed batch (and 8 voxel-density scenes, 8 ensemble instances) through the oracle,
+#     by a pool of fresh worker processes of this file (`bench.py --oracle-worker JOB`) started BEFORE this process initialises the
+#     GPU (never a re-exec), joined before the timed loops, compared after them.  The criterion is utils/util.py:588-663's
+#     (5 degrees / 5 cm) next to exact equality of the centre arg-max and the two rotation bins; every mismatch is attributed
+#     (bin draws at CDF edges from the MLP's arithmetic; a cone-edge flip inside the documented tanf tolerance) or reported as a defect.
+# ======================================================================================================================
+ORACLE_WORKER_ENV = {"OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1", "NUMEXPR_NUM_THREADS": "1"}
+PRIOR_INV_SIGMA = 1.0 / 0.6
+
+
+def product_prior(pc_canon, idx, nb=32):
+    """The teacher prior of the bench (workloads.Step: ops.BinPrior(pos, 1 / 0.6)) in NumPy: the same float32 operations in the
+    same order as BinPrior.dense() and the fused draw's epilogue, so the oracle sees the logits' prior bit for bit."""
+    f = np.float32
+    coords = pc_canon[idx[:, :2]].reshape(idx.shape[0], 6).astype(f)
+    pos = ((np.clip(coords, f(-0.5), f(0.5)) + f(0.5)) * f(31.0)).astype(f)
+    z = ((np.arange(nb, dtype=f)[None, None, :] - pos[..., None]) * f(np.float32(PRIOR_INV_SIGMA))).astype(f)
+    return ((z * z) * f(-0.5)).astype(f)
+
+
+def sha_arrays(arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def weights_sha(w):
+    return sha_arrays(w[k] for k in sorted(w))
+
+
+def seeded_weights(seed, dino=False):
+    """The bench's random-init weights as workloads.Step builds them (CPU generator, then .to(device)): NumPy state dict."""
+    from cppf2_amd.benchlib.workloads import Cfg
+    from cppf2_amd.models import BeyondCPPFDino, BeyondCPPFShot
+    torch.manual_seed(seed + (1 if dino else 0))
+    m = (BeyondCPPFDino if dino else BeyondCPPFShot)(Cfg()).eval()
+    return {k: v.detach().numpy() for k, v in m.state_dict().items()}
+
+
+def oracle_worker(job_path):
+    """`bench.py --oracle-worker JOB`: runs the job's tasks [(name, kind, cloud, scene id)] through the oracle, single-threaded
+    (the pool is the parallelism), and pickles {name: {scene id: record}} + the SHA-256 of the inputs it built for itself."""
+    import pickle
+    with open(job_path) as f:
+        job = json.load(f)
+    torch.set_num_threads(1)
+    from oracle import cppf_oracle as O
+    from oracle import pipeline_oracle as PO
+    from oracle import shot_oracle as S
     from cppf2_amd import synth
+    from cppf2_amd.benchlib.workloads import Cfg
+    seed, N, T, R = job["seed"], job["points"], job["tuples"], job["rots"]
+    trig = (np.array(job["cos"], np.float32), np.array(job["sin"], np.float32))
+    wsh = seeded_weights(seed)
+    out = {"weights_sha": {"shot": weights_sha(wsh)}, "results": {}, "pid": os.getpid()}
+    wd = desc_all = None
+    ens = [t for t in job["tasks"] if t[1] == "ensemble"]
+    if ens:
+        wd = seeded_weights(seed, dino=True)
+        out["weights_sha"]["dino"] = weights_sha(wd)
+        g = torch.Generator(device="cpu").manual_seed(job["desc_seed"])
+        # the first rows of the batch's descriptor array (EnsembleStep: randn((B N, 1024)) of this generator, normalised)
+        nb = max(t[3] - job["scene0"] for t in ens) + 1
+        desc_all = torch.nn.functional.normalize(torch.randn((job["batch"] * N, 1024), generator=g)[:nb * N], dim=-1).numpy()
+    for name, kind, cloud, sid in job["tasks"]:
+        t0 = time.perf_counter()
+        sc = (synth.make_scene_voxel2mm if cloud == "voxel2mm" else synth.make_scene)(seed, sid, N)
+        if kind == "shot":
+            tm = {}
+            o = PO.run_scene_full(wsh, sc["pc"], seed, sid, T, res=Cfg.res, num_rots=R, trig=trig, topk_impl="c", topk_threads=1,
+                                  prior_fn=(lambda idx, sc=sc: product_prior(sc["pc_canon"], idx)) if job["prior"] else None, timings=tm)
+            rec = {k: o[k] for k in ("argmax", "T_est", "R_est", "up_idx", "right_idx")}
+            rec.update(kept=int(o["pairs_mask"].sum()), bins=o["bins"].astype(np.uint8), pred_scale=o.get("pred_scale"), timings=tm,
+                       up_margin=float(np.diff(np.sort(o["up_counts"])[-2:])[0]), right_margin=float(np.diff(np.sort(o["right_counts"])[-2:])[0]))
+        else:
+            b = sid - job["scene0"]
+            idx = O.sample_tuples(seed, sid, T, 5, N).astype(np.int64)
+            shot_feat, normal, _, _ = S.compute_ex(sc["pc"], Cfg.res * 10, Cfg.res * 10, pcl_arithmetic=True)
+            shot_feat, normal = np.nan_to_num(shot_feat, nan=0.0), np.nan_to_num(normal, nan=0.0)
+            prior = product_prior(sc["pc_canon"], idx)
+            desc = desc_all[b * N:(b + 1) * N]
+            per_model = []
+            for m, (lg, scl) in enumerate((PO.mlp_dino(wd, sc["pc"], desc, idx), PO.mlp_shot(wsh, sc["pc"], idx, shot_feat, normal))):
+                per_model.append(((lg + prior).astype(np.float32), scl, O.philox_uniform(seed, sid, 1 + m, T, 6)))
+            o = PO.run_instance_ensemble(sc["pc"], idx, per_model, Cfg.up, Cfg.right, Cfg.front, Cfg.res, num_rots=R, y_only=True,
+                                         trig=trig, topk_impl="c", topk_threads=1)
+            rec = dict(pick=o["pick"], desc_sha=sha_arrays([desc]),
+                       models=[{k: om[k] for k in ("argmax", "up_idx", "right_idx", "loss", "T_est", "R_est")} for om in o["models"]])
+        rec["seconds"] = time.perf_counter() - t0
+        out["results"].setdefault(name, {})[sid] = rec
+    tmp = job["out"] + ".tmp"
+    with open(tmp, "wb") as f:
+        pickle.dump(out, f)
+    os.replace(tmp, job["out"])
+    return 0
+
+
+class OraclePool:
+    """The agreement check's worker processes.  add() tasks, start() BEFORE the GPU is initialised, join() before the timed loops."""
+
+    def __init__(self, args):
+        self.args, self.tasks, self.procs, self.dir, self.t0, self.wall, self.error = args, [], [], None, None, None, None
+        self.extra = {}
+
+    def add(self, name, kind, cloud, scene_ids):
+        self.tasks += [(name, kind, cloud, int(s)) for s in scene_ids]
+
+    @staticmethod
+    def worker_cap():
+        cap = max(1, host_cores() - 2)
+        try:
+            with open("/proc/meminfo") as f:
+                avail_kb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable"))
+            cap = min(cap, max(1, int(avail_kb / 1e6 * 0.5 / 1.5)))       # ~1 GB resident per worker; half of what is free
+        except (OSError, StopIteration, ValueError):
+            pass
+        return cap
+
+    def start(self, **common):
+        import subprocess
+        import tempfile
+        if not self.tasks:
+            return
+        self.dir = tempfile.mkdtemp(prefix="cppf_oracle_pool_")
+        w = min(len(self.tasks), self.worker_cap())
+        # longest tasks first, dealt round-robin (ensemble instances run both models: ~2.5 x a scene)
+        order = sorted(self.tasks, key=lambda t: 0 if t[1] == "ensemble" else 1)
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "HSA_TOOLS")) and k != "LD_PRELOAD"}
+        env.update(ORACLE_WORKER_ENV)
+        self.t0 = time.perf_counter()
+        for i in range(w):
+            job = dict(common, tasks=order[i::w], out=os.path.join(self.dir, "w%d.pkl" % i))
+            jp = os.path.join(self.dir, "w%d.json" % i)
+            with open(jp, "w") as f:
+                json.dump(job, f)
+            self.procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-worker", jp], env=env,
+                                                stdout=subprocess.DEVNULL, stderr=open(os.path.join(self.dir, "w%d.err" % i), "w")),
+                               job["out"], i))
+
+    def join(self, timeout=900.0):
+        """Blocks until every worker has exited (each is waited for by its own PID).  Returns {name: {scene id: record}}."""
+        import pickle
+        import shutil
+        import subprocess
+        if not self.procs:
+            return {}
+        merged, shas, failed = {}, [], []
+        deadline = time.perf_counter() + timeout
+        for p_, out, i in self.procs:
+            try:
+                rc = p_.wait(timeout=max(1.0, deadline - time.perf_counter()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                p_.wait()
+                rc = -9
+            if rc != 0 or not os.path.exists(out):
+                try:
+                    with open(os.path.join(self.dir, "w%d.err" % i)) as f:
+                        tail = f.read()[-400:]
+                except OSError:
+                    tail = ""
+                failed.append("worker %d rc %s: %s" % (i, rc, tail.strip().replace("\n", " | ")))
+                continue
+            with open(out, "rb") as f:
+                r = pickle.load(f)
+            shas.append(r["weights_sha"])
+            for name, d in r["results"].items():
+                merged.setdefault(name, {}).update(d)
+        self.wall = time.perf_counter() - self.t0
+        self.extra = {"workers": len(self.procs), "wall_s": round(self.wall, 2), "worker_weights_sha": shas[0] if shas else None,
+                      "workers_agree_on_weights": all(s_ == shas[0] for s_ in shas) if shas else None}
+        if failed:
+            self.error = "; ".join(failed)[:1500]
+        shutil.rmtree(self.dir, ignore_errors=True)
+        return merged
+
+
+def _rt(R, t):
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = R, t
+    return m
+
+
+def agreement_shot(step, res, gpu_bins, oracle, pool, cloud, prior=True):
+    """GPU records of `step`'s scenes against the pool's oracle records (`oracle`: {scene id: record}).  Mismatching scenes are
+    re-voted HERE by the oracle from the GPU's own bin draws: equal then = the difference comes from bin draws (the MLP's
+    arithmetic at a CDF edge), not from the voting kernels."""
+    from oracle import cppf_oracle as O
+    from cppf2_amd.benchlib.workloads import Cfg
     from cppf2_amd.metrics import rt_degree_cm
+    a = step.args
+    n = 0
+    eq = dict(centre_argmax_equal=0, up_bin_equal=0, right_bin_equal=0, kept_count_equal=0, translation_bit_equal=0)
+    errs, bins_diff, mism, defects = [], 0, [], []
+    secs = []
+    for b in range(step.B):
+        o = oracle.get(step.scene0 + b)
+        if o is None:
+            continue
+        n += 1
+        secs.append(o["seconds"])
+        same = (int(res["argmax"][b]) == o["argmax"], int(res["up_idx"][b]) == o["up_idx"], int(res["right_idx"][b]) == o["right_idx"])
+        eq["centre_argmax_equal"] += same[0]
+        eq["up_bin_equal"] += same[1]
+        eq["right_bin_equal"] += same[2]
+        eq["kept_count_equal"] += int(res["kept"][b]) == o["kept"]
+        eq["translation_bit_equal"] += bool(np.array_equal(res["t"][b], np.asarray(o["T_est"], dtype=res["t"].dtype)))
+        errs.append(rt_degree_cm(_rt(res["R"][b], res["t"][b]), _rt(o["R_est"], o["T_est"]), "bottle", clip=True))
+        nd = int((gpu_bins[b] != o["bins"]).sum())
+        bins_diff += nd
+        if not all(same):
+            # attribute: the oracle's voting from the GPU's bins (one-hot logits draw exactly those bins)
+            sc = step.scenes[b]
+            idx = O.sample_tuples(a.seed, step.scene0 + b, step.T, 5, step.N).astype(np.int64)
+            onehot = np.full((step.T, 6, 32), -1e4, np.float32)
+            np.put_along_axis(onehot, gpu_bins[b][:, :, None].astype(np.int64), 0.0, -1)
+            u = O.philox_uniform(a.seed, step.scene0 + b, 1, step.T, 6)
+            v = O.run_scene(sc["pc"], idx, onehot, None, u, Cfg.up, Cfg.right, Cfg.front, Cfg.res, num_rots=a.rots,
+                            trig=(step.pipe.cs.cpu().numpy(), step.pipe.sn.cpu().numpy()), topk_impl="c")
+            again = (int(res["argmax"][b]) == v["argmax"], int(res["up_idx"][b]) == v["up_idx"], int(res["right_idx"][b]) == v["right_idx"])
+            margins = {ax: float(np.diff(np.sort(v[ax + "_counts"])[-2:])[0]) for ax in ("up", "right")}
+            if all(again):
+                why = "bin draws: %d of %d draws differ from the oracle's (MLP arithmetic at a CDF edge); with the GPU's bins the oracle votes the same record" % (nd, step.T * 6)
+            elif again[0] and all(again[i] or margins[ax] <= 4.0 for i, ax in ((1, "up"), (2, "right"))):
+                why = "cone-edge flip: rotation-bin runner-up within %s votes of the winner (documented tanf tolerance, <= 4)" % margins
+            else:
+                why = "DEFECT: the oracle, voting from the GPU's own bins, disagrees (argmax/up/right equal: %s)" % (again,)
+                defects.append(step.scene0 + b)
+            mism.append({"scene": step.scene0 + b, "equal(argmax, up, right)": [bool(x) for x in same], "bins_differing": nd, "why": why})
+    out = dict(scenes=n, cloud=cloud, prior=prior,
+               match_5deg5cm=float(np.mean([e[0] <= 5 and e[1] <= 5 for e in errs])) if errs else None,
+               max_rot_err_deg=float(max(e[0] for e in errs)) if errs else None, max_shift_cm=float(max(e[1] for e in errs)) if errs else None,
+               **eq, bin_draws=n * step.T * 6, bin_draws_differing=bins_diff, mismatches=mism, defects=defects,
+               oracle_seconds_per_scene={"mean": round(float(np.mean(secs)), 2), "max": round(float(np.max(secs)), 2)} if secs else None,
+               criterion="utils/util.py:588-663 (5 deg / 5 cm, bottle = up-symmetric) between the GPU record and the oracle's; "
+                         "exact equality of the vote-grid arg-max, the two sphere bins, the kept-pair count, the translation")
+    out.update(pool.extra)
+    if pool.error:
+        out["pool_error"] = pool.error
+    return out
+
+
+def cpu_baseline(args, step, pool_scenes=None):
+    """`cpu_baseline` of the headline: the oracle TIMED on the host for a bounded sequential sample of the same workload --
+    one scene at a time like the reference's loop (eval.py:153), every stage at the CPU path's best: descriptors single-threaded
+    like PCL's estimators (value) and on all cores (shot_all_cores), matmuls on all cores (BLAS), the get_topk_dir stage in C +
+    OpenMP on all cores.  pool_scenes: (scenes, wall seconds, workers) of the agreement pool = the all-cores THROUGHPUT mode
+    (independent scenes side by side, one thread each)."""
+    from oracle import pipeline_oracle as PO          # the checker, timed as the CPU baseline (never the product path)
+    from oracle import shot_oracle as S
+    from oracle import vote_oracle as V
+    from cppf2_amd.benchlib.workloads import Cfg
     weights = {k: v.detach().cpu().numpy() for k, v in step.model.state_dict().items()}
     trig = (step.pipe.cs.cpu().numpy(), step.pipe.sn.cpu().numpy())
+    tm = {}
     t0 = time.perf_counter()
-    outs = []
     for b in range(args.cpu_scenes):
         sc = step.scenes[b]
-        outs.append(PO.run_scene_full(weights, sc["pc"], args.seed, step.scene0 + b, args.tuples, res=Cfg.res, num_rots=args.rots,
-                                      trig=trig, prior_fn=lambda idx, sc=sc: synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6)))
+        PO.run_scene_full(weights, sc["pc"], args.seed, step.scene0 + b, args.tuples, res=Cfg.res, num_rots=args.rots, trig=trig,
+                          prior_fn=lambda idx, sc=sc: product_prior(sc["pc_canon"], idx), shot_threads=1, topk_impl="c",
+                          topk_threads=0, timings=tm)
     dt = time.perf_counter() - t0
-    cpu = dict(value=args.cpu_scenes / dt, unit="scenes/s", cores=host_cores(), kind="port",
-               sample="%d scene(s) of the same workload (first scenes of rank 0's batch), NumPy oracle + C SHOT "
-                      "oracle (SHOT single-threaded like PCL, matmuls on all cores), %.1f s" % (args.cpu_scenes, dt),
+    t1 = time.perf_counter()
+    for b in range(args.cpu_scenes):
+        S.compute_ex(step.scenes[b]["pc"], Cfg.res * 10, Cfg.res * 10, pcl_arithmetic=True, threads=0)
+    dt_shot_all = time.perf_counter() - t1
+    n = args.cpu_scenes
+    shot1 = tm.get("shot_descriptor", 0.0)
+    cpu = dict(value=n / dt, unit="scenes/s", cores=host_cores(), kind="port",
+               sample="%d scene(s) of the same workload (first scenes of rank 0's batch), one at a time: C SHOT oracle single-threaded "
+                      "like PCL, NumPy matmuls on all cores (BLAS), decode / centre vote / back-vote in NumPy (1 thread), get_topk_dir "
+                      "in C + OpenMP on all cores; %.1f s" % (n, dt),
                threads_per_stage={"shot_descriptor (C oracle, like PCL)": 1, "mlp_matmuls (NumPy -> BLAS)": "all cores (BLAS default)",
-                                  "decode / votes / back-vote / rotation bins (NumPy)": 1})
+                                  "decode / centre vote / back-vote (NumPy)": 1,
+                                  "get_topk_dir (C + OpenMP, oracle/vote_oracle.c)": V.max_threads()},
+               seconds_per_scene_by_stage={k: round(v / n, 4) for k, v in tm.items()},
+               shot_single_thread_s_per_scene=round(shot1 / n, 4), shot_all_cores_s_per_scene=round(dt_shot_all / n, 4),
+               shot_all_cores_threads=S.max_threads(),
+               value_with_shot_on_all_cores=n / max(dt - shot1 + dt_shot_all, 1e-9))
+    if pool_scenes:
+        ns, wall, workers = pool_scenes
+        cpu["all_cores_pool"] = {"value": ns / wall, "unit": "scenes/s", "scenes": ns, "workers": workers, "threads_per_worker": 1,
+                                 "wall_s": round(wall, 2),
+                                 "note": "the agreement check's oracle runs: independent scenes side by side, one single-threaded "
+                                         "process each (start-up and imports included; concurrent with this run's rocprofv3 counter "
+                                         "passes) -- the host's throughput mode, a lower bound"}
+    return cpu
 
-    def rt(R, t):
-        m = np.eye(4)
-        m[:3, :3], m[:3, 3] = R, t
-        return m
-    errs = [rt_degree_cm(rt(res["R"][b], res["t"][b]), rt(o["R_est"], o["T_est"]), "bottle", clip=True) for b, o in enumerate(outs)]
-    agree = dict(scenes=len(outs), match_5deg5cm=float(np.mean([e[0] <= 5 and e[1] <= 5 for e in errs])),
-                 max_rot_err_deg=float(max(e[0] for e in errs)), max_shift_cm=float(max(e[1] for e in errs)),
-                 centre_argmax_equal=int(sum(int(res["argmax"][b]) == o["argmax"] for b, o in enumerate(outs))),
-                 up_bin_equal=int(sum(int(res["up_idx"][b]) == o["up_idx"] for b, o in enumerate(outs))),
-                 right_bin_equal=int(sum(int(res["right_idx"][b]) == o["right_idx"] for b, o in enumerate(outs))))
-    return cpu, agree
+
+def agreement_ensemble(step, both, pick, oracle, pool):
+    """--workload ensemble: both models' records and the selection against the pool's run_instance_ensemble results."""
+    n, outs, bs = 0, [], []
+    for b in range(step.B):
+        o = oracle.get(step.scene0 + b)
+        if o is not None:
+            outs.append(o)
+            bs.append(b)
+            n += 1
+    N = step.N
+    desc_ok = all(o["desc_sha"] == sha_arrays([step.desc[b * N:(b + 1) * N].cpu().numpy()]) for b, o in zip(bs, outs))
+    agree = dict(instances=n, descriptors_identical_to_the_gpu_run=bool(desc_ok),
+                 pick_equal=int(sum(int(pick[b]) == o["pick"] for b, o in zip(bs, outs))),
+                 centre_argmax_equal=[int(sum(int(both[m]["argmax"][b]) == o["models"][m]["argmax"] for b, o in zip(bs, outs))) for m in (0, 1)],
+                 up_bin_equal=[int(sum(int(both[m]["up_idx"][b]) == o["models"][m]["up_idx"] for b, o in zip(bs, outs))) for m in (0, 1)],
+                 right_bin_equal=[int(sum(int(both[m]["right_idx"][b]) == o["models"][m]["right_idx"] for b, o in zip(bs, outs))) for m in (0, 1)],
+                 max_abs_loss_difference=float(max(abs(float(step.pipe.losses[m][b]) - o["models"][m]["loss"])
+                                                   for b, o in zip(bs, outs) for m in (0, 1))) if n else None,
+                 oracle_seconds_per_instance=round(float(np.mean([o["seconds"] for o in outs])), 2) if n else None)
+    agree.update(pool.extra)
+    if pool.error:
+        agree["pool_error"] = pool.error
+    return agree
 
 
 def cpu_baseline_ensemble(args, step, both, pick):
-    """The same for --workload ensemble: both models' NumPy forward + run_instance_ensemble per instance."""
+    """The same for --workload ensemble: both models' NumPy forward + run_instance_ensemble per instance (sequential sample, timed);
+    the agreement over 8 instances comes from the worker pool (main() attaches it as step.pool_agreement)."""
     from oracle import pipeline_oracle as PO          # the checker, timed as the CPU baseline (never the product path)
     from oracle import cppf_oracle as O
     from oracle import shot_oracle as S
-    from cppf2_amd import synth
+    from cppf2_amd.benchlib.workloads import Cfg
     N, T, R = step.N, step.T, args.rots
     wd = {k_: v_.detach().cpu().numpy() for k_, v_ in step.dino.state_dict().items()}
     wsh = {k_: v_.detach().cpu().numpy() for k_, v_ in step.model.state_dict().items()}
     trig = (step.pipe.cs.cpu().numpy(), step.pipe.sn.cpu().numpy())
     n_cpu = min(args.cpu_scenes, 2)
     t0 = time.perf_counter()
-    outs = []
     for b in range(n_cpu):
         sc = step.scenes[b]
         idx = O.sample_tuples(args.seed, step.scene0 + b, T, 5, N).astype(np.int64)
         shot_feat, normal, _, _ = S.compute_ex(sc["pc"], Cfg.res * 10, Cfg.res * 10, pcl_arithmetic=True)
         shot_feat, normal = np.nan_to_num(shot_feat, nan=0.0), np.nan_to_num(normal, nan=0.0)
-        prior = synth.teacher_logits(sc["pc_canon"], idx, 32, 0.6)
+        prior = product_prior(sc["pc_canon"], idx)
         desc = step.desc[b * N:(b + 1) * N].cpu().numpy()
         per_model = []
         for m, (lg, scl) in enumerate((PO.mlp_dino(wd, sc["pc"], desc, idx), PO.mlp_shot(wsh, sc["pc"], idx, shot_feat, normal))):
             per_model.append(((lg + prior).astype(np.float32), scl, O.philox_uniform(args.seed, step.scene0 + b, 1 + m, T, 6)))
-        outs.append(PO.run_instance_ensemble(sc["pc"], idx, per_model, Cfg.up, Cfg.right, Cfg.front, Cfg.res, num_rots=R,
-                                             y_only=True, trig=trig))
+        PO.run_instance_ensemble(sc["pc"], idx, per_model, Cfg.up, Cfg.right, Cfg.front, Cfg.res, num_rots=R, y_only=True, trig=trig,
+                                 topk_impl="c", topk_threads=0)
     dtc = time.perf_counter() - t0
     cpu = dict(value=n_cpu / dtc, unit="instances/s", cores=host_cores(), kind="port",
-               sample="%d instance(s) of the same workload, both models (NumPy oracle: mlp_dino + mlp_shot + run_instance_ensemble; "
-                      "C SHOT oracle), %.1f s" % (n_cpu, dtc),
-               threads_per_stage={"shot_descriptor": 1, "mlp_matmuls": "BLAS default (all cores)", "votes_and_bins": 1})
-    agree = dict(instances=n_cpu,
-                 pick_equal=int(sum(int(pick[b]) == o["pick"] for b, o in enumerate(outs))),
-                 centre_argmax_equal=[int(sum(int(both[m]["argmax"][b]) == o["models"][m]["argmax"] for b, o in enumerate(outs))) for m in (0, 1)],
-                 up_bin_equal=[int(sum(int(both[m]["up_idx"][b]) == o["models"][m]["up_idx"] for b, o in enumerate(outs))) for m in (0, 1)],
-                 max_abs_loss_difference=float(max(abs(float(step.pipe.losses[m][b]) - o["models"][m]["loss"])
-                                                   for b, o in enumerate(outs) for m in (0, 1))))
-    return cpu, agree
+               sample="%d instance(s) of the same workload, one at a time, both models (NumPy oracle: mlp_dino + mlp_shot + "
+                      "run_instance_ensemble; C SHOT oracle single-threaded like PCL; get_topk_dir in C + OpenMP), %.1f s" % (n_cpu, dtc),
+               threads_per_stage={"shot_descriptor": 1, "mlp_matmuls": "BLAS default (all cores)", "decode / votes (NumPy)": 1,
+                                  "get_topk_dir (C + OpenMP)": "all cores"})
+    return cpu, getattr(step, "pool_agreement", None)
 
 
 class Timer:
@@ -185,7 +466,7 @@ def completion_intervals(ends, group=1):
             "p05": round(d[int(0.05 * len(d))], 4), "p95": round(d[int(0.95 * len(d))], 4), "steps_per_interval": group}
 
 
-def run_other_workload(args, rank, world, dev, backend, timer):
+def run_other_workload(args, rank, world, dev, backend, timer, pool, tel):
     """--workload ensemble | dense64k: single-stream loop with stage events; ensemble also its two-stream batch mode."""
     step = EnsembleStep(args, rank, world, dev) if args.workload == "ensemble" else DenseStep(args, rank, world, dev)
     step.prepare_events()
@@ -193,8 +474,10 @@ def run_other_workload(args, rank, world, dev, backend, timer):
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step.run()
+    oracle_out = pool.join()               # before anything is timed
     sampled = sampled_steps(args.steps, Step.EVENT_SLOTS)
-    dt1, mine, evs = timer.loop(args.steps, lambda i: step.run(timed=sampled.get(i)))      # single stream: stage events
+    with tel.window("single_stream_loop", torch.cuda.synchronize):
+        dt1, mine, evs = timer.loop(args.steps, lambda i: step.run(timed=sampled.get(i)))      # single stream: stage events
     step.two = None
     dt = dt1
     if args.workload == "ensemble" and not args.single_stream:
@@ -210,7 +493,8 @@ def run_other_workload(args, rank, world, dev, backend, timer):
         step.ops.mlp_reserve_cus(args.mlp_reserve_cus)
         for _ in range(max(2, args.warmup)):
             step.run_two_streams(streams)
-        dt, mine, _ = timer.loop(args.steps, lambda i: step.run_two_streams(streams))
+        with tel.window("two_stream_loop", torch.cuda.synchronize):
+            dt, mine, _ = timer.loop(args.steps, lambda i: step.run_two_streams(streams))
         step.ops.mlp_reserve_cus(0)
         same = bool(torch.equal(step.pipe.selected, ref_sel) and torch.equal(step.pipe.result_slots, ref_slots))
         step.two = {"streams": 2, "mlp_reserved_cus": args.mlp_reserve_cus, "records_identical_to_single_stream": same, "value_single_stream": step.B * world * args.steps / dt1,
@@ -219,16 +503,46 @@ def run_other_workload(args, rank, world, dev, backend, timer):
                             "for the DINO scale; per-stage times come from the single-stream loop of the same run"}
     rank_ms = timer.per_rank(mine, args.steps)
     if rank == 0:
+        power = tel.finish()
+        if args.workload == "ensemble" and oracle_out.get("ensemble"):
+            both = [step.pipe.results_to_numpy(step.pipe.result_slots[m]) for m in (0, 1)]
+            pick = step.pipe.results_to_numpy(step.pipe.selected)["pad_"][:, 0]
+            step.pool_agreement = agreement_ensemble(step, both, pick, oracle_out["ensemble"], pool)
+            sha = {"dino": weights_sha({k: v.detach().cpu().numpy() for k, v in step.dino.state_dict().items()}),
+                   "shot": weights_sha({k: v.detach().cpu().numpy() for k, v in step.model.state_dict().items()})}
+            step.pool_agreement["weights_identical_to_the_gpu_run"] = bool(pool.extra.get("worker_weights_sha") == sha)
         if args.workload == "ensemble":
             line = report.report_ensemble(args, step, dt, evs, world, backend, cpu_fn=cpu_baseline_ensemble, rank_ms=rank_ms)
         else:
             line = report.report_dense(args, step, dt, evs, world, backend, rank_ms=rank_ms)
+        line["roofline"]["power"] = power
         print(json.dumps(line))
         return 0 if line.get("ok", True) else 3
     return 0
 
 
+def start_oracle_pool(args, rank, world):
+    """The agreement check's workers -- started before anything initialises the GPU.  Returns an OraclePool (maybe empty)."""
+    pool = OraclePool(args)
+    if rank != 0 or world != 1 or args.cpu_scenes <= 0 or args.agreement_scenes <= 0 or args.counter_child:
+        return pool
+    B = args.scenes_per_gpu
+    if args.workload == "shot":
+        pool.add("headline", "shot", args.cloud, range(min(B, args.agreement_scenes)))
+        if args.cloud == "synthetic" and not args.no_voxel_density:
+            pool.add("voxel2mm", "shot", "voxel2mm", range(min(B, args.agreement_voxel_scenes)))
+    elif args.workload == "ensemble":
+        pool.add("ensemble", "ensemble", "synthetic", range(min(B, args.agreement_voxel_scenes)))
+    ang = torch.arange(args.rots).float() / args.rots * 2 * np.pi          # ops.rotation_table: CPU torch, then copied to the device
+    pool.start(seed=args.seed, points=args.points, tuples=65536 if args.workload == "dense64k" else args.tuples, rots=args.rots,
+               prior=True, cos=[float(x) for x in torch.cos(ang)], sin=[float(x) for x in torch.sin(ang)], scene0=0, batch=B,
+               desc_seed=args.seed + 17)
+    return pool
+
+
 def main():
+    if "--oracle-worker" in sys.argv:
+        sys.exit(oracle_worker(sys.argv[sys.argv.index("--oracle-worker") + 1]))
     args = launch.parse()
     if args.workload == "dense64k" and "--scenes-per-gpu" not in sys.argv:
         args.scenes_per_gpu = 16
@@ -244,7 +558,7 @@ def main():
         sys.exit(2)
     if args.counter_child:              # a child of collect_counters: the bare single-stream loop, nothing else
         args.single_stream = args.no_reference_order = args.no_native_arith = args.no_f16x2 = args.no_evidence = args.no_counters = True
-        args.no_voxel_density = True
+        args.no_voxel_density = args.no_prior_variants = args.no_launch_power = True
         args.cpu_scenes = 0
     COUNTERS = counters.COUNTERS
     profiled = any(k_.startswith(("ROCP_", "ROCPROF")) for k_ in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -252,6 +566,9 @@ def main():
         # this process is itself being profiled (the tool's library is loaded and has initialised the GPU): no children from here
         args.no_counters = True
         COUNTERS["reason"] = "running under a profiler: the counter passes are started by unprofiled runs only"
+    # CPU workers of the whole-batch agreement check and the power / clock sampler: fresh children, started before the GPU is touched
+    pool = start_oracle_pool(args, rank, world)
+    tel = telemetry.Telemetry.start() if (rank == 0 and not args.counter_child and not profiled) else telemetry.Telemetry()
     counter_children = 0
     if world == 1 and rank == 0 and not args.no_counters and not launch.cdist_forced():
         # BEFORE this process initialises the GPU: fresh children under rocprofv3, one counter pass each (one rank only: a rank of
@@ -274,6 +591,7 @@ def main():
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     counters.set_device_cus(torch.cuda.get_device_properties(dev).multi_processor_count)
+    tel.attach(torch.cuda.get_device_properties(dev))
     affinity = launch.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     from cppf2_amd import dist as cdist
     backend = None
@@ -290,7 +608,7 @@ def main():
         _models.MLP_ARITH = args.mlp_arith
     if args.workload in ("ensemble", "dense64k"):
         assert _models.MLP_ARITH in ("split", "split16"), "--workload %s runs the library's kernels (split arithmetic)" % args.workload
-        rc = run_other_workload(args, rank, world, dev, backend, timer)
+        rc = run_other_workload(args, rank, world, dev, backend, timer, pool, tel)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         sys.exit(rc)
@@ -310,6 +628,12 @@ def main():
     torch.cuda.synchronize()        # kernel attributes -- so that even --warmup 0 times steady-state steps
     for _ in range(args.warmup):
         step.run()
+
+    # the oracle workers' results (they ran beside the counter passes and the set-up above): joined BEFORE anything is timed
+    oracle_out = pool.join()
+    torch.cuda.synchronize()
+    with tel.window("idle"):
+        time.sleep(0.5 if tel.proc is not None else 0.0)
 
     # one completion event per step of the headline loops (recorded on the step's stream right after its last launch): the
     # intervals between consecutive completions are the per-step figures of the line (step_interval_ms)
@@ -357,7 +681,7 @@ def main():
     # single-stream loop of rounds 1-3 is timed right after it with the same protocol (value_single_stream); --single-stream makes
     # it the headline.
     two = None
-    dt_single = None
+    dt_single = dt_noprior = dt_arrayprior = None
     if not args.single_stream:
         ns = max(2, int(args.streams))
         others = [Step(args, rank, world, dev, scene_shift=j * args.scenes_per_gpu * world) for j in range(1, ns)]
@@ -382,21 +706,45 @@ def main():
                 with mode.next() as s_:
                     s_.run()
             torch.cuda.synchronize()
-            dt, mine, evs, ends = timed_loop(args.steps, pair=mode)
+            with tel.window("two_stream_loop"):
+                dt, mine, evs, ends = timed_loop(args.steps, pair=mode)
         pair = (all_steps, streams)
         intervals = completion_intervals(ends, group=len(streams))
         same = bool(all(torch.equal(s_.pipe.results, r_) for s_, r_ in zip(pair[0], refs)))
         distinct = bool(all(not torch.equal(refs[0], r_) for r_ in refs[1:]))
-        dt_single, _, evs_single, ends_single = timed_loop(args.steps)
+        with tel.window("single_stream_loop"):
+            dt_single, _, evs_single, ends_single = timed_loop(args.steps)
         intervals_single = completion_intervals(ends_single)
         two = {"streams": ns, "mlp_reserved_cus": args.mlp_reserve_cus, "records_identical_to_single_stream": same, "pipelines_hold_different_scenes": distinct,
                "note": "steps alternate between two HIP streams with double-buffered state; the pipelines hold different scene batches, and "
                        "each one's records are compared byte for byte with what the same pipeline produced alone on one stream in this "
                        "run; per-stage times of the headline are measured on the stage's own stream while the other stream's kernels "
                        "share the chip (per_stage_ms_two_streams; per_stage_ms: the same stages alone)"}
+        # the same loop (batch mode, same protocol) WITHOUT the teacher prior -- what a trained checkpoint runs: the reference has no
+        # prior (eval.py:225-235); the bench's random-init weights need one for votes to cluster -- and with the prior as a
+        # [T, 6, 32] array (rounds 1-4; ADVICE r5: the generator form removed 983 MB of reads per step from the timed region)
+        if report.FUSED_DRAW and not args.no_prior_variants and world == 1 and not args.array_prior:
+            def prior_variant(form):
+                for s_ in all_steps:
+                    s_.prior = None if form == "none" else s_.prior_dense
+                    s_.run()
+                with BatchMode(all_steps, device=dev, reserve_cus=args.mlp_reserve_cus, streams=streams) as m_:
+                    for _ in range(2 * ns):
+                        with m_.next() as s_:
+                            s_.run()
+                    torch.cuda.synchronize()
+                    return timed_loop(args.steps, sample=False, pair=m_)[0]
+            dt_noprior = prior_variant("none")
+            dt_arrayprior = prior_variant("array")
+            for s_ in all_steps:
+                s_.prior, s_._prior_dense = s_.teacher, None
+            step.run()
+            torch.cuda.synchronize()
+            assert torch.equal(step.pipe.results, refs[0]), "records changed after the prior-variant loops"
         del others
     else:
-        dt, mine, evs, ends = timed_loop(args.steps)
+        with tel.window("single_stream_loop"):
+            dt, mine, evs, ends = timed_loop(args.steps)
         intervals = completion_intervals(ends)
         intervals_single = None
         evs_single = evs
@@ -438,7 +786,11 @@ def main():
                              for i in range(r3_.shape[0]))),
                          "max_abs_scale_difference": float(np.nanmax(np.abs(r16["scale"] - r3_["scale"]))),
                          "max_abs_translation_difference_m": float(np.nanmax(np.abs(r16["t"] - r3_["t"])))}
-    # the same path on clouds at the point density real inputs have (--cloud voxel2mm: ~250 neighbours inside the SHOT support)
+    def bins_of(st_):
+        return st_.pipe.bins.reshape(st_.B, st_.T, 6).cpu().numpy().astype(np.uint8)
+
+    # the same path on clouds at the point density real inputs have (--cloud voxel2mm: ~250 neighbours inside the SHOT support):
+    # single stream with stage events, then the batch mode (two streams, two different batches) like the headline
     voxel = None
     if args.cloud == "synthetic" and not args.no_voxel_density and world == 1:
         vargs = type(args)(**vars(args))
@@ -448,16 +800,51 @@ def main():
             vstep.run()
         torch.cuda.synchronize()
         kv = min(args.steps, 20)
-        dtv, _, evv, _ = timed_loop(kv, one=vstep)
+        with tel.window("voxel_density_single_stream_loop"):
+            dtv, _, evv, _ = timed_loop(kv, one=vstep)
         vms = report.stage_means(evv)
-        voxel = {"value": vstep.B * kv / dtv, "unit": "scenes/s", "ms_per_step": 1e3 * dtv / kv, "steps": kv, "streams": 1,
+        v_rec = vstep.pipe.results.clone()
+        v_agree = None
+        if rank == 0 and oracle_out.get("voxel2mm"):
+            v_agree = agreement_shot(vstep, vstep.pipe.results_to_numpy(), bins_of(vstep), oracle_out["voxel2mm"], pool, "voxel2mm")
+        dtv2, v_same = None, None
+        if not args.single_stream:
+            from cppf2_amd.pipeline import BatchMode
+            vstep2 = Step(vargs, rank, world, dev, cloud="voxel2mm", scene_shift=args.scenes_per_gpu * world)
+            vstep2.run()
+            with BatchMode([vstep, vstep2], device=dev, reserve_cus=args.mlp_reserve_cus, streams=streams) as m_:
+                for _ in range(4):
+                    with m_.next() as s_:
+                        s_.run()
+                torch.cuda.synchronize()
+                with tel.window("voxel_density_two_stream_loop"):
+                    dtv2 = timed_loop(kv, sample=False, pair=m_)[0]
+            v_same = bool(torch.equal(vstep.pipe.results, v_rec))
+            del vstep2
+        voxel = {"value": vstep.B * kv / (dtv2 or dtv), "unit": "scenes/s", "ms_per_step": 1e3 * (dtv2 or dtv) / kv, "steps": kv,
+                 "streams": 2 if dtv2 else 1, "value_single_stream": vstep.B * kv / dtv, "ms_per_step_single_stream": 1e3 * dtv / kv,
+                 "records_identical_to_single_stream": v_same,
                  "cloud": "voxel2mm (cppf2_amd.synth.make_scene_voxel2mm: one point per 2 mm cell, ~250 neighbours in the 2 cm support)",
                  "shot_stage_ms": round(vms.get("shot_frames", 0.0) + vms.get("shot352", 0.0), 4),
                  "per_stage_ms": {s_: round(vms.get(s_, 0.0), 4) for s_ in Step.STAGES},
-                 "pose_5deg5cm_vs_gt": report.pose_ok_vs_gt(vstep.pipe.results_to_numpy(), vstep.scenes) / vstep.B}
+                 "pose_5deg5cm_vs_gt": report.pose_ok_vs_gt(vstep.pipe.results_to_numpy(), vstep.scenes) / vstep.B,
+                 "oracle_agreement": v_agree}
         del vstep
         step.run()
         torch.cuda.synchronize()
+
+    # socket power and shader clock while each launch form of the tuple MLP runs on its own (roofline.power.mlp_launches)
+    launches = None
+    if (rank == 0 and world == 1 and tel.proc is not None and not args.no_launch_power and report.GATHERED_TUPLES
+            and _models.MLP_ARITH in ("split", "split16")):
+        launches = evidence.mlp_launch_loops(step, tel)
+        step.run()
+        torch.cuda.synchronize()
+    power = tel.finish() if rank == 0 else None
+    if power is not None and launches is not None:
+        for l_ in launches:
+            l_.update({k_: v_ for k_, v_ in (power.get("windows", {}).pop(l_["window"], None) or {}).items() if k_ != "seconds"})
+        power["mlp_launches"] = launches
 
     if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
         for i_, ev in enumerate(evs):
@@ -475,14 +862,22 @@ def main():
     failed = False
     if rank == 0:
         cpu = None
-        if args.cpu_scenes > 0 and world == 1:     # CPU baseline: rank 0 at N=1 only
-            cpu = cpu_baseline(args, step, step.pipe.results_to_numpy())
+        if args.cpu_scenes > 0 and world == 1:     # CPU baseline + whole-batch agreement: rank 0 at N=1 only
+            agree = None
+            if oracle_out.get("headline"):
+                agree = agreement_shot(step, step.pipe.results_to_numpy(), bins_of(step), oracle_out["headline"], pool, args.cloud)
+                sha_mine = weights_sha({k: v.detach().cpu().numpy() for k, v in step.model.state_dict().items()})
+                agree["weights_identical_to_the_gpu_run"] = bool(pool.extra.get("worker_weights_sha", {}).get("shot") == sha_mine)
+            elif pool.error:
+                agree = {"scenes": 0, "pool_error": pool.error}
+            n_pool = sum(len(v_) for v_ in oracle_out.values())
+            cpu = (cpu_baseline(args, step, pool_scenes=(n_pool, pool.wall, pool.extra.get("workers")) if n_pool else None), agree)
         ev_ = evidence.arithmetic_evidence(step) if world == 1 and not args.no_evidence else {}
         line, problems = report.report_shot(dict(
             args=args, step=step, world=world, backend=backend, dt=dt, dt_single=dt_single, dt_other=dt_other, dt_native=dt_native,
             dt_f16=dt_f16, f16_agreement=f16_agreement, two=two, intervals=intervals, intervals_single=intervals_single,
             stage_ms=stage_ms, stage_ms_2s=stage_ms_2s, step_times=step_times, affinity=affinity, cpu=cpu, evidence=ev_, voxel=voxel,
-            rank_ms=rank_ms))
+            rank_ms=rank_ms, dt_noprior=dt_noprior, dt_arrayprior=dt_arrayprior, power=power))
         line["counter_children_started"] = counter_children
         print(json.dumps(line))
         if problems:

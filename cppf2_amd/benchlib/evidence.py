@@ -58,3 +58,65 @@ def arithmetic_evidence(step, rows_err=4096, scenes_flip=10):
     out["bin_flip_rate_vs_expf"] = {"draws": int(ref.numel()), "flips": flips, "rate": flips / ref.numel(),
                                     "max_bin_distance": int((ref - got).abs().max().item())}
     return out
+
+
+MLP_LAUNCH_OPS = ("reslayer_split_encode", "reslayer_split_gather", "reslayer_split", "reslayer_split_decode", "reslayer_split16")
+
+
+@torch.no_grad()
+def mlp_launch_loops(step, tel, seconds=1.5):
+    """Each launch of the tuple MLP (the step's three cppf_reslayer_split* calls: gathered 360 -> 128 chain | 128 -> 256 tapped +
+    the logit head's 256-wide layers | 256 -> 192 + bin draw) run BACK TO BACK ON ITS OWN for ~`seconds`, under telemetry windows
+    `mlp_launch_<i>`: socket power and shader clock while nothing but that launch form runs -- the measurement behind (or against)
+    "the MLP kernels sit at the power limit".  The calls are recorded from one real step (same tensors, same arguments) and
+    replayed; returns [{launch, op, ms (HIP events over the loop), window}]."""
+    from cppf2_amd import models as M
+    from cppf2_amd import shot as shotmod
+    ops, pipe, a = step.ops, step.pipe, step.args
+    calls = []
+    saved = {n: getattr(ops, n) for n in MLP_LAUNCH_OPS}
+
+    def recorder(name):
+        def f(*args, **kw):
+            calls.append((name, args, kw))
+            return saved[name](*args, **kw)
+        return f
+    ids = tuple(range(step.scene0, step.scene0 + step.B))
+    idx = ops.sample_tuples(step.N, step.T, 5, a.seed, ids, step.dev)
+    shotmod.prepare_device(step.pts, pipe.pt_off, Cfg.res * 10, Cfg.res * 10, step.normal)
+    shot = shotmod.describe_device(step.pts, pipe.pt_off, step.normal, Cfg.res * 10, out=step.shot, nan_to_zero=True)
+    normal = ops.nan_to_zero_(step.normal)
+    feat = step.model.encode_points(shot)
+    u = ops.philox_uniform(step.T, 6, a.seed, 1, ids, step.dev)
+    src = ops.TupleSource(step.pts, idx, normal, pipe.pt_off, pipe.tup_off)
+    for n in MLP_LAUNCH_OPS:
+        setattr(ops, n, recorder(n))
+    try:
+        M.fused_stack((step.model.tuple_encoder, step.model.logit_encoder), None, gather=(src, None, feat),
+                      decode=(u, step.prior, pipe.bins) if M.decode_supported(step.model.logit_encoder, feat) else None)
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
+    torch.cuda.synchronize()
+    out = []
+    for i, (name, args, kw) in enumerate(calls):
+        fn = saved[name]
+        for _ in range(3):
+            fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(8):
+            fn(*args, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        reps = max(16, int(seconds * 1e3 / max(e0.elapsed_time(e1) / 8, 1e-3)))
+        wname = "mlp_launch_%d" % i
+        with tel.window(wname, torch.cuda.synchronize):
+            e0.record()
+            for _ in range(reps):
+                fn(*args, **kw)
+            e1.record()
+        out.append({"launch": i, "op": name, "chain": kw.get("chain"), "reps": reps, "ms": round(e0.elapsed_time(e1) / reps, 4),
+                    "window": wname})
+    return out

@@ -46,6 +46,16 @@ def parse(argv=None):
     ap.add_argument("--rots", type=int, default=180)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--agreement-scenes", type=int, default=1 << 30,
+                    help="scenes of rank 0's timed batch the CPU oracle re-computes end to end for oracle_agreement (default: all of "
+                         "them; worker processes started before the GPU is initialised; 0 = skip; needs --cpu-scenes > 0)")
+    ap.add_argument("--agreement-voxel-scenes", type=int, default=8,
+                    help="scenes of the voxel-density loop (and instances of --workload ensemble) the oracle re-computes")
+    ap.add_argument("--no-prior-variants", action="store_true",
+                    help="skip the extra timed loops without the teacher prior (value_no_prior) and with the prior as a [T, 6, 32] "
+                         "array (value_array_prior)")
+    ap.add_argument("--no-launch-power", action="store_true",
+                    help="skip the per-launch power / clock loops of the tuple MLP (roofline.power.mlp_launches)")
     ap.add_argument("--vote-mode", type=int, default=0)
     ap.add_argument("--array-prior", action="store_true",
                     help="pass the teacher prior as a [T, 6, 32] array instead of its generator (ops.BinPrior): same records, + 0.34 ms")

@@ -385,6 +385,7 @@ def report_shot(run):
             hbm=hbm))
         for k_ in ("algorithmic_bytes_per_launch", "launch_ms_kind"):
             roofline.pop(k_, None)
+    roofline["power"] = run.get("power")
     ok = pose_ok_vs_gt(res, step.scenes)
     cpu, agree = run.get("cpu") or (None, None)
     total_scenes = B * world * args.steps
@@ -428,8 +429,18 @@ def report_shot(run):
         "f16x2_agreement": f16_agreement,
         # the same path on clouds at the point density real inputs have (eval.py:185-201's 2 mm voxel grid: ~250 neighbours inside
         # the SHOT support instead of the synthetic clouds' ~90), single stream, same loop protocol; with its per-stage times
+        # (round 6: `value` of the voxel-density object is the batch mode's -- two streams like the headline --, the single-stream
+        # figure of rounds 4-5 is value_voxel_density_single_stream)
         "value_voxel_density": (run.get("voxel") or {}).get("value"),
+        "value_voxel_density_single_stream": (run.get("voxel") or {}).get("value_single_stream"),
         "voxel_density": run.get("voxel"),
+        # the headline loop WITHOUT the teacher prior (the reference has none, eval.py:225-235: what trained checkpoints run; with
+        # the bench's random-init weights the votes then do not cluster, so only its speed means anything) and with the prior read
+        # as a [T, 6, 32] array (the form of rounds 1-4: + 983 MB of reads per step)
+        "value_no_prior": (total_scenes / run["dt_noprior"]) if run.get("dt_noprior") else None,
+        "value_array_prior": (total_scenes / run["dt_arrayprior"]) if run.get("dt_arrayprior") else None,
+        "prior_form_timed": ("array [T, 6, 32]" if getattr(args, "array_prior", False) else
+                             "generator (ops.BinPrior: 24 bytes per tuple, evaluated in the bin draw's epilogue)"),
         # the headline's stream mode; value_single_stream = the same steps on ONE stream (rounds 1-3), same loop protocol
         "two_streams": two,
         "value_single_stream": (total_scenes / dt_single) if dt_single else None,
@@ -459,6 +470,11 @@ def report_shot(run):
         problems.append("two_streams: a pipeline's records differ from the single-stream records of its own scenes")
     if f16_agreement is not None and f16_agreement["scenes_with_equal_argmax_rotation_bins_kept_count"] != f16_agreement["scenes"]:
         problems.append("f16x2_agreement: a scene's arg-max / rotation bins / kept count differs from the headline arithmetic's")
+    for name_, ag_ in (("oracle_agreement", agree), ("voxel_density.oracle_agreement", (run.get("voxel") or {}).get("oracle_agreement"))):
+        if ag_ and ag_.get("defects"):
+            problems.append("%s: scenes %s differ from the oracle even when it votes from the GPU's own bin draws" % (name_, ag_["defects"]))
+        if ag_ and ag_.get("weights_identical_to_the_gpu_run") is False:
+            problems.append("%s: the oracle workers' weights differ from the GPU run's" % name_)
     bad = [k_ for k_, e_ in per_kernel.items() if e_.get("frac") is not None and not (0.0 < e_["frac"] <= 1.0)]
     if bad:
         problems.append("roofline.per_kernel: fraction outside (0, 1] for " + ", ".join(bad))

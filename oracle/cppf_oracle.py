@@ -417,7 +417,9 @@ def cone_threshold(angle_tol):
     return F32(np.cos(2 * angle_tol / 180 * np.pi))
 
 
-def get_topk_dir(pred, sphere_pts, bmm_size, angle_tol, wt=None, topk=1, return_counts=False):
+def get_topk_dir(pred, sphere_pts, bmm_size, angle_tol, wt=None, topk=1, return_counts=False, impl="numpy", threads=0):
+    """impl="numpy": the definition below.  impl="c": the same arithmetic in oracle/vote_oracle.c (OpenMP, `threads` = 0 for all
+    cores; float64 weights only) -- bit-equal counts (tests/test_oracle_golden.py), what bench.py's cpu_baseline times."""
     pred = np.asarray(pred, dtype=F32)
     sphere_pts = np.asarray(sphere_pts, dtype=F32)
     S = sphere_pts.shape[0]
@@ -426,6 +428,12 @@ def get_topk_dir(pred, sphere_pts, bmm_size, angle_tol, wt=None, topk=1, return_
         wt = np.ones((pred.shape[0], 1), dtype=F32)
     wt = np.asarray(wt)
     thr = cone_threshold(angle_tol)
+    if impl == "c" and wt.dtype == np.float64 and pred.shape[0] > 0:
+        from . import vote_oracle as V
+        counts = V.sphere_counts(pred, sphere_pts, wt, thr, bmm_size, threads)
+        order = np.argsort(-counts, kind="stable")[:topk]
+        topk_dir = np.array(sphere_pts[order])
+        return (topk_dir, counts[order], counts) if return_counts else (topk_dir, counts[order])
     sph_t = sphere_pts.T
     for i in range((pred.shape[0] - 1) // bmm_size + 1):
         blk = pred[i * bmm_size:(i + 1) * bmm_size]
@@ -470,7 +478,7 @@ def assemble_pose(preds_up, preds_right, up, right):
 # ----------------------------------------------------------------------------
 def run_scene(pc, point_idxs_all, pred_cls, pred_scales, uniforms, cfg_up, cfg_right, cfg_front,
               res, num_rots=180, angle_tol=1.0, backproj_ratio=0.1, imp_wt_margin=0.01,
-              bmm_size=100000, sphere_pts=None, trig=None):
+              bmm_size=100000, sphere_pts=None, trig=None, topk_impl="numpy", topk_threads=0):
     """Returns a dict with every stage boundary (used by parity tests and the CPU baseline)."""
     pc = np.asarray(pc, dtype=F32)
     idx = np.asarray(point_idxs_all).astype(np.int64)
@@ -493,7 +501,8 @@ def run_scene(pc, point_idxs_all, pred_cls, pred_scales, uniforms, cfg_up, cfg_r
         cand, vmask = vote_rotation(pc, rot_f[:, col], filt[:, :2], num_rots, trig)
         cand = cand.reshape(-1, 3)
         w = np.broadcast_to(imp_pair_wt[vmask, None], (int(vmask.sum()), num_rots)).reshape(-1, 1)
-        d, c, allc = get_topk_dir(cand, sphere_pts, bmm_size, angle_tol, w, topk=1, return_counts=True)
+        d, c, allc = get_topk_dir(cand, sphere_pts, bmm_size, angle_tol, w, topk=1, return_counts=True, impl=topk_impl,
+                                  threads=topk_threads)
         out[name + "_idx"] = int(np.argsort(-allc, kind="stable")[0])
         out[name + "_counts"] = allc
         dirs.append(d[0])

@@ -34,19 +34,35 @@ def mlp_shot(weights, pc, idx, shot_feat, normal):
 
 
 def run_scene_full(weights, pc, seed, scene_id, num_tuples, res=2e-3, num_rots=180, prior_fn=None,
-                   cfg_up=(0, 1, 0), cfg_right=(1, 0, 0), cfg_front=(0, 0, 1), trig=None):
-    """Sampler -> SHOT -> MLP -> decode -> votes -> pose for one scene; mirrors bench.py's GPU step."""
+                   cfg_up=(0, 1, 0), cfg_right=(1, 0, 0), cfg_front=(0, 0, 1), trig=None, shot_threads=1, topk_impl="numpy",
+                   topk_threads=0, timings=None):
+    """Sampler -> SHOT -> MLP -> decode -> votes -> pose for one scene; mirrors bench.py's GPU step.
+    shot_threads / topk_impl / topk_threads: how the descriptor and the get_topk_dir stages run (results identical for every
+    setting); timings: a dict that receives seconds per stage."""
+    import time
+    t_ = [time.perf_counter()]
+
+    def lap(name):
+        t_.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + t_[-1] - t_[-2]
     n = pc.shape[0]
     idx = O.sample_tuples(seed, scene_id, num_tuples, 5, n).astype(np.int64)
     # eval.py:210; the normals in pcl::NormalEstimation's arithmetic, like the product's default (cppf2_amd.shot.ARITHMETIC)
-    shot_feat, normal, _, _ = S.compute_ex(pc, res * 10, res * 10, pcl_arithmetic=True)
+    lap("sample_tuples")
+    shot_feat, normal, _, _ = S.compute_ex(pc, res * 10, res * 10, pcl_arithmetic=True, threads=shot_threads)
     shot_feat = np.nan_to_num(shot_feat, nan=0.0)                               # eval.py:215-216
     normal = np.nan_to_num(normal, nan=0.0)
+    lap("shot_descriptor")
     logits, scales = mlp_shot(weights, pc, idx, shot_feat, normal)
+    lap("mlp")
     if prior_fn is not None:
         logits = (logits + prior_fn(idx)).astype(np.float32)
     u = O.philox_uniform(seed, scene_id, 1, num_tuples, 6)
-    out = O.run_scene(pc, idx, logits, scales, u, cfg_up, cfg_right, cfg_front, res, num_rots=num_rots, trig=trig)
+    lap("prior_and_uniforms (bench setup, not the path)")
+    out = O.run_scene(pc, idx, logits, scales, u, cfg_up, cfg_right, cfg_front, res, num_rots=num_rots, trig=trig,
+                      topk_impl=topk_impl, topk_threads=topk_threads)
+    lap("decode_votes_backvote_rotation_bins_pose")
     out["idx"] = idx
     return out
 
@@ -81,7 +97,7 @@ def alignment_loss(pc, T_est, R_est, pred_scale_norm, idx_filtered, pred_pairs_f
 
 def run_instance_ensemble(pc, idx, per_model, cfg_up, cfg_right, cfg_front, res, num_rots=180, y_only=False,
                           geo_branch=True, visual_branch=True, trig=None, angle_tol=1.0, backproj_ratio=0.1,
-                          imp_wt_margin=0.01):
+                          imp_wt_margin=0.01, topk_impl="numpy", topk_threads=0):
     """eval.py:217-372 for one instance (opt off): both models vote, each pose is scored by the alignment loss, the
     smaller one wins.  per_model: [(pred_cls, pred_scales, uniforms) for the DINO model, ... for the SHOT model] -- the
     networks' outputs are inputs here (mlp_dino / mlp_shot produce them).  Reproduced quirks: the scale (median of the
@@ -92,7 +108,8 @@ def run_instance_ensemble(pc, idx, per_model, cfg_up, cfg_right, cfg_front, res,
     outs = []
     for model_idx, (pred_cls, pred_scales, uniforms) in enumerate(per_model):
         o = O.run_scene(pc, idx, pred_cls, pred_scales, uniforms, cfg_up, cfg_right, cfg_front, res, num_rots=num_rots,
-                        angle_tol=angle_tol, backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, trig=trig)
+                        angle_tol=angle_tol, backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, trig=trig,
+                        topk_impl=topk_impl, topk_threads=topk_threads)
         if model_idx == 0:
             pred_scale = o["pred_scale"]                                                         # eval.py:309
             pred_scale_norm = np.linalg.norm(pred_scale)                                         # eval.py:310 (float32)

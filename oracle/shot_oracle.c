@@ -29,6 +29,9 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -556,17 +559,42 @@ static int shot_lrf_sorted(const float* pts, int i, const Nb* nb, int m, float r
  * histogram before normalisation, neighbours within shot_r, smallest |d^2 - r^2| / r^2 over ALL points (how close a
  * point comes to entering / leaving the support: its contribution does not vanish at the rim, so that is a jump too). */
 #define DIAG_LEN 9
+/* Threads of shot_oracle_compute_ex (bench.py's cpu_baseline: 1 = like PCL, 0 = all cores). */
+static int g_threads = 1;
+int shot_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void shot_oracle_set_threads(int t) { g_threads = t; }
+
 void shot_oracle_compute_ex(const float* pts, int n, float normal_r, float shot_r, int mode, float* out_shot,
                             float* out_normal, float* out_rf, double* out_diag) {
-  Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)(n > 0 ? n : 1));
+  /* Every query point is independent (own neighbour list, own output rows): with -fopenmp and g_threads != 1 the two loops run
+   * over the points in parallel, each thread with its own neighbour buffer; the outputs do not depend on the thread count.
+   * g_threads = 1 (the default) is the reference's own mode: PCL's estimators at src_shot/shot.cpp:66-89 are single-threaded. */
+  const int nthreads = g_threads == 1 ? 1 : (g_threads > 1 ? g_threads : shot_oracle_max_threads());
+  (void)nthreads;
   if (mode == 1) {
-    for (int i = 0; i < n; ++i) {
-      const int m = sorted_neighbours(pts, n, i, normal_r, nb);
-      pcl_normal(pts, i, nb, m, out_normal + 3 * i);
+#pragma omp parallel num_threads(nthreads)
+    {
+      Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)(n > 0 ? n : 1));
+#pragma omp for schedule(dynamic, 32)
+      for (int i = 0; i < n; ++i) {
+        const int m = sorted_neighbours(pts, n, i, normal_r, nb);
+        pcl_normal(pts, i, nb, m, out_normal + 3 * i);
+      }
+      free(nb);
     }
   } else {
     shot_oracle_normals(pts, n, normal_r, out_normal);
   }
+#pragma omp parallel num_threads(nthreads)
+  {
+  Nb* nb = (Nb*)malloc(sizeof(Nb) * (size_t)(n > 0 ? n : 1));
+#pragma omp for schedule(dynamic, 32)
   for (int i = 0; i < n; ++i) {
     const float* p = pts + 3 * i;
     float* shot = out_shot + (size_t)SHOT_LEN * i;
@@ -613,6 +641,7 @@ void shot_oracle_compute_ex(const float* pts, int n, float normal_r, float shot_
     for (int c = 0; c < SHOT_LEN; ++c) shot[c] /= (float)acc;
   }
   free(nb);
+  }
 }
 
 

@@ -35,6 +35,9 @@ def _load():
         _lib.shot_oracle_compute_color.restype = None
         _lib.shot_oracle_normals.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         _lib.shot_oracle_normals.restype = None
+        _lib.shot_oracle_set_threads.argtypes = [C.c_int]
+        _lib.shot_oracle_set_threads.restype = None
+        _lib.shot_oracle_max_threads.restype = C.c_int
     return _lib
 
 
@@ -57,8 +60,14 @@ def normals(pc, normal_r):
     return out
 
 
-def compute_ex(pc, normal_r, shot_r, pcl_arithmetic=False):
-    """Like compute(), plus diagnostics and the PCL-arithmetic mode (see shot_oracle.c).  Returns (shot, normal, rf,
+def max_threads():
+    return int(_load().shot_oracle_max_threads())
+
+
+def compute_ex(pc, normal_r, shot_r, pcl_arithmetic=False, threads=1):
+    """threads: 1 = single-threaded like PCL's estimators (src_shot/shot.cpp:66-89; the default), 0 = all cores (OpenMP over the
+    query points; identical outputs).
+    Like compute(), plus diagnostics and the PCL-arithmetic mode (see shot_oracle.c).  Returns (shot, normal, rf,
     diag f64[N,9]): LRF eigenvalues (descending), the sign tallies 2*plus - n of the x and z axes, the smallest
     margin of a neighbour to a decision boundary of PCL's interpolation (cosine step, radial shell, equator, octant), the histogram's L2 norm, the neighbour count,
     the smallest |d^2 - r^2| / r^2 over all points (proximity of a point to the rim of the support)."""
@@ -68,6 +77,7 @@ def compute_ex(pc, normal_r, shot_r, pcl_arithmetic=False):
     normal = np.empty((n, 3), np.float32)
     rf = np.empty((n, 9), np.float32)
     diag = np.empty((n, 9), np.float64)
+    _load().shot_oracle_set_threads(int(threads))
     _load().shot_oracle_compute_ex(pc.ctypes.data, n, C.c_float(normal_r), C.c_float(shot_r), int(bool(pcl_arithmetic)),
                                    shot.ctypes.data, normal.ctypes.data, rf.ctypes.data, diag.ctypes.data)
     return shot, normal, rf, diag
