@@ -599,7 +599,11 @@ def main():
         # RCCL over xGMI; CPPF_BENCH_BACKEND=gloo is a dry-run switch for boxes with fewer GPUs than ranks.
         # CPPF_DIST_FORCE_COLLECTIVE=1 makes a one-rank run create the group and issue the all_gather too.
         backend = os.environ.get("CPPF_BENCH_BACKEND", "nccl")
-        cdist.init(backend=backend, device=dev if backend == "nccl" else None)
+        try:
+            cdist.init(backend=backend, device=dev if backend == "nccl" else None)
+        except cdist.DistInitError as e:           # rank, backend, MASTER_* are in the message; non-zero exit, never a re-exec
+            print("bench.py: %s" % e, file=sys.stderr)
+            sys.exit(4)
         assert torch.distributed.get_world_size() == world and torch.distributed.get_rank() == rank
     timer = Timer(dev)
 

@@ -170,29 +170,94 @@ def self_launch(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    return run_ranks([[sys.executable, BENCH] + sys.argv[1:]] * n, have, port)
+
+
+LAUNCH_TIMEOUT_S = 1500.0
+
+
+def run_ranks(cmds, visible_gpus, port, timeout_s=None, out=None):
+    """Starts one fresh process per entry of `cmds` (rank = its index; the environment torch.distributed.run would give it), waits
+    for them WITHOUT polling (blocking waitpid), and returns the exit status of the run: 0 if every rank exited 0.  On the first
+    failing rank -- or when the run exceeds `timeout_s` (CPPF_BENCH_LAUNCH_TIMEOUT_S, default 1500 s) -- the other ranks, which
+    would otherwise wait in a collective for their own timeout, are stopped by PID (SIGTERM, then SIGKILL after 10 s), and EVERY
+    rank's exit status and the tail of its stderr are printed, so that the first real multi-GPU run explains itself.  Rank 0's
+    stdout is this process' stdout (the JSON line); every rank's stderr goes to a file of its own and rank 0's is forwarded at the
+    end."""
+    import signal
+    import subprocess
+    import tempfile
+    import time
+    n = len(cmds)
+    timeout_s = float(os.environ.get("CPPF_BENCH_LAUNCH_TIMEOUT_S", LAUNCH_TIMEOUT_S)) if timeout_s is None else float(timeout_s)
+    out = out or sys.stderr
+    d = tempfile.mkdtemp(prefix="cppf_ranks_")
+    procs, errs = [], []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % have), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(1, visible_gpus)), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         for k_ in SET_HERE:                     # every rank sets up its own TunableOp table (its own device ordinal and directory)
             env.pop(k_, None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, BENCH] + sys.argv[1:], env=env, cwd=os.getcwd()))
-    # wait for the ranks without polling: the parent sleeps in waitpid until a child exits
-    rc = 0
-    live = {p_.pid: p_ for p_ in procs}
-    while live:
+        errs.append(os.path.join(d, "rank%d.err" % r))
+        with open(errs[-1], "w") as ef:
+            procs.append(subprocess.Popen(cmds[r], env=env, cwd=os.getcwd(), stderr=ef,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+    live = {p_.pid: (r, p_) for r, p_ in enumerate(procs)}
+    status = [None] * n
+    why = None
+
+    class _Timeout(Exception):
+        pass
+
+    def on_alarm(*_):
+        raise _Timeout()
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.setitimer(signal.ITIMER_REAL, timeout_s)
+    try:
+        while live:
+            try:
+                pid, st = os.waitpid(-1, 0)          # sleeps until a child exits
+            except ChildProcessError:
+                break
+            if pid not in live:
+                continue
+            r, p_ = live.pop(pid)
+            status[r] = p_.returncode = os.waitstatus_to_exitcode(st)
+            if status[r] != 0 and why is None:
+                why = "rank %d exited with status %d" % (r, status[r])
+                break
+    except _Timeout:
+        why = "the run exceeded %.0f s" % timeout_s
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+        signal.signal(signal.SIGALRM, old)
+    if live:                                        # a failed run: stop exactly the PIDs that are left
+        for r, p_ in live.values():
+            p_.terminate()
+        t_end = time.monotonic() + 10.0
+        for r, p_ in live.values():
+            try:
+                status[r] = p_.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                status[r] = p_.wait()
+            status[r] = "stopped by the launcher (%s)" % status[r]
+
+    def tail(path, lines):
         try:
-            pid, status = os.waitpid(-1, 0)
-        except ChildProcessError:
-            break
-        p_ = live.pop(pid, None)
-        if p_ is None:
-            continue
-        r_ = os.waitstatus_to_exitcode(status)
-        p_.returncode = r_
-        if r_ != 0 and rc == 0:
-            rc = r_ if r_ > 0 else 1
-            for q_ in live.values():       # a failed rank leaves the others waiting in a collective: stop exactly those PIDs
-                q_.terminate()
+            with open(path, errors="replace") as f:
+                return "".join(f.readlines()[-lines:])
+        except OSError:
+            return ""
+    if why is not None:
+        print("bench.py: multi-rank run FAILED: %s.  Per rank:" % why, file=out)
+        for r in range(n):
+            print("---- rank %d: exit %s; last lines of its stderr:\n%s" % (r, status[r], tail(errs[r], 15).rstrip()), file=out)
+        rc = next((s_ for s_ in status if isinstance(s_, int) and s_ > 0), 1)
+    else:
+        out.write(tail(errs[0], 200))              # rank 0's diagnostics of a good run (self-check messages, warnings)
+        rc = 0
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
     return rc

@@ -39,7 +39,7 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     inc = os.path.join(ROOT, "include")
-    hdrs = [os.path.join(inc, "cppf_hip.h"), os.path.join(CSRC, "cppf_common.h")]
+    hdrs = [os.path.join(inc, "cppf_hip.h"), os.path.join(inc, "cppf_hip_experimental.h"), os.path.join(CSRC, "cppf_common.h")]
     extra = os.environ.get("CPPF_EXTRA_FLAGS", "").split()
     objs = []
     for src in SOURCES:

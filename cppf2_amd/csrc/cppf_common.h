@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "cppf_hip.h"
+#include "cppf_hip_experimental.h"
 
 #define CPPF_WAVE 64
 

@@ -844,10 +844,10 @@ extern "C" int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const f
   return CPPF_OK;
 }
 
-extern "C" int cppf_decode_bins(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms, const float* pts,
-                                const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
-                                int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,
-                                float* scale, float* tr, float* rot, void* stream) {
+extern "C" int cppf_decode_bins_prior(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms,
+                                      const float* pts, const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                                      int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,
+                                      float* scale, float* tr, float* rot, void* stream) {
   CPPF_CHECK_ARG(B > 0 && logits && uniforms && pts && idx && pt_off && tup_off && h_axes);
   CPPF_CHECK_ARG(nb >= 2 && nb <= DEC_MAX_NB);
   CPPF_CHECK_ARG(k >= 2 && k <= 8);
@@ -865,6 +865,16 @@ extern "C" int cppf_decode_bins(int B, const float* logits, const float* logit_p
                        tr, rot);
   CPPF_LAUNCH_CHECK();
   return CPPF_OK;
+}
+
+// the stable form (eval.py:225-240 has no prior)
+extern "C" int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
+                                const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
+                                int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled,
+                                float* scale, float* tr, float* rot, void* stream) {
+  const int st = cppf_decode_bins_prior(B, logits, nullptr, nb, uniforms, pts, idx, k, pt_off, tup_off, total_tuples, h_axes, bins,
+                                        scaled, scale, tr, rot, stream);
+  return st;
 }
 
 __global__ __launch_bounds__(256) void target_pairs_kernel(int B, const float* __restrict__ pairs,

@@ -86,23 +86,21 @@ __host__ __device__ constexpr int rs_stage_bytes(int stg) { return stg * 3 * RS_
 // operand, three products per K step; see the f16x2 section below)
 __host__ __device__ constexpr int rs_tile_bytes(int pc) { return pc * RS_FRAG_BYTES; }
 
-// measured variants kept as switches: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more),
-// and a hand-placed MFMA / filler interleave (RS_INTERLEAVE 1; 2 = everything in front of each tile's back-to-back MFMA chain).
+// measured variant kept as a switch: LDS fragments requested two tiles ahead instead of one (no faster, 12 registers more).
+// (A hand-placed MFMA / filler interleave -- one MFMA, then a few independent instructions; or everything in front of each tile's
+// back-to-back MFMA chain -- was measured in round 3 and removed from the source in round 6: docs/experiments/r6_removed_mlp_variants.patch.)
 // Round 3 measurements (scratch/rs/: rs_probe.hip with the RS_DBG switches, filler_price.hip, mfma_chain.hip + PMC): the kernel is
 // bound by the chip's POWER limit, not by issue slots or latency -- dependent MFMA chains issue every 32.2 cycles, up to four plain
 // VALU instructions fit between two MFMAs for free in cycles, and removing the chunk barrier raises the matrix pipe's busy
 // fraction by 5 points while the clock drops by the same factor (same wall time); what moves the time is the work executed
 // beside the MFMAs (each VALU instruction per MFMA costs ~3 % through the clock, a ds_read_b128 ~5 %): without the operand
 // split the 256-wide kernel runs 14 % faster, without the weight stream 9 %, without its global loads / stores 8 %.  Hence
-// RS_INTERLEAVE 0 (the compiler's own order: fewer register moves, 5 % faster on the 256-wide identity kernel, equal elsewhere).
+// the compiler's own order within a tile region (fewer register moves, 5 % faster on the 256-wide identity kernel, equal elsewhere).
 // Also measured, not kept: two tiles per region with their MFMA chains alternating between the two accumulators (3-8 % slower),
 // output halves / quarters for the 256-wide layers at two wavefronts per SIMD (equal), register-staged instead of LDS-DMA weight
 // chunks, the residual of the 256-wide identity kernel loaded before the first product (RS_EARLY_RESIDUAL: 128 registers too many).
 #ifndef RS_DEEP_PREFETCH
 #define RS_DEEP_PREFETCH 0
-#endif
-#ifndef RS_INTERLEAVE
-#define RS_INTERLEAVE 0
 #endif
 // timing probes (scratch/rs/rs_probe.hip; results are wrong with any bit set): 1 no weight pieces, 2 no operand split,
 // 4 no LDS fragment reads, 8 no chunk barrier, 16 no x tiles, 32 no residual load / output store
@@ -114,18 +112,6 @@ __host__ __device__ constexpr int rs_tile_bytes(int pc) { return pc * RS_FRAG_BY
 #endif
 #ifndef RS_XCD_BLOCKS
 #define RS_XCD_BLOCKS 1          // 0: row blocks dealt round-robin over all workgroups (rounds 2-3)
-#endif
-#ifndef RS_SIDE_INTERLEAVE
-#define RS_SIDE_INTERLEAVE 4     // vector instructions per MFMA gap in regions that carry side work (0: the scheduler's own order)
-#endif
-#ifndef RS_DEFER_DRAW
-// 1: the bin draw of a row block cut into 24 pieces per coordinate and placed into the tile regions of the NEXT block's first
-// product (RsDraw below; bins bit-identical, tests pass with it).  Measured in round 4 and NOT faster: 2.18 ms against 2.06 ms
-// for the 256 -> 192 launch with the draw as its own epilogue (MFMA-busy 0.45 against 0.51; the scheduler does interleave the
-// pieces with the MFMAs, with and without a forced 3 / 4 / 5-per-gap pattern -- RS_SIDE_INTERLEAVE -- and the clock does not drop:
-// the regions of this 12-tile product already carry the operand split, three LDS fragment reads and the weight DMA per tile, and
-// the extra ~8 vector instructions per region lengthen the dependent MFMA chains more than the removed epilogue saves).
-#define RS_DEFER_DRAW 0
 #endif
 #ifndef RS_EARLY_RESIDUAL
 #define RS_EARLY_RESIDUAL 0      // 1: the wide identity kernel then needs 128 registers more than there are (spills)
@@ -331,12 +317,8 @@ __device__ __forceinline__ RsFrag rs_read(const u32x4* w, int tile) {
 // of the NEXT step's B operand, a quarter per call) and `dma(q)`, q < PMAX, the LDS-DMA issue of one piece of the next
 // weight chunk: both are placed in front of a tile's MFMAs so that they issue in their shadow; the scheduling barrier
 // per tile keeps the compiler from hoisting all the reads / all the filler to the step's front.
-// (side(u): further independent vector work of the region of tile u -- the deferred bin draw of the previous row block, RsDraw)
-struct RsNoSide {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-template <int NTILES, bool PREFETCH, int PMAX, int PC, class F, class D, class S = RsNoSide>
-__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler, D&& dma, S&& side = S()) {
+template <int NTILES, bool PREFETCH, int PMAX, int PC, class F, class D>
+__device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, const RsFrag& b, F&& filler, D&& dma) {
   // PREFETCH: fragments are requested two tiles ahead (one wavefront per SIMD: nobody else covers the LDS latency);
   // otherwise one tile ahead
   RsFrag a0 = rs_read<PC>(w, 0), a1 = a0;
@@ -353,41 +335,7 @@ __device__ __forceinline__ void rs_step(f32x16 (&acc)[NTILES], const u32x4* w, c
     for (int q = (u * PMAX + NTILES - 1) / NTILES; q < ((u + 1) * PMAX + NTILES - 1) / NTILES; ++q) dma(q);
 #pragma unroll
     for (int p = (u * 4) / NTILES; p < ((u + 1) * 4) / NTILES; ++p) filler(p);
-    side(u);
     rs_mma<PC>(acc[u], a0, b);
-    if constexpr (!std::is_same<std::decay_t<S>, RsNoSide>::value && RS_SIDE_INTERLEAVE) {
-      // with side work in the region: spread the independent instructions over the gaps of the MFMA chain (four plain vector
-      // instructions fit a gap for free; the scheduler's own order bunches eight and more into one)
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-        if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        if (k == 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read (LDS-DMA)
-        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);       // SALU
-        __builtin_amdgcn_sched_group_barrier(0x002, RS_SIDE_INTERLEAVE, 0);       // VALU
-      }
-    }
-#if RS_INTERLEAVE == 1
-    // issue order within the tile: one MFMA, then a few of the independent instructions (the three LDS reads, a DMA piece,
-    // a slice of the split) that fit its 32-cycle shadow -- not all of them behind the first MFMA
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-      if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-      if (k == 3) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read (LDS-DMA)
-      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);       // SALU
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);       // VALU
-    }
-#elif RS_INTERLEAVE == 2
-    // the six MFMAs of a tile are a dependent chain on its accumulator: issued back to back they forward the accumulator at
-    // full rate, any instruction between two of them breaks that (~40 cycles, MI355X_MICROARCH.md) -- so everything else
-    // of the region goes in front of the chain, where the neighbouring MFMAs belong to another tile's accumulator
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);         // DS read
-    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);         // VMEM read (LDS-DMA)
-    __builtin_amdgcn_sched_group_barrier(0x004, 16, 0);        // SALU
-    __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);        // VALU
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);         // MFMA
-#endif
     __builtin_amdgcn_sched_barrier(0);
     a0 = a1;
     if (PREFETCH) a1 = a2;
@@ -479,47 +427,6 @@ __device__ __forceinline__ void rs_product_x(f32x16 (&acc)[NTILES], const X xs, 
       }
     }
   }
-}
-
-// rs_product_x for one K step per weight chunk (more than 8 tiles), with side work: the first `pairs` PAIRS of K steps call
-// side.begin(pair) and then side.template piece<m>() in the region of tile u of step 2 pair + par, m = par NTILES + u -- a
-// compile-time piece in every region, so that its instructions share the region's basic block with the six MFMAs and the compiler
-// can place them between those (a wave-uniform branch per region would fence them off).  Steps beyond the pairs: plain.
-template <int NTILES, bool PREFETCH, int PC, class X, class Stream, class Side>
-__device__ __forceinline__ void rs_product_x_side(f32x16 (&acc)[NTILES], const X xs, const RsRow rw, int ks1, Stream& ws, int pairs,
-                                                  Side& side) {
-  static_assert(rs_spc(NTILES, Stream::STG_) == 1, "one K step per chunk");
-  float xv[8];
-  RS_WAIT(4, 15);
-  __builtin_amdgcn_sched_barrier(0);
-  xs.read(xv, 0, 0);
-  RsFrag b = rs_split<PC>(xv);
-  int slot = 1;
-  auto step = [&](int s, auto par_tag, auto with_side) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par_tag)::value;
-    constexpr bool WITH = decltype(with_side)::value;
-    const u32x4* w = ws.template acquire<0>();
-    RS_WAIT(2, 15);
-    __builtin_amdgcn_sched_barrier(0);
-    xs.read(xv, s + 1, slot);
-    xs.issue(s + 3, slot == 0 ? 2 : slot - 1, rw);
-    slot = slot == 2 ? 0 : slot + 1;
-    RsFrag bn;
-    rs_step<NTILES, PREFETCH, Stream::PMAX, PC>(acc, w, b,
-                              [&](int p) { rs_split_pair<PC, true>(xv[2 * p], xv[2 * p + 1], bn.h[p], bn.m[p], bn.l[p]); },
-                              [&](int q) { ws.piece(q); },
-                              [&](int u) __attribute__((always_inline)) {
-                                if constexpr (WITH) side.step_piece(std::integral_constant<int, PAR>(), u);
-                              });
-    b = bn;
-  };
-  int s = 0;
-  for (int pr = 0; pr < pairs; ++pr, s += 2) {
-    side.begin(pr);
-    step(s, std::integral_constant<int, 0>(), std::true_type());
-    step(s + 1, std::integral_constant<int, 1>(), std::true_type());
-  }
-  for (; s < ks1; ++s) step(s, std::integral_constant<int, 0>(), std::false_type());
 }
 
 // dst[u] (u < NTILES) += W[tile u] src^T where src is NS accumulator tiles of this lane's row (the output of a previous
@@ -669,150 +576,10 @@ __device__ __forceinline__ void rs_decode_epilogue(f32x16 (&o)[NT], const RsDeco
   }
 }
 
-// The same draw cut into 24 pieces per coordinate so that it can run in the shadow of the NEXT row block's first product instead of
-// behind this block's last one with the matrix pipe idle (one wavefront per SIMD at this width: nobody else would use it): the
-// output tiles of a row block are parked (`pending`), and while the following block's x W1^T / x W0^T is being multiplied, K steps
-// 2 p and 2 p + 1 carry the 24 pieces of coordinate p -- one per tile region (12 tiles per step), a handful of vector instructions
-// each, which the compiler places between the region's six MFMAs.  Piece m of a coordinate (v = this lane's 16 logits of it):
-//   0-3   prior of bins 8 q + 4 g .. + 3 added (q = m)                 4-5   max over the 32 bins (cross-lane exchange in between)
-//   6-13  softmax_exp of elements 2 j, 2 j + 1 (j = m - 6)             14-21 the running sum in bin order, round q = (m - 14) / 2:
-//   22    target = uniform x total; count of cdf <= target                   lanes g = 0 continue `back`, hand over, lanes g = 1 continue
-//   23    counts of the two lanes added; the bin stored                      and hand back (two pieces per round)
-// The arithmetic per coordinate is rs_decode_epilogue's (= decode_bins_kernel<32>'s), bit for bit; only the interleaving differs.
-struct RsDraw {
-  f32x16 v;
-  float mx, ex, back, fwd, tot, tb3, ta[4], uni;
-  int cnt, cx;
-  const float* pr;              // prior of this coordinate's 32 bins (this lane's 4 g offset applied) or NULL
-  float ppos, pis;              // generated prior: position of this coordinate, 1 / sigma (pis == 0: none)
-  int32_t* bin;                 // where the bin goes (NULL: row out of range)
-};
-
-template <int M, int PC>
-__device__ __forceinline__ void rs_draw_piece(RsDraw& d, int g, float bs) {
-  if constexpr (M < 4) {
-    constexpr int q = M;
-    if (PC == 2) {                               // back to the true scale (f16x2: the accumulators carry the weight scale)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) d.v[4 * q + i] *= bs;
-    }
-    if (d.pr) {
-      const f32x4 p4 = *reinterpret_cast<const f32x4*>(d.pr + 8 * q);
-      d.v[4 * q + 0] += p4.x; d.v[4 * q + 1] += p4.y; d.v[4 * q + 2] += p4.z; d.v[4 * q + 3] += p4.w;
-    } else if (d.pis != 0.0f) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float z = ((float)(i + 8 * q + 4 * g) - d.ppos) * d.pis;
-        d.v[4 * q + i] += (z * z) * -0.5f;
-      }
-    }
-  } else if constexpr (M == 4) {
-    float m = d.v[0];
-#pragma unroll
-    for (int e = 1; e < 16; ++e) m = fmaxf(m, d.v[e]);
-    d.mx = m;
-    d.ex = __shfl_xor(m, 32);
-  } else if constexpr (M == 5) {
-    d.mx = fmaxf(d.mx, d.ex);
-    d.back = 0.0f;
-  } else if constexpr (M < 14) {
-    constexpr int j = M - 6;
-    d.v[2 * j] = softmax_exp(d.v[2 * j] - d.mx);
-    d.v[2 * j + 1] = softmax_exp(d.v[2 * j + 1] - d.mx);
-  } else if constexpr (M < 22) {
-    constexpr int q = (M - 14) >> 1;
-    if constexpr (((M - 14) & 1) == 0) {         // lanes g = 0: bins 8 q .. 8 q + 3 continue the total the partner sent back
-      d.ta[0] = d.back + d.v[4 * q + 0];
-      d.ta[1] = d.ta[0] + d.v[4 * q + 1];
-      d.ta[2] = d.ta[1] + d.v[4 * q + 2];
-      d.ta[3] = d.ta[2] + d.v[4 * q + 3];
-      d.fwd = __shfl_xor(d.ta[3], 32);
-    } else {                                     // lanes g = 1: bins 8 q + 4 .. 8 q + 7 continue from there
-      const float t0 = d.fwd + d.v[4 * q + 0];
-      const float t1 = t0 + d.v[4 * q + 1];
-      const float t2 = t1 + d.v[4 * q + 2];
-      const float t3 = t2 + d.v[4 * q + 3];
-      d.back = __shfl_xor(t3, 32);
-      d.tb3 = t3;
-      d.v[4 * q + 0] = g ? t0 : d.ta[0]; d.v[4 * q + 1] = g ? t1 : d.ta[1];
-      d.v[4 * q + 2] = g ? t2 : d.ta[2]; d.v[4 * q + 3] = g ? t3 : d.ta[3];   // this lane's CDF values
-    }
-  } else if constexpr (M == 22) {
-    d.tot = g ? d.tb3 : d.back;                  // after round 3: the total, on both lanes
-    const float target = d.uni * d.tot;
-    int c = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) c += (d.v[e] <= target) ? 1 : 0;
-    d.cnt = c;
-    d.cx = __shfl_xor(c, 32);
-  } else {
-    const int c = d.cnt + d.cx;
-    if (d.bin && g == 0) *d.bin = c < 31 ? c : 31;
-  }
-}
-
-// piece m (runtime, wave-uniform) of the coordinate in `d`
-template <int PC>
-__device__ __forceinline__ void rs_draw_dispatch(RsDraw& d, int m, int g, float bs) {
-  switch (m) {
-#define RS_DRAW_CASE(M) case M: rs_draw_piece<M, PC>(d, g, bs); break;
-    RS_DRAW_CASE(0) RS_DRAW_CASE(1) RS_DRAW_CASE(2) RS_DRAW_CASE(3) RS_DRAW_CASE(4) RS_DRAW_CASE(5) RS_DRAW_CASE(6) RS_DRAW_CASE(7)
-    RS_DRAW_CASE(8) RS_DRAW_CASE(9) RS_DRAW_CASE(10) RS_DRAW_CASE(11) RS_DRAW_CASE(12) RS_DRAW_CASE(13) RS_DRAW_CASE(14) RS_DRAW_CASE(15)
-    RS_DRAW_CASE(16) RS_DRAW_CASE(17) RS_DRAW_CASE(18) RS_DRAW_CASE(19) RS_DRAW_CASE(20) RS_DRAW_CASE(21) RS_DRAW_CASE(22) RS_DRAW_CASE(23)
-#undef RS_DRAW_CASE
-    default: break;
-  }
-}
-
-// the parked output tiles of one row block (six separate values, not an array: coordinate p is picked by per-element selects --
-// an array indexed by the wave-uniform p would be placed in scratch memory) and the row they belong to
-struct RsPending {
-  f32x16 o0, o1, o2, o3, o4, o5;
-  int64_t row;                  // < 0: nothing parked
-  bool in;
-};
-
-// coordinate p of the parked block becomes the coordinate being drawn
-__device__ __forceinline__ void rs_draw_begin(RsDraw& d, const RsPending& pd, const RsDecode& dc, int p, int g) {
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float x = pd.o0[e];
-    x = p == 1 ? pd.o1[e] : x;
-    x = p == 2 ? pd.o2[e] : x;
-    x = p == 3 ? pd.o3[e] : x;
-    x = p == 4 ? pd.o4[e] : x;
-    x = p == 5 ? pd.o5[e] : x;
-    asm volatile("" : "+v"(x));                  // (keeps the selects: no lookup through memory)
-    d.v[e] = x;
-  }
-  d.pr = dc.prior ? dc.prior + pd.row * 192 + 32 * p + 4 * g : nullptr;
-  d.pis = (!dc.prior && dc.prior_pos) ? dc.prior_inv_sigma : 0.0f;
-  d.ppos = d.pis != 0.0f ? dc.prior_pos[pd.row * 6 + p] : 0.0f;
-  d.uni = dc.uniforms[pd.row * 6 + p];
-  d.bin = pd.in ? dc.bins + pd.row * 6 + p : nullptr;
-}
-
-// the side work of rs_product_x_side: pair p of K steps draws coordinate p of the parked block
-template <int PC>
-struct RsDrawSide {
-  RsDraw& d;
-  const RsPending& pd;
-  const RsDecode& dc;
-  int g;
-  float bs;
-  __device__ __forceinline__ void begin(int pair) { rs_draw_begin(d, pd, dc, pair, g); }
-  template <int PAR>
-  __device__ __forceinline__ void step_piece(std::integral_constant<int, PAR>, int u) {
-    // u is the induction variable of an unrolled loop: after unrolling exactly one case is left in every tile region
-    switch (u) {
-#define RS_SIDE_CASE(U) case U: rs_draw_piece<PAR * 12 + U, PC>(d, g, bs); break;
-      RS_SIDE_CASE(0) RS_SIDE_CASE(1) RS_SIDE_CASE(2) RS_SIDE_CASE(3) RS_SIDE_CASE(4) RS_SIDE_CASE(5)
-      RS_SIDE_CASE(6) RS_SIDE_CASE(7) RS_SIDE_CASE(8) RS_SIDE_CASE(9) RS_SIDE_CASE(10) RS_SIDE_CASE(11)
-#undef RS_SIDE_CASE
-      default: break;
-    }
-  }
-};
+// the claimed-row-block slots in LDS (dynamic scheduling): workgroup-scope relaxed atomics -- ordered by the workgroup barriers
+// between the store and the loads, and not movable across them by the compiler
+__device__ __forceinline__ void rs_claim_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int rs_claim_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct RsTap {                  // optional second output: the activation after the FIRST layer of a chained launch
   float* out = nullptr;         // [rows, >= n_out] or NULL
@@ -968,10 +735,13 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
   int* const sched = ga.sched;
   const bool dyn = sched != nullptr && !LIN;
   // (the claim slots: 16 bytes of the dynamic LDS behind the biases -- a static array would not fit beside 160 KiB of dynamic LDS)
+  // (accessed with workgroup-scope atomics only -- rs_claim_store / rs_claim_load: thread 0's stores and every lane's loads stay where
+  // they are written relative to the barriers of the products; the s_barrier builtin carries no memory semantics the compiler would
+  // have to respect for plain LDS accesses)
   int* const s_claim = reinterpret_cast<int*>(s_ring + 2 * rs_stage_bytes(rs_stage_tiles(MODE)) + WAVES * 3 * 2048 + (2 + chain) * 32 * NT * 4);
   if (dyn) { bfirst = blockIdx.x; bstride = 0; bend = nblocks; }
   const int64_t mine = dyn ? (bfirst < bend ? 1 : 0) : (bend > bfirst ? (bend - bfirst + bstride - 1) / bstride : 0);
-  if (dyn && threadIdx.x == 0) s_claim[0] = (int)gridDim.x + atomicAdd(&sched[0], 1);
+  if (dyn && threadIdx.x == 0) rs_claim_store(&s_claim[0], (int)gridDim.x + atomicAdd(&sched[0], 1));
 
   constexpr int STG = rs_stage_tiles(MODE), RING_BYTES = 2 * rs_stage_bytes(STG);
   RsStream<NT, T0, WAVES, PC, LIN, STG> ws;
@@ -1045,7 +815,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     }
     return rw;
   };
-  int64_t next_blk = dyn ? (int64_t)s_claim[0] : bfirst + bstride;      // (after the barrier above)
+  int64_t next_blk = dyn ? (int64_t)rs_claim_load(&s_claim[0]) : bfirst + bstride;      // (after the barrier above)
   int par = 1;
   RsRow cur = row_of(bfirst < bend ? bfirst : 0);
   auto first_tiles = [&](const RsRow rw) {        // x tiles of K steps 0, 1, 2 of a row block into slots 0, 1, 2
@@ -1099,11 +869,6 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     RS_WAIT(0, 15);
     return;
   }
-  // DECODE: the output tiles of the previous row block, drawn during this block's first product (RsDraw)
-  RsPending pend;
-  RsDraw draw;
-  pend.row = -1;
-  pend.in = false;
   for (int64_t blk = bfirst; blk < bend;) {
     const int64_t row = blk * BLOCK_ROWS + wave * 32 + r;
     const bool in = row < rows;
@@ -1159,24 +924,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     }
     {
       f32x16 (&first)[T0] = *reinterpret_cast<f32x16 (*)[T0]>(&acc[0]);
-      if constexpr (DECODE && NT == 6 && RS_DEFER_DRAW) {
-        // K steps 2 p, 2 p + 1 draw coordinate p of the parked block (p < 6, both steps inside the product); 12 tiles per step
-        static_assert(T0 == 12, "24 pieces per coordinate = two K steps of twelve tile regions");
-        if (pend.row >= 0) {
-          const int pairs = (ks1 >> 1) < 6 ? (ks1 >> 1) : 6;
-          RsDrawSide<PC> side{draw, pend, dc, g, bs};
-          rs_product_x_side<T0, PF, PC>(first, xs, cur, ks1, ws, pairs, side);
-          for (int p = pairs; p < 6; ++p) {       // coordinates the product was too short for
-            rs_draw_begin(draw, pend, dc, p, g);
-#pragma unroll
-            for (int m = 0; m < 24; ++m) rs_draw_dispatch<PC>(draw, m, g, bs);
-          }
-        } else {
-          rs_product_x<T0, PF, PC>(first, xs, cur, ks1, ws);
-        }
-      } else {
-        rs_product_x<T0, PF, PC>(first, xs, cur, ks1, ws);
-      }
+      rs_product_x<T0, PF, PC>(first, xs, cur, ks1, ws);
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -1203,7 +951,7 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
         for (int u = 0; u < NT; ++u) rs_load_tile(o[u], ((RS_DBG & 32) ? (const float*)s_b1 : xrow) + 32 * u, g);
       }
     }
-    if (dyn && threadIdx.x == 0) s_claim[par] = (int)gridDim.x + claim;   // (read at the loop's end: barriers of the products between)
+    if (dyn && threadIdx.x == 0) rs_claim_store(&s_claim[par], (int)gridDim.x + claim);   // (read at the loop's end: barriers of the products between)
     // the next row block's first x tiles travel during the remaining products (their slots are free now)
     if (more) first_tiles(nxt);
     cur = nxt;
@@ -1238,13 +986,9 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
       rs_product_h<NT, NT, PF, PC>(o, h, ws, bs);
     }
     if (DECODE) {
-      if constexpr (NT == 6 && RS_DEFER_DRAW) {   // parked: drawn under the next block's first product (or after the loop)
-        pend.o0 = o[0]; pend.o1 = o[1]; pend.o2 = o[2]; pend.o3 = o[3]; pend.o4 = o[4]; pend.o5 = o[5];
-        pend.row = in ? row : rows - 1;
-        pend.in = in;
-      } else if constexpr (NT == 6) {
-        rs_decode_epilogue<NT, PC>(o, dc, in ? row : rows - 1, in, g, bs);
-      }
+      // (the draw as the row block's own epilogue.  Cut into pieces and hidden under the NEXT block's first product it was
+      // slower -- round 4, 2.18 against 2.06 ms -- and left the source in round 6: docs/experiments/r6_removed_mlp_variants.patch)
+      if constexpr (NT == 6) rs_decode_epilogue<NT, PC>(o, dc, in ? row : rows - 1, in, g, bs);
     } else if (in && (!(RS_DBG & 32) || o[0][0] == 1.2345e30f)) {
       float* orow = out + row * ldo + 4 * g;
 #pragma unroll
@@ -1260,17 +1004,8 @@ __global__ __launch_bounds__(64 * rs_waves_mode(NT, MODE), rs_wgs_per_cu(MODE)) 
     }
     blk = nb;
     if (dyn) {
-      next_blk = s_claim[par];
+      next_blk = rs_claim_load(&s_claim[par]);
       par ^= 1;
-    }
-  }
-  if constexpr (DECODE && NT == 6 && RS_DEFER_DRAW) {
-    if (pend.row >= 0) {                          // the last row block's draw: nothing left to hide it behind
-      for (int p = 0; p < 6; ++p) {
-        rs_draw_begin(draw, pend, dc, p, g);
-#pragma unroll
-        for (int m = 0; m < 24; ++m) rs_draw_dispatch<PC>(draw, m, g, bs);
-      }
     }
   }
   // Nothing may be in flight when the wavefront ends: the pieces issued during the last chunk (plan() past the end: a re-read of
@@ -1306,10 +1041,10 @@ extern "C" int cppf_reslayer_split_debug_grid(int32_t workgroups) {
 
 // Batch-mode knob (include/cppf_hip.h): CUs every persistent launch leaves to the kernels of other streams
 static std::atomic<int> g_rs_reserved_cus{0};
+// returns the previous reservation (>= 0); a negative argument only queries
 extern "C" int cppf_mlp_reserve_cus(int32_t cus) {
-  CPPF_CHECK_ARG(cus >= 0 && cus <= 1024);
-  g_rs_reserved_cus.store(cus);
-  return CPPF_OK;
+  CPPF_CHECK_ARG(cus <= 1024);
+  return cus < 0 ? g_rs_reserved_cus.load() : g_rs_reserved_cus.exchange(cus);
 }
 
 template <int NT, bool PROJ, bool GATHER = false, bool DECODE = false, int PC = 3, int MODE = RS_RESLAYER>
@@ -1512,9 +1247,10 @@ extern "C" int cppf_reslayer_split_encode(int B, const float* pts, const float* 
 // uniforms[t, c] -- the same arithmetic as cppf_decode_bins, bit for bit -- so the logits are never written; follow with
 // cppf_decode_from_bins for the vote parameters.  x / wq / b1 / b0 as cppf_reslayer_split with n_out = 192, chain = 0;
 // logit_prior float32 [rows, 192] or NULL, uniforms float32 [rows, 6], bins int32 [rows, 6].
-extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
-                                          const float* b1, const float* b0, const float* logit_prior, const float* prior_pos,
-                                          float prior_inv_sigma, const float* uniforms, int32_t* bins, int32_t* sched, void* stream) {
+extern "C" int cppf_reslayer_split_decode_prior(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
+                                                const float* b1, const float* b0, const float* logit_prior, const float* prior_pos,
+                                                float prior_inv_sigma, const float* uniforms, int32_t* bins, int32_t* sched,
+                                                void* stream) {
   CPPF_CHECK_ARG(x && wq && b1 && b0 && uniforms && bins && rows >= 0);
   CPPF_CHECK_ARG(!(logit_prior && prior_pos) && (!prior_pos || (prior_inv_sigma > 0.0f && prior_inv_sigma < INFINITY)));
   CPPF_CHECK_ARG(k_in > 0 && (k_in & 7) == 0 && ldx >= k_in && (ldx & 3) == 0);
@@ -1534,6 +1270,14 @@ extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k
   ga.sched = sched;
   return rs_launch<6, true, false, true>(x, ldx, k_in, nullptr, 192, rows, static_cast<const char*>(wq), b1, b0, 0,
                                          n_cu > 0 ? n_cu : 256, (hipStream_t)stream, ga, dc);
+}
+
+
+// the stable form: the reference draws from the network's own logits (eval.py:225-229)
+extern "C" int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
+                                          const float* b1, const float* b0, const float* uniforms, int32_t* bins, int32_t* sched,
+                                          void* stream) {
+  return cppf_reslayer_split_decode_prior(x, ldx, k_in, rows, wq, wq_bytes, b1, b0, nullptr, nullptr, 0.0f, uniforms, bins, sched, stream);
 }
 
 

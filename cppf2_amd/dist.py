@@ -31,9 +31,26 @@ def force_collective():
     return os.environ.get("CPPF_DIST_FORCE_COLLECTIVE", "0") not in ("", "0")
 
 
-def init(backend=None, device=None):
+INIT_TIMEOUT_S = 180.0
+
+
+class DistInitError(RuntimeError):
+    """The process group could not be formed: carries rank, backend and the rendezvous address in its message."""
+
+
+def rendezvous_description(backend):
+    return "rank %s/%s backend %s MASTER_ADDR=%s MASTER_PORT=%s LOCAL_RANK=%s" % (
+        os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+        os.environ.get("LOCAL_RANK"))
+
+
+def init(backend=None, device=None, timeout_s=None):
     """Initialises torch.distributed from the torchrun environment (no-op for a single process unless the collective is
-    forced, see force_collective())."""
+    forced, see force_collective()).  The rendezvous and every later collective are bounded by `timeout_s` (default
+    INIT_TIMEOUT_S = 180 s, CPPF_DIST_TIMEOUT_S overrides; torch's default of 10 minutes would hold a GPU box that long on a wedged
+    RCCL bootstrap); a failure raises DistInitError naming the rank, the backend and MASTER_* -- the caller exits non-zero with
+    it (never a re-exec)."""
+    from datetime import timedelta
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if dist.is_initialized():
         return dist.get_world_size(), dist.get_rank()
@@ -44,10 +61,16 @@ def init(backend=None, device=None):
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-    kw = {}
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("CPPF_DIST_TIMEOUT_S", INIT_TIMEOUT_S))
+    kw = {"timeout": timedelta(seconds=float(timeout_s))}
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
-    dist.init_process_group(backend, **kw)
+    try:
+        dist.init_process_group(backend, **kw)
+    except Exception as e:      # noqa: BLE001  (store timeouts, connection refusals, RCCL bootstrap errors: all fatal here)
+        raise DistInitError("init_process_group failed within %.0f s (%s): %s: %s"
+                            % (timeout_s, rendezvous_description(backend), type(e).__name__, e)) from e
     return dist.get_world_size(), dist.get_rank()
 
 

@@ -422,7 +422,7 @@ class BinPrior:
     """A logit prior given by its generator instead of its [T, 6, 32] array: prior[t, c, k] = -0.5 ((k - pos[t, c]) * inv_sigma)^2,
     a Gaussian bump in logit space around a per-coordinate bin position (the synthetic teacher of the benchmarks and of
     eval.main's synthetic mode; a coarse pose hypothesis would supply the same).  The fused bin draw evaluates it in its epilogue
-    (cppf_reslayer_split_decode: prior_pos / prior_inv_sigma) -- 24 bytes per tuple read instead of 768; dense() is the array, built
+    (cppf_reslayer_split_decode_prior: prior_pos / prior_inv_sigma; the reference has no prior -- cppf_hip_experimental.h) -- 24 bytes per tuple read instead of 768; dense() is the array, built
     with the same three float32 operations in the same order, so both forms draw the same bins bit for bit."""
 
     def __init__(self, pos, inv_sigma):
@@ -456,10 +456,15 @@ def reslayer_split_decode(x, wq, b1, b0, uniforms, prior=None, bins=None):
     if bins is None:
         bins = torch.empty((rows, 6), dtype=torch.int32, device=x.device)
     assert bins.dtype == torch.int32 and bins.is_contiguous() and bins.numel() == rows * 6
-    _lib.check(_L.cppf_reslayer_split_decode(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
-                                             _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(ppos), C.c_float(pis), _p(u), _p(bins),
-                                             _sched(), _stream()),
-               "cppf_reslayer_split_decode")
+    if prior is None and ppos is None:       # the reference's draw (eval.py:225-229): the stable entry point
+        _lib.check(_L.cppf_reslayer_split_decode(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
+                                                 _p(b1.contiguous()), _p(b0.contiguous()), _p(u), _p(bins), _sched(), _stream()),
+                   "cppf_reslayer_split_decode")
+        return bins
+    _lib.check(_L.cppf_reslayer_split_decode_prior(_p(x), x.stride(0), x.shape[1], rows, _p(wq), wq.numel() * wq.element_size(),
+                                                   _p(b1.contiguous()), _p(b0.contiguous()), _p(prior), _p(ppos), C.c_float(pis), _p(u),
+                                                   _p(bins), _sched(), _stream()),
+               "cppf_reslayer_split_decode_prior")
     return bins
 
 
@@ -541,8 +546,12 @@ def batch_mode_reserved_cus(dev=None):
 
 def mlp_reserve_cus(cus):
     """cppf_mlp_reserve_cus: every later cppf_reslayer_split* launch of this process leaves `cus` CUs to the kernels of other
-    streams (0 = one persistent workgroup per CU).  Results do not depend on it."""
-    _lib.check(_L.cppf_mlp_reserve_cus(int(cus)), "cppf_mlp_reserve_cus")
+    streams (0 = one persistent workgroup per CU).  Results do not depend on it.  Returns the PREVIOUS reservation: nested users
+    (eval.run_ensemble inside a BatchMode block, ...) restore that instead of zeroing the outer one; cus < 0 only queries."""
+    prev = int(_L.cppf_mlp_reserve_cus(int(cus)))
+    if prev < 0:
+        _lib.check(prev, "cppf_mlp_reserve_cus")
+    return prev
 
 
 class mlp_cus_reserved:
@@ -553,11 +562,11 @@ class mlp_cus_reserved:
         self.cus = batch_mode_reserved_cus() if cus is None else int(cus)
 
     def __enter__(self):
-        mlp_reserve_cus(self.cus)
+        self.prev = mlp_reserve_cus(self.cus)
         return self
 
     def __exit__(self, *exc):
-        mlp_reserve_cus(0)
+        mlp_reserve_cus(self.prev)
         return False
 
 
@@ -744,9 +753,14 @@ def decode_bins(pred_cls, uniforms, points, point_idxs_all, up, right, front, pt
     tr = torch.empty((T, 2), dtype=torch.float32, device=dev)
     rot = torch.empty((T, 3), dtype=torch.float32, device=dev)
     pr = None if prior is None else _t(prior, torch.float32, dev).reshape(T, 6, nb)
-    _lib.check(_L.cppf_decode_bins(B, _p(lg), _p(pr), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
-                                   _axes9(up, right, front), _p(bins), _p(scaled), _p(scale), _p(tr), _p(rot),
-                                   _stream()), "cppf_decode_bins")
+    if pr is None:
+        _lib.check(_L.cppf_decode_bins(B, _p(lg), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
+                                       _axes9(up, right, front), _p(bins), _p(scaled), _p(scale), _p(tr), _p(rot),
+                                       _stream()), "cppf_decode_bins")
+    else:
+        _lib.check(_L.cppf_decode_bins_prior(B, _p(lg), _p(pr), nb, _p(un), _p(pts), _p(idx), k, _p(pt_off), _p(tup_off), T,
+                                             _axes9(up, right, front), _p(bins), _p(scaled), _p(scale), _p(tr), _p(rot),
+                                             _stream()), "cppf_decode_bins_prior")
     return dict(bins=bins, pred_pairs_scaled=scaled, scale=scale, targets_tr=tr, targets_rot=rot)
 
 

@@ -116,10 +116,16 @@ class VotingPipeline:
     def decode(self, pts, idx, logits, uniforms, prior=None):
         """prior (optional, same shape as logits) is added to the logits inside the kernel (== logits + prior)."""
         self.nb = int(logits.shape[-1])
-        _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), ops._p(prior), logits.shape[-1], ops._p(uniforms), ops._p(pts),
-                                       ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
-                                       self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
-                                       ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")
+        if prior is None:
+            _lib.check(_L.cppf_decode_bins(self.B, ops._p(logits), logits.shape[-1], ops._p(uniforms), ops._p(pts),
+                                           ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
+                                           self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
+                                           ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins")
+        else:                      # the synthetic benchmarks' teacher (the reference has no prior: cppf_hip_experimental.h)
+            _lib.check(_L.cppf_decode_bins_prior(self.B, ops._p(logits), ops._p(prior), logits.shape[-1], ops._p(uniforms), ops._p(pts),
+                                                 ops._p(idx), self.k, ops._p(self.pt_off), ops._p(self.tup_off), self.Ttot,
+                                                 self.axes, ops._p(self.bins), ops._p(self.scaled), ops._p(self.scale),
+                                                 ops._p(self.tr), ops._p(self.rot), ops._stream()), "cppf_decode_bins_prior")
 
     def decode_from_bins(self, pts, idx, nb=32):
         """The vote parameters from bins already drawn into self.bins (by the MLP's output layer:
@@ -326,12 +332,12 @@ class BatchMode:
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             st.wait_stream(cur)
-        ops.mlp_reserve_cus(self.reserve_cus if len(self.states) > 1 else 0)
+        self.prev_reserved = ops.mlp_reserve_cus(self.reserve_cus if len(self.states) > 1 else 0)
         self.active = True
         return self
 
     def __exit__(self, *exc):
-        ops.mlp_reserve_cus(0)
+        ops.mlp_reserve_cus(self.prev_reserved)     # (the enclosing block's reservation, not 0: ADVICE r5)
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             cur.wait_stream(st)

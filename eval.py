@@ -228,13 +228,13 @@ def run_ensemble(cfg, dino_model, shot_model, pcs, descs, seed, scene_ids, num_p
                              counts=pp.counts.cpu().numpy()))
 
     # (two streams: the persistent MLP launches leave one CU per shader engine to the other pass' kernels, cppf_mlp_reserve_cus)
-    ops.mlp_reserve_cus(ops.batch_mode_reserved_cus(dev) if two else 0)
+    prev_reserved = ops.mlp_reserve_cus(ops.batch_mode_reserved_cus(dev) if two else 0)
     try:
         for model_idx in (0, 1):                                                           # eval.py:219
             with torch.cuda.stream(streams[model_idx]):
                 one_pass(model_idx)
     finally:
-        ops.mlp_reserve_cus(0)
+        ops.mlp_reserve_cus(prev_reserved)        # an enclosing BatchMode / mlp_cus_reserved block keeps its reservation
     for st_ in streams:
         main.wait_stream(st_)
     # ---- ensemble selection (eval.py:217,365-372): strict '<' against inf, model 0 first -- on the device ---------

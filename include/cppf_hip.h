@@ -1,6 +1,15 @@
 /*
- * cppf_hip.h -- C ABI of libcppf_hip.so, the MI355X (gfx950) implementation of the
+ * cppf_hip.h -- the STABLE C ABI of libcppf_hip.so, the MI355X (gfx950) implementation of the
  * CPPF++ (qq456cvb/CPPF2) point-pair-feature voting hot path.
+ *
+ * ABI 11 (round 6) splits the interface in two.  THIS file is what a maintainer of the reference binds: the entry points the
+ * drop-in modules (eval.py, train_*.py, dataset.py, utils/util.py, src_shot/build/shot.py), INTEGRATION.md and the default bench
+ * call -- one per stage of the path, each with exactly the reference's semantics -- plus the workspace-size
+ * queries.  Everything else the library exports -- launch forms kept for A/B measurements, the f16x2 arithmetic, the float16
+ * table and weighted-vote extensions' helpers, the synthetic benchmarks' logit prior, test hooks -- is declared in
+ * cppf_hip_experimental.h and may change without an ABI bump.  tests/test_abi.py holds both files to the ctypes tables of
+ * cppf2_amd/_lib.py symbol by symbol; tests/test_zz_stable_abi_coverage_gpu.py asserts that a GPU test session calls every
+ * stable symbol through ctypes.
  *
  * The reference has no FFI of its own for this path except one pybind11 module
  * (src_shot/shot.cpp:164-168); everything else is Python glue over torch ops.  Each entry
@@ -38,7 +47,7 @@ extern "C" {
 #define CPPF_EHIP         -3   /* a HIP runtime call failed (see cppf_last_error_string) */
 #define CPPF_ECAPACITY    -4   /* a caller-provided capacity is too small */
 
-#define CPPF_ABI_VERSION 10
+#define CPPF_ABI_VERSION 11
 
 /* Per-scene voxel grid geometry: train_dino.py:172-173 (corners, grid_res). 32 bytes. */
 typedef struct CppfSceneGrid {
@@ -97,10 +106,6 @@ int64_t cppf_shot352_workspace_bytes(int B, int64_t total_points);
 int cppf_shot352(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r, float shot_r,
                  float* out_shot, float* out_normal, float* out_rf /* optional float32[n,9] local frames */,
                  void* workspace, int64_t workspace_bytes, int flags, void* stream);
-/* The descriptor half alone, on normals the caller already has (e.g. from cppf_estimate_normals). */
-int cppf_shot352_from_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points,
-                              const float* normals, float shot_r, float* out_shot, float* out_rf,
-                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* shot.compute_color (src_shot/shot.cpp:102-161 -> pcl::SHOTColorEstimation, SHOT1344): colors float32[total_points,3] in
  * [0,1] (stored as uint8 = c * 255 truncated, like the wrapper), out_shot float32[total_points,1344] = 32 sectors x 11
@@ -122,9 +127,6 @@ int cppf_shot_describe(int B, const float* pts, const int32_t* pt_off, int64_t t
                        int64_t workspace_bytes, void* stream);
 /* x[isnan(x)] = 0 in place, n floats: eval.py:216 on the normals (after the descriptor has read them). */
 int cppf_nan_to_zero(float* x, int64_t n, void* stream);
-/* out_half[i] = (float16) x[i], n elements (round to nearest even): the float16 feature table of BASELINE config 5 from the
- * point encoder's float32 output (cppf_encode_tuples_shot_f16 gathers it). */
-int cppf_cast_f16(const float* x, void* out_half, int64_t n, void* stream);
 /* estimate_normal(pc, normal_r) (src_shot/shot.cpp:12-42).  Same workspace size as cppf_shot352. */
 int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_t total_points, float normal_r,
                           float* out_normal, void* workspace, int64_t workspace_bytes, int flags, void* stream);
@@ -134,26 +136,13 @@ int cppf_estimate_normals(int B, const float* pts, const int32_t* pt_off, int64_
  *   feat[idx_0..k-1] (k*feat_dim)]; feat is the per-point output of shot_encoder, float32[n,feat_dim],
  *   feat_dim % 4 == 0.  out: float32[tup_off[B], C(k,2)*4 + k*feat_dim].
  * DINO model (train_dino.py:92): only the coordinate part, written at the start of rows of
- *   `out_stride` floats (the descriptor part is an nn.Linear, left to PyTorch). */
+ *   `out_stride` floats (the descriptor part: cppf_linear_split + cppf_reslayer_split_sumencode below). */
 int cppf_encode_tuples_shot(int B, const float* pts, const float* normals, const float* feat, int feat_dim,
                             const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                             int64_t total_tuples, float* out, void* stream);
-/* Same row layout from a half-precision feature table (float16 [n, feat_dim], feat_dim % 8 == 0), float32 output
- * (BASELINE config 5, "fp16 features"; not in the reference -- equals the float32 entry on half-rounded features). */
-int cppf_encode_tuples_shot_f16(int B, const float* pts, const float* normals, const void* feat_half, int feat_dim,
-                                const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
-                                int64_t total_tuples, float* out, void* stream);
 int cppf_encode_tuples_coord(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
                              const int32_t* tup_off, int64_t total_tuples, float* out, int out_stride,
                              void* stream);
-
-/* a3' descriptor part (DINO model): replaces desc_pair_transform(cat_i desc_transform(desc[idx_i])) (train_dino.py:95-96)
- * by a gather-add of per-point products: tables float32[total_points, k, D] with tables[n][i] = W_i . d[n] (W_i = the i-th
- * column block of desc_pair_transform.weight, d = desc_transform(desc)), bias float32[D] or NULL;
- * out[t, out_col + c] = bias[c] + sum_i tables[pt_off[b] + idx[t,i]][i][c].  D % 4 == 0; out row stride in floats. */
-int cppf_encode_tuples_dino(int B, const float* tables, int k, int D, const float* bias, const int32_t* idx,
-                            const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, float* out,
-                            int out_stride, int out_col, void* stream);
 
 /* ---- a4+a5. bin decode + vote parameters: replaces eval.py:225-240 (softmax, one multinomial draw per
  * (tuple, coord) by inverse CDF from `uniforms`, bin/(nb-1)-0.5, per-pair metric scale) fused with
@@ -162,10 +151,9 @@ int cppf_encode_tuples_dino(int B, const float* tables, int k, int D, const floa
  * in the positional order handed to generate_target_pairs (eval.py passes up, front, right).
  * Outputs (any may be NULL): bins int32[T,6], scaled float32[T,6] (pred_pairs_scaled), scale float32[T],
  * tr float32[T,2] (proj_len, dist2o), rot float32[T,3].
- * logit_prior (optional, same shape as logits): added to the logits before the softmax with one float32 add each
- * (an extension: a per-bin prior without a separate pass over the 15 MB/scene logit tensor; NULL = none). */
-int cppf_decode_bins(int B, const float* logits, const float* logit_prior, int nb, const float* uniforms,
-                     const float* pts,
+ * (The reference has no logit prior; the synthetic benchmarks' stand-in for trained weights is cppf_decode_bins_prior in
+ * cppf_hip_experimental.h.) */
+int cppf_decode_bins(int B, const float* logits, int nb, const float* uniforms, const float* pts,
                      const int32_t* idx, int k, const int32_t* pt_off, const int32_t* tup_off,
                      int64_t total_tuples, const double* h_axes, int32_t* bins, float* scaled, float* scale,
                      float* tr, float* rot, void* stream);
@@ -255,13 +243,10 @@ int cppf_rot_bins2(int B, const float* pts, const int32_t* pt_off, const int32_t
                    float* counts, int32_t* top_idx, float* top_count,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Global tuple rows of the kept pairs, int64[B, max_kept] (device): row = tup_off[b] + kept_tuple[tup_off[b] + j] for
- * j < kept_count[b], the scene's first tuple row otherwise -- the fixed-shape index a caller gathers per-pair tensors with
- * (e.g. the tuple features the scale head runs on, eval.py:272) without reading kept_count on the host. */
-int cppf_kept_rows(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count, int max_kept,
-                   int64_t* rows, void* stream);
-/* The same list as int32[B, max_kept] (what cppf_reslayer_split_gather and cppf_reslayer_tail index with); a scene without
- * tuples pads with row 0.  Padded entries are valid rows to read and are never written through (cppf_reslayer_tail skips
+/* Global tuple rows of the kept pairs, int32[B, max_kept] (device): row = tup_off[b] + kept_tuple[tup_off[b] + j] for
+ * j < kept_count[b], the scene's first tuple row otherwise -- the fixed-shape index a caller gathers per-pair tensors with (the
+ * tuple features the scale head runs on, eval.py:272; what cppf_reslayer_tail scatters through) without reading kept_count on
+ * the host; a scene without tuples pads with row 0.  Padded entries are valid rows to read and are never written through (cppf_reslayer_tail skips
  * them by kept_count). */
 int cppf_kept_rows32(int B, const int32_t* tup_off, const int32_t* kept_tuple, const int32_t* kept_count, int max_kept,
                      int32_t* rows, void* stream);
@@ -342,14 +327,6 @@ int cppf_interpolate_features(const float* desc, int C, int h, int w, int64_t st
                               int64_t stride_x, const float* pts, int n, float strides, int normalize, void* out,
                               int out_f16, void* stream);
 
-/* ---- 128-wide residual layer of the tuple / point encoders (train_shot.py:19-45 ResLayer with dim_in == dim_out == 128,
- * bn = dropout = False; five of the six layers of `tuple_encoder` and `shot_encoder`):
- *     x <- x + relu(x W1^T + b1) W2^T        in place on x float32[rows,128] (device, contiguous)
- * w1, w2: float32[128,128] row-major [out,in] (the nn.Linear weights), b1 float32[128]; fc2's bias is left to the caller
- * (it commutes with the residual stream).  One kernel on the f32 matrix cores: both products of a 32-row tile stay in
- * registers.  float32 in, float32 accumulate: results differ from a library GEMM's only by summation order. */
-int cppf_reslayer128(float* x, int64_t rows, const float* w1, const float* b1, const float* w2, void* stream);
-
 /* ---- a ResLayer with at most 8 outputs (the scale head's output layer ResLayer(64, 3), train_shot.py:67-71) in plain float32
  * (fmaf chains in index order: a float32 GEMM up to the summation order, independent of the row count), one thread per row:
  *     out[r] = skip(x[i]) + relu(x[i, :k_in] W1^T + b1) W2^T,   skip = x W0^T + b0 (b0 carries fc2's bias), or x when w0 == NULL
@@ -363,8 +340,9 @@ int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out,
                        const int32_t* valid_count, int32_t per_group, float* out, int64_t ldo, void* stream);
 
 /* ---- the ResLayers of the models (train_shot.py:19-45; bn = dropout = False), one or several per kernel, on the bf16
- * matrix cores in float32-equivalent arithmetic (every float32 operand is the exact sum of three bf16 values; six
- * exact-product MFMAs per K step, float32 accumulate; error against float64 = a float32 GEMM's, see cppf_mlp_split.hip):
+ * matrix cores in split-float32 arithmetic (every float32 operand is the exact sum of three bf16 values; the six largest of the
+ * nine bf16 products, each exact in float32, per K step; float32 accumulate.  Error against float64: within 3 x a library
+ * float32 GEMM's -- measured 2.4 x, tests/test_mlp_split.py holds e_split < 3 e_native + 2e-7 -- see cppf_mlp_split.hip):
  *     y = skip(x) + relu(x[:, :k_in] W1^T + b1) W2^T          skip(x) = x when b0 == NULL (then k_in == n_out; out may be
  *                                                              x itself: in place), x W0^T + b0 otherwise
  *     then `chain` times                       y <- y + relu(y W1_l^T + b1_l) W2_l^T   without leaving the registers
@@ -372,8 +350,8 @@ int cppf_reslayer_tail(const float* x, int64_t ldx, int32_t k_in, int32_t n_out,
  * pointers 16-byte aligned); k_in a multiple of 8 (columns of x beyond the layer's true dim_in must hold finite values;
  * their weights are zero in the stream); n_out in {64, 128, 192, 256}; b1 float32[(1 + chain) * n_out].  wq = the weights
  * pre-split into bf16 triples in the per-lane operand order the kernel streams (cppf2_amd.models.pack_split writes it;
- * cppf_reslayer_split_stream_bytes gives its size, -1 for unsupported shapes).  Each layer's fc2 bias is the caller's, as
- * for cppf_reslayer128.
+ * cppf_reslayer_split_stream_bytes gives its size, -1 for unsupported shapes).  Each layer's fc2 bias is the caller's (it commutes
+ * with the residual stream).
  * sched (ABI 10; every cppf_reslayer_split* entry point takes it in front of `stream`): NULL, or int32[2] device memory of the
  * caller's, ZERO before the first launch that uses it.  With it the launch's persistent workgroups claim their 128- / 256-row
  * blocks from a counter instead of taking a fixed share each: workgroups that start late or run slower -- another stream's
@@ -392,27 +370,15 @@ int cppf_reslayer_split_tap(const float* x, int64_t ldx, int32_t k_in, float* fi
                             int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
                             const float* b0, int32_t chain, int32_t* sched, void* stream);
 
-/* ---- the tuple encode feeding the tuple MLP without materialising its rows (train_shot.py:75-83 -> :100-111): the pair
- * features alone and the tuples' global point indices ...
- *   heads float32 [T, ld_heads >= 4 C(k,2)]: the first 4 C(k,2) columns of cppf_encode_tuples_shot's rows, bit for bit;
- *   gidx  int32 [T, k] = scene point base + idx
- * ... and the first ResLayer of the tuple encoder (a 128-wide projection layer, `chain` identity layers behind it) reading
- * row t = [heads[t, 0:head_cols] | table[gidx[t, 0]] | ... | table[gidx[t, slots-1]]] through its x-tile fetches: table
- * float32 [points, fdim] (the point encoder's output), fdim a power of two >= 8, head_cols % 8 == 0, slots <= 8; wq / b1 /
- * b0 / chain as cppf_reslayer_split for k_in = head_cols + slots * fdim.  Bit-identical to cppf_reslayer_split on the
- * materialised rows; saves writing and re-reading them (1.8 GB per 64 scenes). */
-int cppf_encode_tuples_shot_heads(int B, const float* pts, const float* normals, const int32_t* idx, int k,
-                                  const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, float* heads,
-                                  int32_t ld_heads, int32_t* gidx, void* stream);
-int cppf_reslayer_split_gather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
-                               const float* table, int32_t fdim, float* out, int64_t ldo, int32_t n_out, int64_t rows,
-                               const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
-                               int32_t* sched, void* stream);
-/* prepare_tuple_inputs (train_shot.py:75-83) and the tuple encoder's first launch in ONE kernel (ABI 9): the 40 pair features of a
- * 5-point tuple -- what cppf_encode_tuples_shot_heads writes, bit for bit -- are computed by the ResLayer kernel's own lanes from
- * pts / normals float32 [points, 3] and the sampler's scene-local idx int32 [rows, 5] (pt_off / tup_off int32 [B + 1]) and go
- * straight into its x tiles; the descriptors are gathered from `table` as in cppf_reslayer_split_gather.  No per-tuple array exists
- * between the sampler and the tuple encoder.  k = 5, n_out = 128; wq / b1 / b0 / chain for k_in = 40 + 5 fdim. */
+/* ---- prepare_tuple_inputs (train_shot.py:75-83) and the tuple encoder's first launch (train_shot.py:100-111) in ONE kernel: the
+ * first ResLayer of the tuple encoder (a 128-wide projection layer, `chain` identity layers behind it) on rows
+ * [40 pair features | table[pt_off[b] + idx[t, 0]] | ... | table[pt_off[b] + idx[t, 4]]] that are never written: the pair features of
+ * a 5-point tuple -- the first 40 columns of cppf_encode_tuples_shot's rows, bit for bit -- are computed by the kernel's own lanes
+ * from pts / normals float32 [points, 3] and the sampler's scene-local idx int32 [rows, 5] (pt_off / tup_off int32 [B + 1]) and go
+ * straight into its x tiles; the descriptors are gathered from table float32 [points, fdim] (the point encoder's output; fdim a
+ * power of two >= 8) by the x-tile fetches.  Bit-identical to cppf_reslayer_split on the materialised rows (1.8 GB per 64
+ * scenes saved).  k = 5, n_out = 128; wq / b1 / b0 / chain as cppf_reslayer_split for k_in = 40 + 5 fdim.  (The two-kernel forms
+ * of rounds 3-4, cppf_encode_tuples_shot_heads + cppf_reslayer_split_gather, are in cppf_hip_experimental.h.) */
 int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, const int32_t* idx, int32_t k,
                                const int32_t* pt_off, const int32_t* tup_off, const float* table, int32_t fdim, float* out,
                                int64_t ldo, int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1,
@@ -424,98 +390,49 @@ int cppf_reslayer_split_encode(int B, const float* pts, const float* normals, co
  *   cppf_reslayer_split; n_out a multiple of 256, k_in a multiple of 8; wq = cppf_linear_split_stream_bytes(k_in, n_out) bytes
  *   (cppf2_amd.models.pack_linear).  Replaces the library GEMMs of desc_transform (train_dino.py:86, 95) and of the per-slot
  *   slices of desc_pair_transform (train_dino.py:87, 96).
- * cppf_encode_tuples_coord_heads: heads float32 [T, ld_heads >= round8(3 C(k,2))] = the coordinate columns of
- *   cppf_encode_tuples_coord's rows (train_dino.py:92), bit for bit, zero-padded to a multiple of 8 columns; gidx int32 [T, k] =
- *   scene point base + idx.
- * cppf_reslayer_split_sumgather: the tuple encoder's first ResLayer (128-wide projection layer, `chain` identity layers behind
- *   it) on rows [heads | s(t)] where s(t) is linear in per-point vectors of the tuple's points (DINO: desc_pair_transform of the
- *   concatenated desc_transform outputs, train_dino.py:95-96; SHOT: the concatenated point features, train_shot.py:82): the
- *   per-point parts of x W1^T and x W0^T come from tables float32 [points, slots, 256] (= [W1_i p | W0_i p] per point p and slot
- *   i; point pitch ld_tables floats) that cppf_linear_split wrote from host-folded weights, and are summed into the
- *   accumulators in slot order; only the head columns run through the first product.  wq =
- *   cppf_reslayer_split_stream_bytes(head_cols, 128, 1, chain) bytes; b1 / b0 include the folded transforms' bias terms.
- *   Algebraically the reference's network; the [T, 286] / [T, 360] rows are never formed. */
+ * cppf_reslayer_split_sumencode: prepare_tuple_inputs (train_dino.py:91-97) + the tuple encoder's first ResLayer (128-wide projection
+ *   layer, `chain` identity layers behind it) on rows [30 coordinate differences | s(t)] that are never written, where s(t) =
+ *   desc_pair_transform of the concatenated desc_transform outputs of the tuple's points (train_dino.py:95-96) is linear in per-point
+ *   vectors: the per-point parts of x W1^T and x W0^T come from tables float32 [points, 5, 256] (= [W1_i p | W0_i p] per point p and
+ *   slot i; point pitch ld_tables floats) that cppf_linear_split wrote from host-folded weights, and are summed into the accumulators
+ *   in slot order; the coordinate columns are built by the kernel's own lanes from pts float32 [points, 3] and the sampler's
+ *   scene-local idx int32 [rows, 5] (pt_off / tup_off int32 [B + 1]) and are the only columns that run through the first product.
+ *   wq = cppf_reslayer_split_stream_bytes(32, 128, 1, chain) bytes; b1 / b0 include the folded transforms' bias terms.  k = 5,
+ *   n_out = 128.  Algebraically the reference's network; the [T, 286] rows are never formed.  (Two-kernel form:
+ *   cppf_encode_tuples_coord_heads + cppf_reslayer_split_sumgather, cppf_hip_experimental.h.) */
 int64_t cppf_linear_split_stream_bytes(int32_t k_in, int32_t n_out);
 int cppf_linear_split(const float* x, int64_t ldx, int32_t k_in, float* out, int64_t ldo, int32_t n_out, int64_t rows,
                       const void* wq, int64_t wq_bytes, const float* bias, void* stream);
-int cppf_encode_tuples_coord_heads(int B, const float* pts, const int32_t* idx, int k, const int32_t* pt_off,
-                                   const int32_t* tup_off, int64_t total_tuples, float* heads, int32_t ld_heads, int32_t* gidx,
-                                   void* stream);
-int cppf_reslayer_split_sumgather(const float* heads, int64_t ld_heads, int32_t head_cols, const int32_t* gidx, int32_t slots,
-                                  const float* tables, int64_t ld_tables, float* out, int64_t ldo, int32_t n_out, int64_t rows,
-                                  const void* wq, int64_t wq_bytes, const float* b1, const float* b0, int32_t chain,
-                                  int32_t* sched, void* stream);
-/* cppf_reslayer_split_sumgather with the coordinate columns built inside the kernel (ABI 9; RS_SUMENCODE): the DINO model's
- * prepare_tuple_inputs (train_dino.py:91-97) + its tuple encoder's first launch with no per-tuple array in between -- pts float32
- * [points, 3], idx int32 [rows, 5] scene-local tuple indices (the sampler's), pt_off / tup_off int32 [B + 1]; tables / wq / b1 / b0 /
- * chain as cppf_reslayer_split_sumgather with head_cols = 32.  k = 5, n_out = 128.  Bit-identical to the two-kernel form. */
 int cppf_reslayer_split_sumencode(int B, const float* pts, const int32_t* idx, int32_t k, const int32_t* pt_off,
                                   const int32_t* tup_off, const float* tables, int64_t ld_tables, float* out, int64_t ldo,
                                   int32_t n_out, int64_t rows, const void* wq, int64_t wq_bytes, const float* b1, const float* b0,
                                   int32_t chain, int32_t* sched, void* stream);
 
 /* ---- the bin draw fused into the MLP's output layer (eval.py:225-229 behind train_shot.py:62-66): the 192-wide projection
- * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]
- * (+ logit_prior[t, c, :])) at uniforms[t, c]  as its epilogue -- cppf_decode_bins' arithmetic bit for bit -- so that the
- * logits are never written; cppf_decode_from_bins then computes what the second half of cppf_decode_bins computes (scaled
- * pair, scale, targets_tr, targets_rot) from the bins.  x / wq / b1 / b0 as cppf_reslayer_split (n_out = 192, chain = 0);
- * logit_prior float32 [rows, 192] or NULL; uniforms float32 [rows, 6]; bins int32 [rows, 6].
- * prior_pos / prior_inv_sigma (ABI 10; instead of logit_prior, never both): the prior GENERATED in the epilogue --
- * prior[t, c, k] = -0.5 ((k - prior_pos[t, c]) * prior_inv_sigma)^2, float32, these three operations in this order -- a Gaussian bump
- * in logit space around a per-coordinate bin position (what a synthetic teacher or a coarse pose hypothesis supplies): 24 bytes per
- * row read instead of 768 (the array form costs the launch 0.34 ms per 1.28 M rows, all of it its 983 MB of reads).  Bit-identical
- * to passing the array built with the same three operations. */
+ * ResLayer of the logit head (6 coordinates x 32 bins) with  bins[t, c] = inverse-CDF draw of softmax(logits[t, c, :]) at
+ * uniforms[t, c]  as its epilogue -- cppf_decode_bins' arithmetic bit for bit -- so that the logits are never written;
+ * cppf_decode_from_bins then computes what the second half of cppf_decode_bins computes (scaled pair, scale, targets_tr,
+ * targets_rot) from the bins.  x / wq / b1 / b0 as cppf_reslayer_split (n_out = 192, chain = 0); uniforms float32 [rows, 6];
+ * bins int32 [rows, 6].  (With a logit prior -- the synthetic benchmarks' stand-in for trained weights; the reference has
+ * none -- cppf_reslayer_split_decode_prior, cppf_hip_experimental.h.) */
 int cppf_reslayer_split_decode(const float* x, int64_t ldx, int32_t k_in, int64_t rows, const void* wq, int64_t wq_bytes,
-                               const float* b1, const float* b0, const float* logit_prior, const float* prior_pos,
-                               float prior_inv_sigma, const float* uniforms, int32_t* bins, int32_t* sched, void* stream);
+                               const float* b1, const float* b0, const float* uniforms, int32_t* bins, int32_t* sched,
+                               void* stream);
 int cppf_decode_from_bins(int B, const int32_t* bins, int nb, const float* pts, const int32_t* idx, int k,
                           const int32_t* pt_off, const int32_t* tup_off, int64_t total_tuples, const double* h_axes,
                           float* scaled, float* scale, float* tr, float* rot, void* stream);
-
-/* ---- the same ResLayer launches in f16x2 arithmetic (cppf2_amd.models.MLP_ARITH = "split16"; not the default): every
- * float32 operand as an fp16 pair hi + lo (RNE; 22-23 significant bits), the three products hi hi + hi lo + lo hi on the fp16
- * matrix cores, float32 accumulate -- half the matrix-core work of the exact bf16-triple form, error against float64 at the
- * level of a float32 GEMM's accumulation error (tests/test_mlp_split.py, bench.py mlp_error_vs_f64), but NOT exact products, and
- * fp16's range: activations must stay below 65504 in magnitude (larger ones become Inf -> NaN rows); activations whose lo piece
- * is subnormal keep an absolute resolution of 2^-25.  wq = fp16 (hi, lo) fragment pairs of weight_scale x the weights in the
- * fragment order of cppf_reslayer_split (cppf_reslayer_split16_stream_bytes bytes), b1 / b0 = weight_scale x the biases,
- * weight_scale a power of two chosen so that the largest |weight| x weight_scale is ~2^13.  One struct for all launch forms:
- * plain (x, out[, first_out = tap]); gather (gidx != NULL: x = heads with k_in head columns, table, slots, fdim; n_out = 128);
- * decode (uniforms != NULL: n_out = 192, chain = 0, bins out, logit_prior optional).  Unused members must be zero. */
-typedef struct CppfReslayerSplit16Args {
-  const float* x; int64_t ldx; int32_t k_in;
-  float* out; int64_t ldo; int32_t n_out; int64_t rows;
-  const void* wq; int64_t wq_bytes; const float* b1; const float* b0; int32_t chain;
-  float weight_scale;
-  float* first_out; int64_t ld_first;
-  const int32_t* gidx; int32_t slots; const float* table; int32_t fdim;
-  const float* logit_prior; const float* uniforms; int32_t* bins;
-  void* stream;
-  int32_t mode;            /* 0: the forms above; 1: plain Linear (cppf_linear_split: n_out % 256 == 0, b1 = bias or NULL, b0 NULL);
-                              2: gather with per-point slot tables summed into the accumulators (cppf_reslayer_split_sumgather:
-                              table = [points, slots, 256], ld_table its point pitch, fdim unused) */
-  int64_t ld_table;
-  int32_t* sched;          /* NULL or the block-scheduling counters (see cppf_reslayer_split; not used by mode 1) */
-  const float* prior_pos;  /* decode: the generated prior of cppf_reslayer_split_decode (instead of logit_prior) or NULL */
-  float prior_inv_sigma;
-} CppfReslayerSplit16Args;
-int64_t cppf_reslayer_split16_stream_bytes(int32_t k_in, int32_t n_out, int32_t proj, int32_t chain);
-int cppf_reslayer_split16(const CppfReslayerSplit16Args* args);
 
 /* Batch mode (two HIP streams working on different batches): the cppf_reslayer_split* launches are
  * persistent -- one workgroup per CU holding the CU's whole register file -- so while one runs, no kernel of another stream
  * can start anywhere on the chip.  cppf_mlp_reserve_cus(n) makes every later launch of this process use n fewer CUs (never
  * fewer than half of them); the kernels are power-limited, so 32 fewer CUs cost them ~4 % while the other stream's voting /
  * descriptor kernels run beside them.  Use one CU per shader engine (CUs / 8 = 32 on an MI355X): workgroups are placed
- * round-robin over the engines, and one engine without a free CU stalls the other stream's launch (docs/measurements.md 11.7).  0 (default) = one workgroup per CU.  Results never
- * depend on it.  With the per-device cache of line 18 this is the library's only process-wide state; it is an atomic
- * integer, safe to set from any thread, and applies to launches enqueued afterwards. */
+ * round-robin over the engines, and one engine without a free CU stalls the other stream's launch (docs/measurements.md
+ * 11.7).  0 (default) = one workgroup per CU.  Results never depend on it.  Returns the PREVIOUS reservation (>= 0; ABI 11) so
+ * that nested users restore it instead of zeroing it; a negative argument only queries.  With the per-device cache named in the
+ * conventions above this is the library's only process-wide state; it is an atomic integer, safe to set from any thread, and
+ * applies to launches enqueued afterwards. */
 int cppf_mlp_reserve_cus(int32_t cus);
-
-/* Test hook: workgroups > 0 forces the number of persistent workgroups of every later cppf_reslayer_split* launch of this
- * process (the kernels' results do not depend on it; tests/test_mlp_split.py runs the counted-wait protocol at 1, 7 and all
- * CUs beside a saturating copy stream); 0 restores one workgroup per CU. */
-int cppf_reslayer_split_debug_grid(int32_t workgroups);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# every call through cppf2_amd._lib.load() records its symbol (tests/test_zz_stable_abi_coverage_gpu.py reads _lib.CALLED last)
+os.environ.setdefault("CPPF_ABI_TRACE", "1")
+
 
 BENCH2 = {}      # the bench jobs of a GPU run: {"dir", "proc", "gpus"} (tests/_bench_jobs.py runs them one after another)
 
@@ -31,18 +34,22 @@ def _bench_jobs():
       its 16 gathered records must equal, in global scene order, those of one rank holding all 16 scenes;
     * rccl_one_rank: `bench.py --gpus 1` with CPPF_DIST_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...) and the path's
       all_gather (plus the bench's barrier and all_reduce) really run through RCCL, in a one-rank group;
+    * one_rank_512 / eight_ranks_64: the same at the real run's geometry -- eight ranks of 64 scenes against one rank of 512;
     * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly;
     * two_ranks: plain `python bench.py --gpus 2` (no launcher environment): bench.py starts its two ranks itself; they share GPU 0,
       so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks)."""
     def job(tag, argv, scenes=4, counters=False, **env):
         small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
-                 "--no-native-arith", "--no-voxel-density"] + ([] if counters else ["--no-counters"])
+                 "--no-native-arith", "--no-voxel-density", "--no-prior-variants", "--no-launch-power"] + ([] if counters else ["--no-counters"])
         return {"tag": tag, "argv": argv + small, "env": env}
     one = ["--no-f16x2", "--no-evidence", "--single-stream"]
     return [job("counters", ["--gpus", "1"] + one, counters=True),
             job("one_rank_16", ["--gpus", "1"] + one, scenes=16),
             # (no --no-counters here: the ranks of a multi-rank run must decline the counter passes by themselves)
             job("eight_ranks", ["--gpus", "8"] + one, scenes=2, counters=True, CPPF_BENCH_BACKEND="gloo"),
+            # the same comparison at the batch geometry of the real 8-GPU run (64 scenes per rank = 512 scenes): round 6
+            job("one_rank_512", ["--gpus", "1"] + one, scenes=512),
+            job("eight_ranks_64", ["--gpus", "8"] + one, scenes=64, CPPF_BENCH_BACKEND="gloo"),
             job("rccl_one_rank", ["--gpus", "1"], CPPF_DIST_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
             job("refuse_two_gpus", ["--gpus", "2"]),
             job("two_ranks", ["--gpus", "2"], CPPF_BENCH_BACKEND="gloo")]
@@ -84,7 +91,7 @@ def bench_jobs_finished():
     """The bench jobs run to completion BEFORE the first test: they never share the GPU with a test (waiting is not fork + exec)."""
     proc = BENCH2.get("proc")
     if proc is not None:
-        BENCH2["runner_rc"] = proc.wait(timeout=1500)            # (six jobs of ~15-40 s each; 240 s limit per job in the runner)
+        BENCH2["runner_rc"] = proc.wait(timeout=2000)            # (eight jobs of ~15-60 s each; 240 s limit per job in the runner)
     yield
 
 

@@ -9,21 +9,38 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "cppf_hip.h")).read()
+def _header_symbols(name="cppf_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cppf_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
+    """ABI 11: include/cppf_hip.h (stable) <-> _lib.STABLE and include/cppf_hip_experimental.h <-> _lib.EXPERIMENTAL, symbol by
+    symbol; the library exports all of them and nothing else under the cppf_ prefix."""
+    import subprocess
     from cppf2_amd import _lib
     lib = _lib.load()
-    syms = _header_symbols()
-    assert len(syms) >= 20
-    for s in syms:
+    stable, exper = _header_symbols(), _header_symbols("cppf_hip_experimental.h")
+    assert len(stable) >= 40 and len(exper) >= 10 and not set(stable) & set(exper)
+    for s in stable + exper:
         assert hasattr(lib, s), "missing export " + s
-    assert sorted(_lib.SIGNATURES) == syms, "ctypes signatures out of sync with the header"
-    assert lib.cppf_version() == _lib.ABI_VERSION
+    assert sorted(_lib.STABLE) == stable, "ctypes signatures out of sync with the stable header"
+    assert sorted(_lib.EXPERIMENTAL) == exper, "ctypes signatures out of sync with the experimental header"
+    assert lib.cppf_version() == _lib.ABI_VERSION == 11
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\sT\s+(cppf_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == sorted(stable + exper), "the library exports a cppf_ symbol no header declares (or the reverse)"
+
+
+def test_stable_header_is_free_of_the_bench_only_prior_and_of_superseded_forms():
+    """What moved out of the stable interface in round 6 stays out: the reference has no logit prior (eval.py:225-235), the f16x2
+    arithmetic, the two-kernel encode forms and the test hook are experimental."""
+    src = open(os.path.join(ROOT, "include", "cppf_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for word in ("logit_prior", "prior_pos", "prior_inv_sigma", "Split16", "debug_grid", "_heads", "reslayer128", "sumgather"):
+        assert word not in code, word
+    assert "#define CPPF_ABI_VERSION 11" in src
 
 
 def test_struct_layouts():

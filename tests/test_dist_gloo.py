@@ -10,6 +10,9 @@ import torch.multiprocessing as mp
 
 from cppf2_amd import dist as D
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys  # noqa: E402
+
 
 def _free_port():
     s = socket.socket()
@@ -89,3 +92,57 @@ def test_shard_covers_every_scene_once():
                 assert 0 <= lo <= hi <= n and hi - lo <= D.max_shard(n, world)
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def test_init_times_out_with_rank_backend_and_address_in_the_error():
+    """Round 6 hardening: a rendezvous that cannot complete (rank 1 of 2, nobody listening on the master port) fails within the
+    given timeout -- not torch's 10 minutes -- with a DistInitError naming rank, backend and MASTER_*."""
+    import socket
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cppf2_amd import dist\n"
+            "try:\n"
+            "    dist.init(backend='gloo', timeout_s=4)\n"
+            "except dist.DistInitError as e:\n"
+            "    print('DISTINIT', e); sys.exit(4)\n"
+            "sys.exit(0)\n" % ROOT)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p.returncode == 4, p.stdout[-2000:]
+    assert time.time() - t0 < 60
+    line = [l for l in p.stdout.splitlines() if l.startswith("DISTINIT")][0]
+    for word in ("rank 1/2", "backend gloo", "MASTER_ADDR=127.0.0.1", "MASTER_PORT=%d" % port, "within 4 s"):
+        assert word in line, (word, line)
+
+
+def test_run_ranks_reports_every_rank_and_stops_the_survivors():
+    """benchlib.launch.run_ranks: one rank fails -> the others (which would wait in a collective) are stopped by PID, every rank's
+    exit status and stderr tail are printed, the launcher returns the failing status -- within seconds, not a collective timeout."""
+    import io
+    import time
+    from cppf2_amd.benchlib import launch
+    good = [sys.executable, "-c", "import sys, time; print('rank alive', file=sys.stderr, flush=True); time.sleep(120)"]
+    bad = [sys.executable, "-c", "import sys, time; time.sleep(1); print('RCCL bootstrap: connection refused', file=sys.stderr); sys.exit(3)"]
+    buf = io.StringIO()
+    t0 = time.time()
+    rc = launch.run_ranks([good, bad, good], 1, 29999, timeout_s=60, out=buf)
+    assert rc == 3 and time.time() - t0 < 30
+    text = buf.getvalue()
+    assert "multi-rank run FAILED: rank 1 exited with status 3" in text
+    assert "---- rank 0: exit stopped by the launcher" in text and "rank alive" in text
+    assert "---- rank 1: exit 3" in text and "RCCL bootstrap: connection refused" in text and "---- rank 2:" in text
+    # a run that exceeds its limit is stopped and reported too
+    buf = io.StringIO()
+    t0 = time.time()
+    rc = launch.run_ranks([good, good], 1, 29999, timeout_s=2, out=buf)
+    assert rc != 0 and time.time() - t0 < 30 and "the run exceeded 2 s" in buf.getvalue()
+    # a good run: status 0, rank 0's stderr forwarded
+    ok = [sys.executable, "-c", "import sys; print('note from rank', file=sys.stderr)"]
+    buf = io.StringIO()
+    assert launch.run_ranks([ok, ok], 1, 29999, timeout_s=60, out=buf) == 0 and "note from rank" in buf.getvalue()

@@ -494,8 +494,8 @@ def test_generated_bin_prior_equals_its_array(arith):
     if arith == "split":
         L = _lib.load()
         bins = torch.empty((rows, 6), dtype=torch.int32, device=dev)
-        rc = L.cppf_reslayer_split_decode(ops._p(x), x.stride(0), k, rows, ops._p(wq), wq.numel() * wq.element_size(), ops._p(b1), ops._p(b0),
-                                          ops._p(dense), ops._p(pos), 1.0, ops._p(uni), ops._p(bins), None, ops._stream())
+        rc = L.cppf_reslayer_split_decode_prior(ops._p(x), x.stride(0), k, rows, ops._p(wq), wq.numel() * wq.element_size(), ops._p(b1),
+                                                ops._p(b0), ops._p(dense), ops._p(pos), 1.0, ops._p(uni), ops._p(bins), None, ops._stream())
         assert rc != 0                                                     # an array AND a generator: refused
 
 
@@ -573,11 +573,18 @@ def test_reserved_cus_change_the_grid_not_the_results():
         for cus in (1, ops.batch_mode_reserved_cus(dev), 128, 1000):
             ops.mlp_reserve_cus(cus)
             assert torch.equal(ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=2), ref), cus
+        # ABI 11: the call returns the previous reservation, a negative argument only queries, and the context managers restore
+        # the enclosing block's value instead of zeroing it
+        assert ops.mlp_reserve_cus(7) == 1000 and ops.mlp_reserve_cus(-1) == 7 and L.cppf_mlp_reserve_cus(-3) == 7
         with ops.mlp_cus_reserved():
+            assert ops.mlp_reserve_cus(-1) == ops.batch_mode_reserved_cus(dev)
             assert torch.equal(ops.reslayer_split(x.clone(), wq, b1, b0, n, chain=2), ref)
-        assert L.cppf_mlp_reserve_cus(-1) != 0
-        with pytest.raises(_lib.CppfError):
-            ops.mlp_reserve_cus(-3)
+            from cppf2_amd.pipeline import BatchMode
+            with BatchMode([object(), object()], device=dev, reserve_cus=5):
+                assert ops.mlp_reserve_cus(-1) == 5
+            assert ops.mlp_reserve_cus(-1) == ops.batch_mode_reserved_cus(dev)
+        assert ops.mlp_reserve_cus(-1) == 7
+        assert L.cppf_mlp_reserve_cus(5000) < 0 and ops.mlp_reserve_cus(-1) == 7          # out of range: refused, unchanged
     finally:
         ops.mlp_reserve_cus(0)
 
