@@ -842,13 +842,17 @@ def main():
     if (rank == 0 and world == 1 and tel.proc is not None and not args.no_launch_power and report.GATHERED_TUPLES
             and _models.MLP_ARITH in ("split", "split16")):
         launches = evidence.mlp_launch_loops(step, tel)
+        gemm = evidence.library_bf16_gemm_loop(dev, tel)
         step.run()
         torch.cuda.synchronize()
+    else:
+        gemm = None
     power = tel.finish() if rank == 0 else None
     if power is not None and launches is not None:
-        for l_ in launches:
+        for l_ in launches + [gemm]:
             l_.update({k_: v_ for k_, v_ in (power.get("windows", {}).pop(l_["window"], None) or {}).items() if k_ != "seconds"})
         power["mlp_launches"] = launches
+        power["library_bf16_gemm"] = gemm
 
     if os.environ.get("CPPF_BENCH_PER_STEP") and rank == 0:
         for i_, ev in enumerate(evs):

@@ -120,3 +120,33 @@ def mlp_launch_loops(step, tel, seconds=1.5):
         out.append({"launch": i, "op": name, "chain": kw.get("chain"), "reps": reps, "ms": round(e0.elapsed_time(e1) / reps, 4),
                     "window": wname})
     return out
+
+
+@torch.no_grad()
+def library_bf16_gemm_loop(dev, tel, seconds=1.5, n=8192):
+    """What the bf16 matrix pipe delivers on THIS chip under THIS power cap when nothing but a library GEMM runs: torch.matmul of two
+    n x n bf16 matrices (hipBLASLt), back to back for ~`seconds`, under the telemetry window `library_bf16_gemm`.  The yardstick
+    beside roofline.frac_executed: the MLP kernels issue bf16 MFMA work at frac_executed x the 2.5 PFLOP/s nameplate; the nameplate
+    assumes 2.4 GHz, which no kernel that keeps the matrix pipe busy holds at 1 400 W."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randn((n, n), device=dev, generator=g).to(torch.bfloat16)
+    b = torch.randn((n, n), device=dev, generator=g).to(torch.bfloat16)
+    c = torch.empty((n, n), device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b, out=c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        torch.matmul(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    reps = max(8, int(seconds * 1e3 / max(e0.elapsed_time(e1) / 4, 1e-3)))
+    with tel.window("library_bf16_gemm", torch.cuda.synchronize):
+        e0.record()
+        for _ in range(reps):
+            torch.matmul(a, b, out=c)
+        e1.record()
+    ms = e0.elapsed_time(e1) / reps
+    return {"op": "torch.matmul (hipBLASLt), bf16 x bf16 -> bf16, %d^3, random normal operands" % n, "reps": reps, "ms": round(ms, 4),
+            "tflops": round(2.0 * n ** 3 / 1e12 / (ms / 1e3), 1), "window": "library_bf16_gemm"}

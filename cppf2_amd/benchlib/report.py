@@ -385,7 +385,24 @@ def report_shot(run):
             hbm=hbm))
         for k_ in ("algorithmic_bytes_per_launch", "launch_ms_kind"):
             roofline.pop(k_, None)
-    roofline["power"] = run.get("power")
+    roofline["power"] = power = run.get("power")
+    if power and power.get("mlp_launches"):
+        # the claim DESIGN.md section 5 makes about the dominant kernel, decided by this run's telemetry: each launch form of the
+        # tuple MLP, run back to back on its own, against the socket's power cap
+        fr = [l_.get("power_frac_of_cap", {}).get("mean") for l_ in power["mlp_launches"]]
+        ppt = [l_.get("throttle", {}).get("per_ppt_pwr") for l_ in power["mlp_launches"]]
+        if all(f_ is not None for f_ in fr):
+            power["mlp_power_limit"] = {
+                "claim": "the tuple MLP's launches run at the chip's power limit (so roofline.frac is bounded by energy per flop of the "
+                         "split arithmetic, not by stalls)",
+                "criterion": "every launch form alone draws >= 95 % of the power cap (mean over ~1.5 s back to back)",
+                "power_frac_of_cap_per_launch": fr, "ppt_throttle_residency_percent_per_launch": ppt,
+                "confirmed": bool(min(fr) >= 0.95)}
+        g_ = power.get("library_bf16_gemm")
+        if g_ and g_.get("tflops") and roofline.get("achieved_executed"):
+            # the matrix pipe's practical ceiling on this chip under this cap, measured in this run, beside the MLP's issued rate
+            roofline["frac_executed_vs_library_bf16_gemm"] = round(roofline["achieved_executed"] / g_["tflops"], 4)
+            roofline["frac_vs_library_bf16_gemm"] = round(roofline["achieved"] / g_["tflops"], 4)
     ok = pose_ok_vs_gt(res, step.scenes)
     cpu, agree = run.get("cpu") or (None, None)
     total_scenes = B * world * args.steps
@@ -405,7 +422,8 @@ def report_shot(run):
                                   "every step on one HIP stream" if args.single_stream else
                                   "consecutive steps (different scene batches) alternate between two HIP streams (double-buffered state)",
                                   "float32 operands split exactly into 3 x bf16, 6 exact products on the bf16 matrix cores, "
-                                  "float32 accumulate (float32-equivalent accuracy, tests/test_mlp_split.py)"
+                                  "float32 accumulate (error vs float64 within 3 x a library float32 GEMM's: mlp_error_vs_f64, "
+                                  "tests/test_mlp_split.py)"
                                   if _models.MLP_ARITH == "split" else
                                   ("float32 operands as fp16 pairs (22-23 significant bits), 3 products on the fp16 matrix "
                                    "cores, float32 accumulate (error vs float64 at the library float32 GEMMs' level; NOT exact "

@@ -1,5 +1,5 @@
 // cppf_mlp_split.hip -- the ResLayers of the tuple / point MLPs (train_shot.py:19-45), one or several per kernel, on the
-// bf16 matrix cores, computing in float32-equivalent arithmetic by operand splitting.
+// bf16 matrix cores, computing on float32 operands by splitting them (exact operands, the six largest of the nine products).
 //
 //   y = skip(x) + relu(x W1^T + b1) W2^T,     skip(x) = x  (dim_in == dim_out)   or   x W0^T + b0
 //   [then identity layers of the same width chained behind it:  y <- y + relu(y W1_l^T + b1_l) W2_l^T]
@@ -10,8 +10,10 @@
 // So  a * b = (ah + am + al)(bh + bm + bl)  is evaluated as the six products  ah bh + ah bm + am bh + am bm + ah bl + al bh;
 // the three dropped ones (am bl, al bm, al bl) are below 2^-24 |a b| together, i.e. under half a unit in the last place of
 // the product a float32 FMA chain starts from.  The result is not bit-equal to the f32-input MFMA chain (nor is any
-// re-tiled float32 GEMM); its error against a float64 evaluation is that of the library float32 GEMMs (measured side by
-// side in tests/test_mlp_split.py).  Six bf16 MFMAs replace sixteen f32-input MFMA cycles' worth of work: 2.7x the rate.
+// re-tiled float32 GEMM); its error against a float64 evaluation is of the order of the library float32 GEMMs' -- measured
+// side by side: 2.4 x theirs on the tuple MLP's logits (max 1.96e-6 against 8.0e-7 of the largest logit, bench.py
+// mlp_error_vs_f64), held to e_split < 3 e_library + 2e-7 by tests/test_mlp_split.py: the dropped terms and the six
+// accumulations per product instead of one.  Six bf16 MFMAs replace sixteen f32-input MFMA cycles' worth of work: 2.7x the rate.
 // Non-finite operands: a NaN stays a NaN; an infinite x or weight splits into Inf + NaN, so the rows it touches come out NaN
 // (a float32 GEMM would give +-Inf where no 0 * Inf occurs); magnitudes above the largest bf16 (3.39e38) behave like Inf,
 // and contributions below the float32 normal range may be flushed -- none of which the path's inputs reach (the SHOT

@@ -38,7 +38,7 @@ def _stack(dims):
 
 
 # Arithmetic of the inference MLPs on the GPU: "split" = every ResLayer as one kernel on the bf16 matrix cores with each
-# float32 operand split exactly into three bf16 values (cppf_reslayer_split: float32-equivalent accuracy, 2-3x the rate of
+# float32 operand split exactly into three bf16 values (cppf_reslayer_split: error vs float64 within 3 x a float32 GEMM's, 2-3x the rate of
 # the f32-input matrix instruction); "native" = f32-input matrix cores (library GEMMs + cppf_reslayer128).
 # "split16" = the same kernels in f16x2 arithmetic (fp16 operand pairs, three products: half the matrix-core work, float32-GEMM
 # level error against float64, fp16's operand range; ops.reslayer_split16) -- an option, not the default.
@@ -232,7 +232,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
     """Inference-only execution of a stack of ResLayers (train_shot.py:19-45) on the matrix cores.
     MLP_ARITH == "split" (default): every layer whose shape the kernel covers -- widths 64 / 128 / 192 / 256, input columns
     a multiple of 8 -- runs as ONE cppf_reslayer_split launch together with the identity layers of the same width behind it
-    (the activation stays in registers across the chain); float32-equivalent split-bf16 arithmetic.
+    (the activation stays in registers across the chain); split-bf16 arithmetic on exact float32 operands.
     MLP_ARITH == "native", and layers outside that coverage (the scale head's 64 -> 3 output layer): library GEMMs with the
     elementwise work folded into their epilogues --
       h   = relu(x W1^T + b1)            one GEMM, bias+ReLU epilogue (torch._addmm_activation)
@@ -346,7 +346,7 @@ def fused_stack(seq, x, keep_input=False, gather=None, decode=None, tail=None):
                 and x.data_ptr() % 16 == 0 and x.shape[1] >= w1t.shape[0]
                 and ops.reslayer_split_supported(x.shape[1], n_out, w0t is not None)):
             # the whole layer -- and the identity layers of the same width behind it, while they fit one kernel -- on the
-            # bf16 matrix cores in float32-equivalent split arithmetic; the activation stays in registers across the chain
+            # bf16 matrix cores in split-float32 arithmetic; the activation stays in registers across the chain
             cache = _entry_cache(entry)
             ahead = tap_at is not None and tap_at >= li
 

@@ -336,7 +336,7 @@ def reslayer_split_supported(k_in, n_out, proj, chain=0):
 
 def reslayer_split(x, wq, b1, b0, n_out, out=None, chain=0, tap=None):
     """out = skip(x) + relu(x W1^T + b1) W2^T, then `chain` identity ResLayers of the same width on the result, on the
-    bf16 matrix cores in float32-equivalent split arithmetic (cppf_reslayer_split).  x float32 [rows, k_in] (device; row
+    bf16 matrix cores in split-float32 arithmetic (cppf_reslayer_split: exact bf16 triples, error within 3 x a float32 GEMM's).  x float32 [rows, k_in] (device; row
     stride a multiple of 4 elements), wq the packed split weight stream (models.pack_split), b1 [(1 + chain) * n_out] (the
     layers' first biases), b0 [n_out] or None for an identity skip (then out defaults to x: in place).  Returns out.
     tap: float32 [rows, n_out] buffer that also receives the activation after the FIRST layer (cppf_reslayer_split_tap): the
@@ -613,7 +613,7 @@ def linear_split_supported(k_in, n_out):
 
 
 def linear_split(x, wq, bias, n_out, out=None, scale=None):
-    """out = x W^T + bias, a plain nn.Linear on the matrix cores in float32-equivalent split arithmetic (cppf_linear_split; the
+    """out = x W^T + bias, a plain nn.Linear on the matrix cores in the same split-float32 arithmetic (cppf_linear_split; the
     per-point transforms of the DINO model, train_dino.py:86-87).  x float32 [rows, k_in] (device; row stride a multiple of 4),
     wq = models.pack_linear(W, k_in), bias float32 [n_out] or None, n_out a multiple of 256.
     scale: f16x2 arithmetic (cppf_reslayer_split16, mode 1) with wq / bias packed at that weight scale."""

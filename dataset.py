@@ -1,7 +1,9 @@
 """`dataset` of the reference for the names its entry points import from it (eval.py:7,19,22: id2category, resize_crop, DINOV2;
-train_dino.py:9,165: id2category, generate_target_pairs, rotx/roty/rotz), so those lines resolve unchanged with this repository
-first on sys.path.  The ShapeNet / BlenderProc training datasets (dataset.py:140-412) are outside the voting path;
-the trainers here read the reference's exported items through cppf2_amd.training.ExportedItems.
+train_dino.py:9,165 and train_shot.py:9: ShapeNetExportDataset, id2category, generate_target_pairs, rotx/roty/rotz), so those
+lines resolve unchanged with this repository first on sys.path.  The ShapeNet / BlenderProc rendering datasets
+(dataset.py:140-336, 367-412) are outside the voting path; ShapeNetExportDataset -- the reader of the reference's
+EXPORTED training items, the only dataset class its trainers construct (train_shot.py:148, train_dino.py:159) -- is a thin adapter
+over cppf2_amd.training.ExportedItems.
 """
 import numpy as np
 import torch
@@ -12,6 +14,34 @@ from utils.util import downsample                # noqa: F401  dataset.py:107-11
 
 category2id = {"bottle": 1, "bowl": 2, "camera": 3, "can": 4, "laptop": 5, "mug": 6}          # dataset.py:29-37
 id2category = {v: k for k, v in category2id.items()}
+
+
+class ShapeNetExportDataset(torch.utils.data.Dataset):
+    """dataset.py:338-364: `ShapeNetExportDataset(cfg, full_rot=False)` -- 200 items per epoch, each a pickled dict (pc, pc_canon,
+    desc, bound, shot, normal) drawn from `data/category_training_data[_full_rot]/<cfg.category>/*.pkl` (resolved against the working
+    directory, as hydra.utils.to_absolute_path does).  The reference draws with the unseeded global NumPy generator from the models
+    that survive its blacklist files (data/shapenet_*.txt, data/blacklists.txt: not shipped with the reference); here every file of
+    the directory is a candidate and the draw is seeded by (cfg.seed, item) -- cppf2_amd.training.ExportedItems, which raises
+    FileNotFoundError naming the directory when there are no items.  `cfg.data_dir`, if set, overrides the directory."""
+
+    def __init__(self, cfg, full_rot=False):
+        super().__init__()
+        import os
+        from cppf2_amd.training import ExportedItems
+        self.cfg = cfg
+        self.category = cfg.category
+        get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        self.root = str(get("data_dir") or os.path.abspath(os.path.join(
+            "data", "category_training_data%s" % ("_full_rot" if full_rot else ""), str(cfg.category))))
+        self.items = ExportedItems(self.root, length=200, seed=int(get("seed", 0) or 0))          # dataset.py:362-363: 200
+
+    def __getitem__(self, idx):
+        if idx >= len(self):
+            raise IndexError("Index out of bounds")                                           # dataset.py:355-356
+        return self.items[idx]
+
+    def __len__(self):
+        return len(self.items)
 
 
 def _rot4(a, i, j):

@@ -108,8 +108,9 @@ def _side_streams(dev):
     return _SIDE_STREAMS[key]
 
 
-_PIPES = {}                # batch geometry -> (pipe, twin | None, [scales_buf, scales_buf]); least recently used first
+_PIPES = {}                # batch geometry -> (pipe, twin | None, [scales_buf, scales_buf], workspace bytes); least recently used first
 PIPE_CACHE_MAX = 4
+PIPE_CACHE_BYTES = 16 << 30        # bound on the cached pipelines' vote workspaces (B x cells_cap x 4 bytes each, twice with a twin)
 
 
 def _pipelines(dev, Ns, num_pairs, k, cfg, num_rots, angle_tol, backproj_ratio, imp_wt_margin, cap, two):
@@ -117,21 +118,25 @@ def _pipelines(dev, Ns, num_pairs, k, cfg, num_rots, angle_tol, backproj_ratio, 
     kept from call to call: a streaming evaluation calls run_ensemble once per batch and category, and building a pipeline means
     ~25 device allocations, the workspace, and host-to-device copies of the offsets, sphere bins, bin lookup table and rotation
     table -- per call, before.  Keyed by everything the buffers' sizes and tables depend on; at most PIPE_CACHE_MAX geometries are
-    kept (real batches are ragged: a batch with new point counts builds its own and evicts the oldest).  The buffers of a cached
-    pipeline are overwritten by the next call with the same geometry: a caller that keeps run_ensemble's `pipe` reads it before."""
+    kept, and at most PIPE_CACHE_BYTES of vote workspace (real batches are ragged: a batch with new point counts -- the usual case
+    on REAL275 chunks -- builds its own; the oldest entries are dropped BEFORE the new one is built, so the peak is the bound, not
+    the bound plus one).  The cache pays for repeated geometries: the synthetic mode, the benchmarks, fixed-size crops.  The
+    buffers of a cached pipeline are overwritten by the next call with the same geometry: a caller that keeps run_ensemble's
+    `pipe` reads it before."""
     key = (str(torch.device(dev)), tuple(Ns), int(num_pairs), int(k), float(cfg.res), int(num_rots), float(angle_tol),
            float(backproj_ratio), float(imp_wt_margin), tuple(cfg.up), tuple(cfg.right), tuple(cfg.front), int(cap), bool(two))
     hit = _PIPES.pop(key, None)
     if hit is None:
+        cost = len(Ns) * int(cap) * 4 * (2 if two else 1)
+        while _PIPES and (len(_PIPES) >= PIPE_CACHE_MAX or sum(v[3] for v in _PIPES.values()) + cost > PIPE_CACHE_BYTES):
+            del _PIPES[next(iter(_PIPES))]           # evict first: the new pipeline never coexists with more than the bound
         pipe = VotingPipeline(Ns, [num_pairs] * len(Ns), k=k, res=cfg.res, num_rots=num_rots, angle_tol=angle_tol,
                               backproj_ratio=backproj_ratio, imp_wt_margin=imp_wt_margin, cfg_up=cfg.up,
                               cfg_right=cfg.right, cfg_front=cfg.front, cells_cap=cap)
         bufs = [torch.zeros((pipe.Ttot, 3), dtype=torch.float32, device=dev) for _ in range(2)]
-        hit = (pipe, pipe.twin() if two else None, bufs)
+        hit = (pipe, pipe.twin() if two else None, bufs, cost)
     _PIPES[key] = hit
-    while len(_PIPES) > PIPE_CACHE_MAX:
-        del _PIPES[next(iter(_PIPES))]
-    return hit
+    return hit[:3]
 
 
 @torch.no_grad()

@@ -86,6 +86,10 @@ def test_linear_split_matches_float64_like_a_float32_gemm():
         w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
         b = (torch.randn(n, generator=g) * 0.1).to(dev)
         wq = models.pack_linear(w, k)
+        # the stream's size is the library's (the packer and the kernel agree on the layout), and the loaded library is this ABI
+        from cppf2_amd import _lib
+        assert ops.linear_split_supported(k, n) and wq.numel() * wq.element_size() == _lib.load().cppf_linear_split_stream_bytes(k, n)
+        assert _lib.load().cppf_version() == _lib.ABI_VERSION
         for rows in (1, 31, 257, 3001, 20000):
             x = torch.randn(rows, k, device=dev, generator=torch.Generator(device=dev).manual_seed(rows))
             want = x.double() @ w.double().t() + b.double()

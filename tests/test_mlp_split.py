@@ -1,5 +1,5 @@
 """cppf_reslayer_split: the ResLayers of the tuple / point MLPs (train_shot.py:19-45) on the bf16 matrix cores in
-float32-equivalent split arithmetic.  CPU part: the exact three-way split and the documented weight-stream order;
+split-float32 arithmetic (exact bf16 triples, six products).  CPU part: the exact three-way split and the documented weight-stream order;
 GPU part: the kernel against a float64 evaluation, next to the library float32 path's error against the same."""
 import numpy as np
 import pytest
@@ -106,7 +106,7 @@ def test_reslayer_split_matches_float64_like_a_float32_gemm():
             scale = want.abs().max().item()
             e_split = (got.double() - want).abs().max().item() / scale
             e_nat = (nat.double() - want).abs().max().item() / scale
-            # float32-equivalent: a few units of 2^-24 of the largest output, and no worse than 3x what the library's
+            # float32-GEMM-level: a few units of 2^-24 of the largest output, and no worse than 3x what the library's
             # float32 GEMMs (f32-input matrix cores) leave against the same float64 evaluation
             assert e_split < 2e-6, (k, n, proj, rows, e_split)
             assert e_split < 3.0 * e_nat + 2e-7, (k, n, proj, rows, e_split, e_nat)

@@ -27,6 +27,9 @@ def test_reference_import_lines_resolve_by_name():
     # eval.py:7, 19 (eval.py:22's DINOV2 is checked below: it is a class whose constructor needs the hub weights)
     from dataset import id2category
     from dataset import resize_crop  # noqa: F401
+    # train_dino.py:9 and train_shot.py:9, the literal lines
+    from dataset import ShapeNetExportDataset, id2category  # noqa: F401,F811
+    from dataset import ShapeNetExportDataset  # noqa: F401,F811
     # eval.py:15-18
     from src_shot.build import shot
     from train_dino import vote_center, vote_rotation, generate_target_pairs
@@ -51,6 +54,37 @@ def test_reference_import_lines_resolve_by_name():
     assert shot.compute_color is lib_shot.compute_color
     assert fibonacci_sphere is ops.fibonacci_sphere and callable(compute_degree_cm_mAP) and callable(process_data)
     assert issubclass(DINOV2, torch.nn.Module)
+
+
+def test_shapenet_export_dataset_reads_the_reference_item_layout(tmp_path, monkeypatch):
+    """dataset.py:338-364: ShapeNetExportDataset(cfg) = 200 items per epoch out of <cwd>/data/category_training_data/<category>/
+    {:06d}.pkl, each a dict of float32 arrays; an empty directory fails loudly with its path."""
+    import pickle
+    from types import SimpleNamespace
+    from dataset import ShapeNetExportDataset
+    monkeypatch.chdir(tmp_path)
+    cfg = SimpleNamespace(category=1, seed=3)
+    with pytest.raises(FileNotFoundError, match="category_training_data"):
+        ShapeNetExportDataset(cfg)
+    d = tmp_path / "data" / "category_training_data" / "1"
+    d.mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    for i in range(7):
+        item = dict(pc=rng.rand(100, 3), pc_canon=rng.rand(100, 3) - 0.5, desc=rng.rand(100, 1024), bound=rng.rand(3),
+                    shot=rng.rand(100, 352), normal=rng.rand(100, 3))
+        with open(d / ("%06d.pkl" % i), "wb") as f:
+            pickle.dump({k: v.astype(np.float32) for k, v in item.items()}, f)
+    ds = ShapeNetExportDataset(cfg)
+    assert len(ds) == 200 and isinstance(ds, torch.utils.data.Dataset)
+    it = ds[5]
+    assert sorted(it) == ["bound", "desc", "normal", "pc", "pc_canon", "shot"] and it["shot"].shape == (100, 352) and it["pc"].dtype == torch.float32
+    assert torch.equal(ds[5]["pc"], it["pc"])                      # seeded draw
+    with pytest.raises(IndexError):
+        ds[200]
+    full = tmp_path / "data" / "category_training_data_full_rot" / "1"
+    full.mkdir(parents=True)
+    with pytest.raises(FileNotFoundError, match="_full_rot"):
+        ShapeNetExportDataset(cfg, full_rot=True)
 
 
 def test_real2prob_prob2real_match_the_reference(helpers):
