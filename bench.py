@@ -790,6 +790,13 @@ def main():
                              for i in range(r3_.shape[0]))),
                          "max_abs_scale_difference": float(np.nanmax(np.abs(r16["scale"] - r3_["scale"]))),
                          "max_abs_translation_difference_m": float(np.nanmax(np.abs(r16["t"] - r3_["t"])))}
+        if rank == 0 and oracle_out.get("headline"):
+            # and against the CPU oracle, all scenes of the batch, like the headline arithmetic's oracle_agreement
+            a16 = agreement_shot(step, r16, bins16.reshape(step.B, step.T, 6).cpu().numpy().astype(np.uint8), oracle_out["headline"], pool,
+                                 args.cloud)
+            f16_agreement["oracle"] = {k_: a16[k_] for k_ in ("scenes", "match_5deg5cm", "centre_argmax_equal", "up_bin_equal", "right_bin_equal",
+                                                              "kept_count_equal", "translation_bit_equal", "bin_draws", "bin_draws_differing",
+                                                              "mismatches", "defects")}
     def bins_of(st_):
         return st_.pipe.bins.reshape(st_.B, st_.T, 6).cpu().numpy().astype(np.uint8)
 
