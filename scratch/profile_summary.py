@@ -49,8 +49,13 @@ for k in ("value_reference_order", "value_f32_input_mfma", "value_f16x2_mfma"):
     if b.get(k):
         out.append("| %s | %.0f scenes/s |" % (k, b[k]))
 r = b["roofline"]
-out.append("| value_voxel_density (clouds at 2 mm voxel spacing, one stream) | %.0f scenes/s, %.3f ms per step; descriptor stage %.3f ms |"
-           % (b["value_voxel_density"], b["voxel_density"]["ms_per_step"], b["voxel_density"]["shot_stage_ms"]))
+out.append("| value_voxel_density (clouds at 2 mm voxel spacing, %d stream%s) | %.0f scenes/s, %.3f ms per step; descriptor stage %.3f ms%s |"
+           % (b["voxel_density"].get("streams", 1), "s" if b["voxel_density"].get("streams", 1) > 1 else "", b["value_voxel_density"],
+              b["voxel_density"]["ms_per_step"], b["voxel_density"]["shot_stage_ms"],
+              ("; single stream %.0f" % b["value_voxel_density_single_stream"]) if b.get("value_voxel_density_single_stream") else ""))
+if b.get("value_no_prior"):
+    out.append("| value_no_prior / value_array_prior (the reference has no prior; the prior as a [T, 6, 32] array) | %.0f / %.0f scenes/s |"
+               % (b["value_no_prior"], b["value_array_prior"]))
 out.append("| roofline.frac (tuple MLP: algorithmic float32 flops / time / bf16 MFMA peak) | %.0f TFLOP/s of %.0f = **%.4f**; launch_ms %.3f "
            "(rocprofv3: the three launches' durations in `%s_step_trace.txt`); HBM traffic %.2f GB per step |"
            % (r["achieved"], r["peak"], r["frac"], r["launch_ms"], RND, (r["traffic"] or 0) / 1e9))
@@ -61,7 +66,33 @@ out.append("| roofline.hbm (longest streaming kernel: %s) | %.0f GB/s algorithmi
            % (r["hbm"]["kernel"], r["hbm"]["achieved"], r["hbm"]["frac"]))
 cb = b.get("cpu_baseline")
 if cb:
-    out.append("| cpu_baseline | %.3f scenes/s on %d cores (%s) |" % (cb["value"], cb["cores"], cb["kind"]))
+    out.append("| cpu_baseline | %.3f scenes/s on %d cores (%s)%s |" % (cb["value"], cb["cores"], cb["kind"],
+               ("; all-cores pool %.2f scenes/s over %d workers" % (cb["all_cores_pool"]["value"], cb["all_cores_pool"]["workers"]))
+               if cb.get("all_cores_pool") else ""))
+ag = b.get("oracle_agreement")
+if ag:
+    out.append("| oracle_agreement (every scene of the timed batch recomputed by the CPU oracle) | %d scenes: arg-max equal %d, up / right bins %d / %d, "
+               "kept count %d, translation bits %d; 5deg5cm match %.2f; %d of %d bin draws differ; defects %s |"
+               % (ag["scenes"], ag["centre_argmax_equal"], ag["up_bin_equal"], ag["right_bin_equal"], ag["kept_count_equal"],
+                  ag["translation_bit_equal"], ag["match_5deg5cm"], ag["bin_draws_differing"], ag["bin_draws"], ag["defects"]))
+pw = (b.get("roofline") or {}).get("power") or {}
+if pw.get("available"):
+    w = pw["windows"]
+    out.append("| roofline.power: socket power / cap, shader clock, PPT throttle residency | cap %.0f W; idle %.0f W; two-stream loop %.0f W (%.3f), %.0f MHz, %s %%; "
+               "single-stream loop %.0f W (%.3f) |"
+               % (pw["power_cap_w"], w["idle"]["power_w"]["mean"], w["two_stream_loop"]["power_w"]["mean"],
+                  w["two_stream_loop"]["power_frac_of_cap"]["mean"], w["two_stream_loop"]["sclk_mhz"]["mean"],
+                  w["two_stream_loop"].get("throttle", {}).get("per_ppt_pwr"), w["single_stream_loop"]["power_w"]["mean"],
+                  w["single_stream_loop"]["power_frac_of_cap"]["mean"]))
+    for l_ in pw.get("mlp_launches", []):
+        out.append("| roofline.power.mlp_launches[%d] (`%s`, alone, back to back) | %.3f ms; %.0f W = %.3f of the cap; %.0f MHz; PPT residency %s %% |"
+                   % (l_["launch"], l_["op"], l_["ms"], l_["power_w"]["mean"], l_["power_frac_of_cap"]["mean"], l_["sclk_mhz"]["mean"],
+                      l_.get("throttle", {}).get("per_ppt_pwr")))
+    if pw.get("library_bf16_gemm"):
+        g_ = pw["library_bf16_gemm"]
+        out.append("| library bf16 GEMM under the same telemetry (hipBLASLt, 8192^3) | %.0f TFLOP/s; %.0f W = %.3f of the cap; %.0f MHz; the MLP issues %.3f of it |"
+                   % (g_["tflops"], g_["power_w"]["mean"], g_["power_frac_of_cap"]["mean"], g_["sclk_mhz"]["mean"],
+                      b["roofline"].get("frac_executed_vs_library_bf16_gemm") or float("nan")))
 out.append("\n## Kernels of a single-stream step (rocprofv3 averages)\n")
 out.append("| kernel | launches / step | avg us | us / step |\n|---|---|---|---|")
 tot = 0.0
