@@ -38,12 +38,18 @@ def _bench_jobs():
     * refuse_two_gpus: plain `python bench.py --gpus 2` over RCCL on this one-GPU box must fail loudly;
     * two_ranks: plain `python bench.py --gpus 2` (no launcher environment): bench.py starts its two ranks itself; they share GPU 0,
       so the backend is gloo (CPPF_BENCH_BACKEND, the dry-run switch: one GPU cannot host two RCCL ranks)."""
-    def job(tag, argv, scenes=4, counters=False, **env):
-        small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", "0", "--no-reference-order",
+    def job(tag, argv, scenes=4, counters=False, cpu_scenes=0, **env):
+        small = ["--steps", "1", "--warmup", "0", "--scenes-per-gpu", str(scenes), "--cpu-scenes", str(cpu_scenes), "--no-reference-order",
                  "--no-native-arith", "--no-voxel-density", "--no-prior-variants", "--no-launch-power"] + ([] if counters else ["--no-counters"])
         return {"tag": tag, "argv": argv + small, "env": env}
     one = ["--no-f16x2", "--no-evidence", "--single-stream"]
-    return [job("counters", ["--gpus", "1"] + one, counters=True),
+    # agreement: the default run's evidence legs at a small batch -- the oracle worker pool (every scene of the batch recomputed on the
+    # CPU by fresh `bench.py --oracle-worker` children started before the GPU is touched), the power / clock telemetry child with the
+    # per-launch MLP loops and the library GEMM yardstick, the prior-variant loops, the voxel-density loop with ITS agreement
+    agreement = {"tag": "agreement", "env": {},
+                 "argv": ["--gpus", "1", "--steps", "2", "--warmup", "1", "--scenes-per-gpu", "4", "--cpu-scenes", "1", "--agreement-voxel-scenes", "2",
+                          "--no-reference-order", "--no-native-arith", "--no-counters", "--no-evidence"]}
+    return [agreement, job("counters", ["--gpus", "1"] + one, counters=True),
             job("one_rank_16", ["--gpus", "1"] + one, scenes=16),
             # (no --no-counters here: the ranks of a multi-rank run must decline the counter passes by themselves)
             job("eight_ranks", ["--gpus", "8"] + one, scenes=2, counters=True, CPPF_BENCH_BACKEND="gloo"),

@@ -43,6 +43,18 @@ def test_stable_header_is_free_of_the_bench_only_prior_and_of_superseded_forms()
     assert "#define CPPF_ABI_VERSION 11" in src
 
 
+def test_documents_state_the_interface_they_describe():
+    """DESIGN.md / INTEGRATION.md / README.md name the ABI version and the sizes of the two interface parts the headers really have."""
+    from cppf2_amd import _lib
+    n_stable, n_exp = len(_lib.STABLE), len(_lib.EXPERIMENTAL)
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        assert "ABI %d" % _lib.ABI_VERSION in text, doc
+        assert "%d entry points" % n_stable in text or "%d stable entry points" % n_stable in text, (doc, n_stable)
+        assert str(n_exp) in text, (doc, n_exp)
+    assert "cppf_hip_experimental.h" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+
 def test_struct_layouts():
     from cppf2_amd import _lib
     from cppf2_amd.pipeline import RESULT_DTYPE

@@ -128,6 +128,39 @@ def _job(name):
     return bench_job(name)
 
 
+def test_bench_agreement_pool_telemetry_and_prior_variants():
+    """The default run's round-6 legs on the GPU box at a small batch: `oracle_agreement` covers EVERY scene of the batch (worker
+    pool) with all-equal records and the workers' weights identical to the GPU run's; the voxel-density loop has its own; the f16x2
+    loop too; `roofline.power` carries per-window power / clock, the three MLP launch forms, the library GEMM yardstick and the
+    power-limit verdict; value_no_prior / value_array_prior are measured; the CPU baseline states its stages' threads."""
+    rc, out, err = _job("agreement")
+    assert rc == 0, err[-3000:]
+    j = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert j["ok"] and not j["problems"]
+    ag = j["oracle_agreement"]
+    assert ag["scenes"] == 4 == ag["centre_argmax_equal"] == ag["up_bin_equal"] == ag["right_bin_equal"] == ag["kept_count_equal"] == ag["translation_bit_equal"]
+    assert ag["match_5deg5cm"] == 1.0 and ag["defects"] == [] and ag["weights_identical_to_the_gpu_run"] and ag["workers_agree_on_weights"]
+    assert ag["bin_draws"] == 4 * 20000 * 6 and ag["bin_draws_differing"] <= 4 and "pool_error" not in ag
+    va = j["voxel_density"]["oracle_agreement"]
+    assert va["scenes"] == 2 == va["centre_argmax_equal"] == va["up_bin_equal"] == va["right_bin_equal"] and va["defects"] == []
+    assert j["voxel_density"]["streams"] == 2 and j["voxel_density"]["records_identical_to_single_stream"] is True
+    assert j["value_voxel_density_single_stream"] > 0 and j["value_no_prior"] > 0 and j["value_array_prior"] > 0
+    fo = j["f16x2_agreement"]["oracle"]
+    assert fo["scenes"] == 4 == fo["centre_argmax_equal"] and fo["defects"] == []
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["shot_single_thread_s_per_scene"] >= cb["shot_all_cores_s_per_scene"] > 0
+    assert cb["all_cores_pool"]["scenes"] == 6 and "get_topk_dir (C + OpenMP, oracle/vote_oracle.c)" in cb["threads_per_stage"]
+    pw = j["roofline"]["power"]
+    if pw.get("available"):                     # (a box without readable hwmon files reports why instead)
+        assert pw["power_cap_w"] > 0 and {"idle", "two_stream_loop", "single_stream_loop"} <= set(pw["windows"])
+        assert len(pw["mlp_launches"]) == 3 and all(l_["ms"] > 0 and l_["power_w"]["mean"] > pw["windows"]["idle"]["power_w"]["mean"] for l_ in pw["mlp_launches"])
+        assert [l_["op"] for l_ in pw["mlp_launches"]] == ["reslayer_split_encode", "reslayer_split", "reslayer_split_decode"]
+        assert pw["library_bf16_gemm"]["tflops"] > 100 and isinstance(pw["mlp_power_limit"]["confirmed"], bool)
+        assert 0.3 < j["roofline"]["frac_executed_vs_library_bf16_gemm"] < 1.5
+    else:
+        assert pw.get("reason")
+
+
 def test_bench_two_ranks_on_one_gpu():
     """Plain `python bench.py --gpus 2`: bench.py starts both ranks itself (fresh processes, gloo because they share GPU 0)."""
     rc, out, err = _job("two_ranks")
