@@ -524,6 +524,13 @@ def run_other_workload(args, rank, world, dev, backend, timer, pool, tel):
 def start_oracle_pool(args, rank, world):
     """The agreement check's workers -- started before anything initialises the GPU.  Returns an OraclePool (maybe empty)."""
     pool = OraclePool(args)
+    if rank == 0 and world == 1 and args.cpu_scenes > 0 and not args.counter_child:
+        # the checker's C parts are loaded (and, if a source is newer than its library, rebuilt with make) HERE, before this process
+        # initialises the GPU: the CPU legs below must never have to start a child process afterwards
+        from oracle import shot_oracle as S_
+        from oracle import vote_oracle as V_
+        S_._load()
+        V_._load()
     if rank != 0 or world != 1 or args.cpu_scenes <= 0 or args.agreement_scenes <= 0 or args.counter_child:
         return pool
     B = args.scenes_per_gpu
